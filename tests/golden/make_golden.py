@@ -1,0 +1,309 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors that pin oracle/ (run in the BUILD container only).
+
+Imports the reference's own model files from /root/reference/src/model (they depend only on
+torch), loads the build's deterministic weights (oracle.detinit) into them, and records
+outputs and gradients as small .npz fixtures next to this script.  The reference's source
+never travels: only these arrays do.  Loss compositions of main_{pretrain,warmup,optimize}.py
+are restated here on top of the *reference modules* (the stage scripts themselves need
+pytorch_lightning 0.6, which is not installable).
+
+Usage:  python tests/golden/make_golden.py            (writes tests/golden/*.npz)
+"""
+import os
+import random
+import sys
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, REPO)
+sys.path.insert(0, "/root/reference/src")
+
+from oracle.detinit import det_state_dict, det_tensor, det_tokens  # noqa: E402
+
+import model.rnn as ref_rnn  # noqa: E402
+import model.mlm as ref_mlm  # noqa: E402
+import model.match as ref_match  # noqa: E402
+import model.classifier as ref_cls  # noqa: E402
+import model.discriminator as ref_disc  # noqa: E402
+
+torch.set_num_threads(4)
+torch.manual_seed(0)
+
+from oracle.configs import CONFIGS  # noqa: E402
+
+
+def set_constants(c):
+    ref_mlm.d_model = ref_match.d_model = c["d_model"]
+    ref_mlm.n_head = ref_match.n_head = c["n_head"]
+    ref_mlm.n_layer = ref_match.n_layer = c["n_layer"]
+    ref_rnn.d_embed, ref_rnn.d_enc, ref_rnn.d_dec, ref_rnn.p_drop = c["g_embed"], c["g_enc"], c["g_dec"], 0.0
+    ref_cls.d_embed, ref_cls.kernel_number, ref_cls.p_drop = c["c_embed"], c["c_filters"], 0.0
+    ref_disc.embed_dim, ref_disc.num_rep, ref_disc.dis_num_filters = c["d_embed"], c["d_rep"], c["d_filters"]
+
+
+def zero_dropout(m):
+    for s in m.modules():
+        if isinstance(s, nn.Dropout):
+            s.p = 0.0
+        if isinstance(s, nn.MultiheadAttention):
+            s.dropout = 0.0
+    return m
+
+
+def load_det(m, seed):
+    sd = det_state_dict({k: v.shape for k, v in m.state_dict().items()}, seed)
+    m.load_state_dict(sd)
+    return m
+
+
+def build(c):
+    set_constants(c)
+    V = c["V"]
+    G = load_det(zero_dropout(ref_rnn.DenoiseLSTM(V, 2, c["max_len"])), 1)
+    C = load_det(zero_dropout(ref_cls.TextCNN(V, 2)), 2)
+    Mt = load_det(zero_dropout(ref_match.Matcher(V)), 3)
+    Dn = load_det(zero_dropout(ref_mlm.MLM(V, 2)), 4)
+    D = load_det(zero_dropout(ref_disc.RelGAN_D(V, dropout=0.0)), 5)
+    for m in (G, C, Mt, Dn, D):
+        m.train()
+    return G, C, Mt, Dn, D
+
+
+def np32(t):
+    return t.detach().cpu().numpy().astype(np.float32)
+
+
+def grads_of(loss, module, prefix, out, soft=None):
+    module.zero_grad()
+    if soft is not None:
+        soft.grad = None
+    loss.backward()
+    for k, p in module.named_parameters():
+        if p.grad is not None:
+            out[f"{prefix}.grad.{k}"] = np32(p.grad)
+    if soft is not None:
+        out[f"{prefix}.grad.__input__"] = np32(soft.grad)
+
+
+def soft_input(B, L, V, seed):
+    logits = det_tensor(f"soft{seed}", (B, L, V), seed, scale=2.0)
+    return torch.softmax(logits, -1).detach().requires_grad_(True)
+
+
+def coins_for(seed, T):
+    """The coin sequence DenoiseLSTM.forward draws (rnn.py:91) after random.seed(seed)."""
+    random.seed(seed)
+    return [random.random() < 1 / 2 for _ in range(T)]
+
+
+def module_goldens(name, c):
+    out = {}
+    G, C, Mt, Dn, D = build(c)
+    V, B, L = c["V"], c["B"], c["L"]
+    x = det_tokens(B, L, V, 0)
+    x2 = det_tokens(B, L - 1, V, 1)
+    nx = det_tokens(B, L - 1, V, 2)
+    labels = torch.tensor([i % 2 for i in range(B)], dtype=torch.long)
+    out["x"], out["x2"], out["nx"], out["labels"] = x.numpy(), x2.numpy(), nx.numpy(), labels.numpy()
+
+    def lossw(key, t):
+        return (t * det_tensor(key, t.shape, 9, scale=1.0)).sum()
+
+    # -- TextCNN ---------------------------------------------------------------------------
+    y = C(x)
+    out["cls.ids.out"] = np32(y)
+    grads_of(lossw("cls.ids", y), C, "cls.ids", out)
+    sp = soft_input(B, L, V, 11)
+    y = C(sp)
+    out["cls.soft.out"] = np32(y)
+    grads_of(lossw("cls.soft", y), C, "cls.soft", out, sp)
+
+    # -- MLM -------------------------------------------------------------------------------
+    y = Dn(x)
+    out["mlm.ids.out"] = np32(y)
+    grads_of(lossw("mlm.ids", y), Dn, "mlm.ids", out)
+    sp = soft_input(B, L, V, 12)
+    y = Dn(sp)
+    out["mlm.soft.out"] = np32(y)
+    grads_of(lossw("mlm.soft", y), Dn, "mlm.soft", out, sp)
+
+    # -- Matcher ---------------------------------------------------------------------------
+    y = Mt(x, x2)
+    out["mat.ids.out"] = np32(y)
+    grads_of(lossw("mat.ids", y), Mt, "mat.ids", out)
+    sp = soft_input(B, L, V, 13)
+    y = Mt(sp, x)
+    out["mat.soft.out"] = np32(y)
+    grads_of(lossw("mat.soft", y), Mt, "mat.soft", out, sp)
+
+    # -- RelGAN_D --------------------------------------------------------------------------
+    sp = soft_input(B, L, V, 14)
+    y = D(sp)
+    out["disc.soft.out"] = np32(y)
+    grads_of(lossw("disc.soft", y), D, "disc.soft", out, sp)
+    y = D(F.one_hot(x, V).float())
+    out["disc.onehot.out"] = np32(y)
+    grads_of(lossw("disc.onehot", y), D, "disc.onehot", out)
+
+    # -- DenoiseLSTM -----------------------------------------------------------------------
+    # (a) teacher forcing with the recorded coin sequence (res_type "none")
+    coins = coins_for(123, L)
+    out["gen.tf.coins"] = np.array(coins, dtype=np.int64)
+    random.seed(123)
+    y = G(nx, labels, x, labels)
+    out["gen.tf.out"] = np32(y)
+    grads_of(lossw("gen.tf", y), G, "gen.tf", out)
+    # (b) softmax / straight-through mode, free running for max_len steps
+    y = G(x, labels, None, 1 - labels, res_type="softmax", tau=0.1)
+    out["gen.soft.out"] = np32(y)
+    grads_of(lossw("gen.soft", y), G, "gen.soft", out)
+    # (b') a warmer temperature keeps more of the distribution alive in the gradient
+    y = G(x, labels, None, 1 - labels, res_type="softmax", tau=1.0)
+    out["gen.soft1.out"] = np32(y)
+    grads_of(lossw("gen.soft1", y), G, "gen.soft1", out)
+    # (c) greedy free run -> exact ids (main_optimize.py:157-164)
+    with torch.no_grad():
+        G.eval()
+        y = G(x, labels, None, 1 - labels)
+        G.train()
+    out["gen.greedy.ids"] = y.argmax(-1).numpy()
+    out["gen.greedy.out"] = np32(y)
+    # (d) 3-D (soft) encoder input, teacher forced
+    sp = soft_input(B, L, V, 15)
+    random.seed(321)
+    out["gen.soft_in.coins"] = np.array(coins_for(321, L), dtype=np.int64)
+    random.seed(321)
+    y = G(sp, labels, x, labels)
+    out["gen.soft_in.out"] = np32(y)
+    grads_of(lossw("gen.soft_in", y), G, "gen.soft_in", out, sp)
+    return out
+
+
+def gnorm(params):
+    return float(torch.sqrt(sum((p.grad.detach() ** 2).sum() for p in params if p.grad is not None)))
+
+
+def step_goldens(name, c):
+    """Single-step losses of the three stages, composed from the reference modules exactly as
+    main_pretrain.py:66-77, main_warmup.py:45-58 and main_optimize.py:93-124 do."""
+    out = {}
+    G, C, Mt, Dn, D = build(c)
+    V, B, L = c["V"], c["B"], c["L"]
+    ce, mse, bce = nn.CrossEntropyLoss(), nn.MSELoss(), nn.BCEWithLogitsLoss()
+    x = det_tokens(B, L, V, 20)
+    nx1 = det_tokens(B, L, V, 21)
+    nx2 = det_tokens(B, L - 1, V, 22)
+    nx3 = det_tokens(B, L, V, 23)
+    labels = torch.tensor([(i + 1) % 2 for i in range(B)], dtype=torch.long)
+    c_label = torch.from_numpy(np.random.RandomState(5).uniform(0, 1.5, size=(B,)).astype(np.float32))
+    for k, v in dict(x=x, nx1=nx1, nx2=nx2, nx3=nx3, labels=labels, c_label=c_label).items():
+        out[k] = v.numpy()
+
+    # ---- pretrain ----------------------------------------------------------------------
+    s_loss = ce(C(x), labels)
+    c_loss = mse(Mt(nx1, nx2), c_label)
+    dn_logits = Dn(nx3)
+    dn_loss = ce(dn_logits.reshape(-1, dn_logits.size(-1)), x.reshape(-1))
+    for m in (C, Mt, Dn):
+        m.zero_grad()
+    (s_loss + c_loss + dn_loss).backward()
+    out["pretrain.losses"] = np.array([s_loss.item(), c_loss.item(), dn_loss.item()], dtype=np.float64)
+    out["pretrain.gnorm"] = np.array([gnorm(C.parameters()), gnorm(Mt.parameters()), gnorm(Dn.parameters())])
+
+    # ---- warmup ------------------------------------------------------------------------
+    out["warmup.coins"] = np.array(coins_for(77, L), dtype=np.int64)
+    random.seed(77)
+    logits = G(nx2, labels, x, labels)
+    w_loss = ce(logits.reshape(-1, logits.size(-1)), x.reshape(-1))
+    G.zero_grad()
+    w_loss.backward()
+    out["warmup.loss"] = np.array([w_loss.item()])
+    out["warmup.gnorm"] = np.array([gnorm(G.parameters())])
+
+    # ---- optimize: generator step ----------------------------------------------------
+    hp = dict(w_s=0.1, w_c=0.5, w_adv=1.0, w_bt=1.0, tau=0.1, gap=0.0)
+    for m in (G, C, Mt, Dn, D):
+        m.zero_grad()
+    out["optimize.coins"] = np.array(coins_for(99, L), dtype=np.int64)
+    sample_p = G(x, labels, None, 1 - labels, res_type="softmax", tau=hp["tau"])
+    s_logits = C(sample_p)
+    c_logits = Mt(sample_p, x)
+    D.eval()
+    adv_logits = D(sample_p)
+    random.seed(99)
+    bk_logits = G(sample_p.argmax(-1), 1 - labels, x, labels)
+    s_loss = ce(s_logits, 1 - labels)
+    c_loss = mse(c_logits, c_logits.new_full([c_logits.size(0)], hp["gap"]))
+    g_loss = bce(adv_logits, adv_logits.new_full(adv_logits.shape, 1))
+    bk_loss = ce(bk_logits.reshape(-1, bk_logits.size(-1)), x.reshape(-1))
+    loss = hp["w_bt"] * bk_loss + hp["w_c"] * c_loss + hp["w_adv"] * g_loss + hp["w_s"] * s_loss
+    loss.backward()
+    out["optimize.g.losses"] = np.array([loss.item(), g_loss.item(), s_loss.item(),
+                                         c_logits.mean().item(), bk_loss.item()])
+    out["optimize.g.gnorm"] = np.array([gnorm(G.parameters())])
+    out["optimize.g.sample_ids"] = sample_p.argmax(-1).numpy()
+    out["optimize.g.grad.fn_1.bias"] = np32(G.fn_1.bias.grad)
+    out["optimize.g.grad.style_embedding.weight"] = np32(G.style_embedding.weight.grad)
+
+    # ---- optimize: discriminator step ------------------------------------------------
+    for m in (G, D):
+        m.zero_grad()
+    D.train()
+    t_logits = D(F.one_hot(x, V).float())
+    with torch.no_grad():
+        x_ = G(x, labels, None, 1 - labels, res_type="softmax", tau=hp["tau"])
+    f_logits = D(x_)
+    d_loss = 0.5 * (bce(t_logits, t_logits.new_full(t_logits.shape, 1))
+                    + bce(f_logits, f_logits.new_full(f_logits.shape, 0)))
+    (hp["w_adv"] * d_loss).backward()
+    out["optimize.d.losses"] = np.array([d_loss.item()])
+    out["optimize.d.gnorm"] = np.array([gnorm(D.parameters())])
+
+    # ---- optimize: validation_step (main_optimize.py:127-141) ------------------------
+    with torch.no_grad():
+        for m in (G, C, Mt, Dn):
+            m.eval()
+        sp = G(x, labels, None, 1 - labels, res_type="softmax", tau=hp["tau"])
+        tokens = sp.argmax(-1)
+        s = ce(C(tokens), 1 - labels)
+        cl = Mt(tokens, x)
+        nt = Dn(tokens)
+        nt_loss = ce(nt.reshape(-1, nt.size(-1)), tokens.reshape(-1))
+        out["optimize.val"] = np.array([(nt_loss + s + cl.mean()).item()])
+    return out
+
+
+def main():
+    for name, c in CONFIGS.items():
+        mg = module_goldens(name, c)
+        # keep fixtures small: big gradient arrays are replaced by their L2 norm and a
+        # strided sample (every 97th / 1009th element); small ones are stored whole
+        limit = 4096 if name == "ref" else 16384
+        slim = {}
+        for k, v in mg.items():
+            if ".grad." in k and v.size > limit:
+                slim[k.replace(".grad.", ".gradnorm.")] = np.array([np.sqrt((v.astype(np.float64) ** 2).sum())])
+                slim[k.replace(".grad.", ".gradsample.")] = v.reshape(-1)[::(1009 if name == "ref" else 97)].copy()
+            else:
+                slim[k] = v
+        mg = slim
+        np.savez_compressed(os.path.join(HERE, f"modules_{name}.npz"), **mg)
+        # the checkpoint compatibility surface: every state_dict key and shape
+        import json
+        mods = dict(zip(("G", "cls", "mat", "dn", "disc"), build(c)))
+        with open(os.path.join(HERE, f"state_dict_shapes_{name}.json"), "w") as f:
+            json.dump({n: {k: list(v.shape) for k, v in m.state_dict().items()} for n, m in mods.items()},
+                      f, indent=0, sort_keys=True)
+        sg = step_goldens(name, c)
+        np.savez_compressed(os.path.join(HERE, f"steps_{name}.npz"), **sg)
+        print(name, "modules:", len(mg), "arrays;", "steps:", len(sg), "arrays")
+
+
+if __name__ == "__main__":
+    main()
