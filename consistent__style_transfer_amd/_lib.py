@@ -1,0 +1,99 @@
+"""ctypes binding of libcst_hip.so -- the only route from the Python host code to compute.
+
+There is NO fallback: if the shared library is missing or a symbol of include/cst_hip.h is not
+exported, importing this module raises.  Prototypes are parsed from the header, so the header is
+the single source of truth for the ABI.
+"""
+import ctypes
+import os
+import re
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libcst_hip.so")
+HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "cst_hip.h")
+
+_CT = {
+    "int": ctypes.c_int, "long": ctypes.c_long, "float": ctypes.c_float,
+    "uint32_t": ctypes.c_uint32,
+}
+
+
+def parse_header(path=HEADER_PATH):
+    """-> {name: (restype, [argtypes])} for every prototype in include/cst_hip.h."""
+    with open(path) as f:
+        text = f.read()
+    text = re.sub(r"/\*.*?\*/", " ", text, flags=re.S)
+    protos = {}
+    for m in re.finditer(r"(const\s+char\s*\*|int|long)\s+(cst_\w+)\s*\(([^)]*)\)\s*;", text, flags=re.S):
+        ret, name, args = m.group(1), m.group(2), m.group(3)
+        restype = ctypes.c_char_p if "char" in ret else _CT[ret.strip()]
+        argtypes = []
+        for a in [s.strip() for s in args.split(",")]:
+            if not a or a == "void":
+                continue
+            if "*" in a:
+                argtypes.append(ctypes.c_void_p)
+            else:
+                argtypes.append(_CT[a.split()[-2] if len(a.split()) > 1 else a])
+        protos[name] = (restype, argtypes)
+    return protos
+
+
+class _Lib:
+    def __init__(self):
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} is missing: the HIP extension has not been built. Run "
+                "`python -c 'import __graft_entry__ as g; g.build()'` (hipcc --offload-arch=gfx950). "
+                "There is no CPU fallback for the product path.")
+        self.cdll = ctypes.CDLL(LIB_PATH)
+        self.protos = parse_header()
+        self.fn = {}
+        for name, (restype, argtypes) in self.protos.items():
+            try:
+                f = getattr(self.cdll, name)
+            except AttributeError as e:
+                raise ImportError(f"libcst_hip.so does not export {name} declared in include/cst_hip.h") from e
+            f.restype = restype
+            f.argtypes = argtypes
+            self.fn[name] = f
+
+    def last_error(self):
+        return self.fn["cst_last_error"]().decode()
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        _lib = _Lib()
+    return _lib
+
+
+def _ptr(x):
+    if x is None:
+        return None
+    if isinstance(x, torch.Tensor):
+        return x.data_ptr()
+    return x
+
+
+def stream_ptr():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def call(name, *args):
+    """Invoke an int-status entry point on torch's current stream; raise on a non-zero status."""
+    L = lib()
+    rc = L.fn[name](*[_ptr(a) for a in args], stream_ptr())
+    if rc != 0:
+        raise RuntimeError(f"{name} failed (status {rc}): {L.last_error()}")
+
+
+def call_plain(name, *args):
+    """Entry points without a stream / status (workspace queries)."""
+    return lib().fn[name](*[_ptr(a) for a in args])

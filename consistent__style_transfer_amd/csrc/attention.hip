@@ -1,0 +1,315 @@
+// Attention kernels for gfx950 (exact fp32 VALU; tiles are tiny: S <= 64 keys).
+//
+//  (1) Unmasked multi-head self-attention core of nn.TransformerEncoderLayer as the reference
+//      configures it (mlm.py:20-22, match.py:18-20; no mask is ever passed, mlm.py:43,
+//      match.py:39): per (batch row, head), P = softmax(Q K^T / sqrt(hd)), attention dropout on
+//      P, O = P V.  S = L (MLM) or L1+L2 (Matcher) <= 64.
+//      One 256-thread workgroup per (b, h); its 4 wavefronts share the head's K/V.  In the
+//      forward each lane keeps one key row (scores) and one value column (output) in registers
+//      and a wave exchanges the probability row through LDS; softmax reductions are wavefront
+//      shuffles.  The backward stages Q, K, V, dO and the S x S matrices P and dS in LDS.
+//  (2) Single-query dot-product attention of the generator's decoder (rnn.py:46-50, called at
+//      rnn.py:76): one workgroup per batch row, memory (L' <= 64 rows of D) streamed once.
+#include "cst_common.h"
+
+#define MHA_SMAX 64
+
+// ---------------------------------------------------------------------------------------------
+// MHA forward.  qkv [B,S,3d] (q | k | v thirds, heads interleaved inside each third as torch's
+// packed in_proj does), out [B,S,d], lse [B,H,S].
+// ---------------------------------------------------------------------------------------------
+template <int HD>
+__global__ __launch_bounds__(256) void mha_fwd_kernel(const float* __restrict__ qkv, float* __restrict__ out,
+                                                      float* __restrict__ lse, int S, int H, float scale, CstDrop drop) {
+    constexpr int HD4 = HD / 4;
+    constexpr int NC = (HD + 63) / 64;                 // output columns per lane
+    __shared__ __attribute__((aligned(16))) float Qs[MHA_SMAX * HD];
+    __shared__ __attribute__((aligned(16))) float Ps[4][MHA_SMAX];
+    const int b = blockIdx.x / H, h = blockIdx.x % H;
+    const int d = H * HD;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const float* base = qkv + (long)b * S * 3 * d + h * HD;
+
+    // Q tile -> LDS (coalesced over the head dimension)
+    for (int e = threadIdx.x; e < S * HD; e += 256) {
+        const int i = e / HD, c = e % HD;
+        Qs[i * HD + c] = base[(long)i * 3 * d + c];
+    }
+    // key row `lane` -> registers
+    float kreg[HD];
+    if (lane < S) {
+        const float* kp = base + (long)lane * 3 * d + d;
+#pragma unroll
+        for (int c = 0; c < HD; ++c) kreg[c] = kp[c];
+    } else {
+#pragma unroll
+        for (int c = 0; c < HD; ++c) kreg[c] = 0.f;
+    }
+    // value columns lane (+64) -> registers, all S keys
+    float vreg[NC][MHA_SMAX];
+#pragma unroll
+    for (int cc = 0; cc < NC; ++cc) {
+        const int c = lane + 64 * cc;
+#pragma unroll
+        for (int j = 0; j < MHA_SMAX; ++j)
+            vreg[cc][j] = (j < S && c < HD) ? base[(long)j * 3 * d + 2 * d + c] : 0.f;
+    }
+    __syncthreads();
+    const uint32_t dseed = drop.p > 0.f ? cst_drop_seed(drop) : 0u;
+
+    for (int i = w; i < S; i += 4) {
+        float s = 0.f;
+#pragma unroll
+        for (int c4 = 0; c4 < HD4; ++c4) {
+            const float4 q = *reinterpret_cast<const float4*>(&Qs[i * HD + c4 * 4]);
+            s += q.x * kreg[c4 * 4 + 0] + q.y * kreg[c4 * 4 + 1] + q.z * kreg[c4 * 4 + 2] + q.w * kreg[c4 * 4 + 3];
+        }
+        s = (lane < S) ? s * scale : -INFINITY;
+        const float m = wave_max(s);
+        const float e = (lane < S) ? expf(s - m) : 0.f;
+        const float sum = wave_sum(e);
+        float p = e / sum;
+        if (lane == 0) lse[((long)b * H + h) * S + i] = m + logf(sum);
+        if (drop.p > 0.f && lane < S)
+            p *= cst_drop_mask(drop, dseed, (uint32_t)((((long)b * H + h) * S + i) * S + lane));
+        Ps[w][lane] = p;
+        __builtin_amdgcn_wave_barrier();
+        // O[i][c] = sum_j P[i][j] V[j][c]; this wave's own LDS row, lanes now index columns
+        float o[NC];
+#pragma unroll
+        for (int cc = 0; cc < NC; ++cc) o[cc] = 0.f;
+#pragma unroll
+        for (int j4 = 0; j4 < MHA_SMAX / 4; ++j4) {
+            if (j4 * 4 < S) {
+                const float4 pj = *reinterpret_cast<const float4*>(&Ps[w][j4 * 4]);
+#pragma unroll
+                for (int cc = 0; cc < NC; ++cc)
+                    o[cc] += pj.x * vreg[cc][j4 * 4 + 0] + pj.y * vreg[cc][j4 * 4 + 1] + pj.z * vreg[cc][j4 * 4 + 2] + pj.w * vreg[cc][j4 * 4 + 3];
+            }
+        }
+#pragma unroll
+        for (int cc = 0; cc < NC; ++cc) {
+            const int c = lane + 64 * cc;
+            if (c < HD) out[((long)b * S + i) * d + h * HD + c] = o[cc];
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+extern "C" int cst_mha_fwd(const float* qkv, float* out, float* lse, int B, int S, int H, int hd,
+                           float drop_p, uint32_t drop_seed, uint32_t drop_stream, const void* drop_seed_dev,
+                           void* stream) {
+    CST_REQUIRE(qkv && out && lse, "cst_mha_fwd: null pointer");
+    CST_REQUIRE(B > 0 && S > 0 && S <= MHA_SMAX && H > 0, "cst_mha_fwd: S=%d unsupported (max %d)", S, MHA_SMAX);
+    CstDrop dr = cst_make_drop(drop_p, drop_seed, drop_stream, drop_seed_dev);
+    const float scale = 1.0f / sqrtf((float)hd);
+    dim3 grid(B * H), block(256);
+    hipStream_t st = (hipStream_t)stream;
+    switch (hd) {
+        case 8: hipLaunchKernelGGL((mha_fwd_kernel<8>), grid, block, 0, st, qkv, out, lse, S, H, scale, dr); break;
+        case 32: hipLaunchKernelGGL((mha_fwd_kernel<32>), grid, block, 0, st, qkv, out, lse, S, H, scale, dr); break;
+        case 64: hipLaunchKernelGGL((mha_fwd_kernel<64>), grid, block, 0, st, qkv, out, lse, S, H, scale, dr); break;
+        case 96: hipLaunchKernelGGL((mha_fwd_kernel<96>), grid, block, 0, st, qkv, out, lse, S, H, scale, dr); break;
+        default: cst_set_error("cst_mha_fwd: head dim %d unsupported (8, 32, 64, 96)", hd); return CST_ERR_ARG;
+    }
+    CST_LAUNCH_CHECK("cst_mha_fwd");
+    return CST_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// MHA backward: recompute P from Q, K and the saved log-sum-exp, then
+//   dV = Pd^T dO ; dPd = dO V^T ; dS = P o (dP - rowsum(dP o P)) * scale ; dQ = dS K ; dK = dS^T Q
+// with Pd the dropped probabilities.  dqkv [B,S,3d].
+// ---------------------------------------------------------------------------------------------
+template <int HD>
+__global__ __launch_bounds__(256) void mha_bwd_kernel(const float* __restrict__ qkv, const float* __restrict__ dout,
+                                                      const float* __restrict__ lse, float* __restrict__ dqkv,
+                                                      int S, int H, float scale, CstDrop drop) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int HD4 = HD / 4;
+    const int SP = S + 1;
+    float* Qs = smem;                    // [S][HD]
+    float* Ks = Qs + S * HD;             // [S][HD]
+    float* Vs = Ks + S * HD;             // [S][HD]
+    float* Os = Vs + S * HD;             // [S][HD]  (dO)
+    float* Pm = Os + S * HD;             // [S][S+1] dropped probabilities
+    float* Dm = Pm + S * SP;             // [S][S+1] dS
+    const int b = blockIdx.x / H, h = blockIdx.x % H;
+    const int d = H * HD;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const float* base = qkv + (long)b * S * 3 * d + h * HD;
+    const float* dob = dout + (long)b * S * d + h * HD;
+    for (int e = threadIdx.x; e < S * HD; e += 256) {
+        const int i = e / HD, c = e % HD;
+        Qs[e] = base[(long)i * 3 * d + c];
+        Ks[e] = base[(long)i * 3 * d + d + c];
+        Vs[e] = base[(long)i * 3 * d + 2 * d + c];
+        Os[e] = dob[(long)i * d + c];
+    }
+    __syncthreads();
+    // pass 1: lane = key j; key and value rows in registers
+    float kreg[HD], vreg[HD];
+#pragma unroll
+    for (int c = 0; c < HD; ++c) {
+        kreg[c] = (lane < S) ? Ks[lane * HD + c] : 0.f;
+        vreg[c] = (lane < S) ? Vs[lane * HD + c] : 0.f;
+    }
+    const uint32_t dseed = drop.p > 0.f ? cst_drop_seed(drop) : 0u;
+    for (int i = w; i < S; i += 4) {
+        float s = 0.f, dpd = 0.f;
+#pragma unroll
+        for (int c4 = 0; c4 < HD4; ++c4) {
+            const float4 q = *reinterpret_cast<const float4*>(&Qs[i * HD + c4 * 4]);
+            const float4 g = *reinterpret_cast<const float4*>(&Os[i * HD + c4 * 4]);
+            s += q.x * kreg[c4 * 4 + 0] + q.y * kreg[c4 * 4 + 1] + q.z * kreg[c4 * 4 + 2] + q.w * kreg[c4 * 4 + 3];
+            dpd += g.x * vreg[c4 * 4 + 0] + g.y * vreg[c4 * 4 + 1] + g.z * vreg[c4 * 4 + 2] + g.w * vreg[c4 * 4 + 3];
+        }
+        const float l = lse[((long)b * H + h) * S + i];
+        const float p = (lane < S) ? expf(s * scale - l) : 0.f;
+        float mask = 1.f;
+        if (drop.p > 0.f && lane < S)
+            mask = cst_drop_mask(drop, dseed, (uint32_t)((((long)b * H + h) * S + i) * S + lane));
+        const float dp = (lane < S) ? dpd * mask : 0.f;
+        const float delta = wave_sum(dp * p);
+        if (lane < S) {
+            Pm[i * SP + lane] = p * mask;
+            Dm[i * SP + lane] = p * (dp - delta) * scale;
+        }
+    }
+    __syncthreads();
+    // pass 2: lane = head-dim column c
+    float* dq = dqkv + (long)b * S * 3 * d + h * HD;
+    for (int c = lane; c < HD; c += 64) {
+        for (int i = w; i < S; i += 4) {
+            float aq = 0.f, ak = 0.f, av = 0.f;
+            for (int j = 0; j < S; ++j) {
+                aq += Dm[i * SP + j] * Ks[j * HD + c];       // dQ[i][c]
+                ak += Dm[j * SP + i] * Qs[j * HD + c];       // dK[i][c] = sum_j dS[j][i] Q[j][c]
+                av += Pm[j * SP + i] * Os[j * HD + c];       // dV[i][c] = sum_j Pd[j][i] dO[j][c]
+            }
+            dq[(long)i * 3 * d + c] = aq;
+            dq[(long)i * 3 * d + d + c] = ak;
+            dq[(long)i * 3 * d + 2 * d + c] = av;
+        }
+    }
+}
+
+extern "C" int cst_mha_bwd(const float* qkv, const float* dout, const float* lse, float* dqkv,
+                           int B, int S, int H, int hd,
+                           float drop_p, uint32_t drop_seed, uint32_t drop_stream, const void* drop_seed_dev,
+                           void* stream) {
+    CST_REQUIRE(qkv && dout && lse && dqkv, "cst_mha_bwd: null pointer");
+    CST_REQUIRE(B > 0 && S > 0 && S <= MHA_SMAX && H > 0, "cst_mha_bwd: S=%d unsupported (max %d)", S, MHA_SMAX);
+    CstDrop dr = cst_make_drop(drop_p, drop_seed, drop_stream, drop_seed_dev);
+    const float scale = 1.0f / sqrtf((float)hd);
+    const size_t lds = sizeof(float) * ((size_t)4 * S * hd + (size_t)2 * S * (S + 1));
+    CST_REQUIRE(lds <= 160 * 1024, "cst_mha_bwd: LDS need %zu exceeds 160 KiB", lds);
+    dim3 grid(B * H), block(256);
+    hipStream_t st = (hipStream_t)stream;
+#define MHA_BWD_CASE(HDV)                                                                                         \
+    case HDV: {                                                                                                   \
+        if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)mha_bwd_kernel<HDV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL((mha_bwd_kernel<HDV>), grid, block, lds, st, qkv, dout, lse, dqkv, S, H, scale, dr);   \
+        break;                                                                                                    \
+    }
+    switch (hd) {
+        MHA_BWD_CASE(8) MHA_BWD_CASE(32) MHA_BWD_CASE(64) MHA_BWD_CASE(96)
+        default: cst_set_error("cst_mha_bwd: head dim %d unsupported (8, 32, 64, 96)", hd); return CST_ERR_ARG;
+    }
+#undef MHA_BWD_CASE
+    CST_LAUNCH_CHECK("cst_mha_bwd");
+    return CST_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Single-query attention, forward.  q [B, ldq] (D used), mem [B,L,D], out [B, ldo], p [B,L].
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void dot_attn_fwd_kernel(const float* __restrict__ q, long ldq,
+                                                           const float* __restrict__ mem, float* __restrict__ out, long ldo,
+                                                           float* __restrict__ p, int L, int D, float scale) {
+    __shared__ float sc[MHA_SMAX];
+    const int b = blockIdx.x, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const float* qb = q + (long)b * ldq;
+    const float* mb = mem + (long)b * L * D;
+    for (int j = w; j < L; j += 4) {
+        float s = 0.f;
+        for (int c = lane; c < D; c += 64) s += qb[c] * mb[(long)j * D + c];
+        s = wave_sum(s);
+        if (lane == 0) sc[j] = s * scale;
+    }
+    __syncthreads();
+    float m = -INFINITY;
+    for (int j = 0; j < L; ++j) m = fmaxf(m, sc[j]);
+    float sum = 0.f;
+    for (int j = 0; j < L; ++j) sum += expf(sc[j] - m);
+    __syncthreads();
+    if (threadIdx.x < L) {
+        const float pj = expf(sc[threadIdx.x] - m) / sum;
+        sc[threadIdx.x] = pj;
+        p[(long)b * L + threadIdx.x] = pj;
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < D; c += 256) {
+        float o = 0.f;
+        for (int j = 0; j < L; ++j) o += sc[j] * mb[(long)j * D + c];
+        out[(long)b * ldo + c] = o;
+    }
+}
+
+extern "C" int cst_dot_attn_fwd(const float* q, long ldq, const float* mem, float* out, long ldo, float* p,
+                                int B, int L, int D, void* stream) {
+    CST_REQUIRE(q && mem && out && p, "cst_dot_attn_fwd: null pointer");
+    CST_REQUIRE(B > 0 && L > 0 && L <= MHA_SMAX && D > 0, "cst_dot_attn_fwd: L=%d unsupported (max %d)", L, MHA_SMAX);
+    hipLaunchKernelGGL(dot_attn_fwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, q, ldq, mem, out, ldo, p, L, D,
+                       1.0f / sqrtf((float)D));
+    CST_LAUNCH_CHECK("cst_dot_attn_fwd");
+    return CST_OK;
+}
+
+// backward: dq (+)= sum_j ds_j mem_j ; dmem[j] += p_j dout + ds_j q   (dmem accumulates over steps)
+__global__ __launch_bounds__(256) void dot_attn_bwd_kernel(const float* __restrict__ dout, long lddo,
+                                                           const float* __restrict__ q, long ldq,
+                                                           const float* __restrict__ mem, const float* __restrict__ p,
+                                                           float* __restrict__ dq, long lddq, int dq_accumulate,
+                                                           float* __restrict__ dmem, int L, int D, float scale) {
+    __shared__ float ds[MHA_SMAX];
+    __shared__ float ps[MHA_SMAX];
+    const int b = blockIdx.x, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const float* gb = dout + (long)b * lddo;
+    const float* qb = q + (long)b * ldq;
+    const float* mb = mem + (long)b * L * D;
+    for (int j = w; j < L; j += 4) {
+        float s = 0.f;
+        for (int c = lane; c < D; c += 64) s += gb[c] * mb[(long)j * D + c];
+        s = wave_sum(s);
+        if (lane == 0) ds[j] = s;          // dp_j
+    }
+    if (threadIdx.x < L) ps[threadIdx.x] = p[(long)b * L + threadIdx.x];
+    __syncthreads();
+    float delta = 0.f;
+    for (int j = 0; j < L; ++j) delta += ds[j] * ps[j];
+    __syncthreads();
+    if (threadIdx.x < L) ds[threadIdx.x] = ps[threadIdx.x] * (ds[threadIdx.x] - delta) * scale;
+    __syncthreads();
+    float* dmb = dmem + (long)b * L * D;
+    for (int c = threadIdx.x; c < D; c += 256) {
+        const float g = gb[c], qc = qb[c];
+        float a = 0.f;
+        for (int j = 0; j < L; ++j) {
+            a += ds[j] * mb[(long)j * D + c];
+            dmb[(long)j * D + c] += ps[j] * g + ds[j] * qc;
+        }
+        float* o = dq + (long)b * lddq + c;
+        *o = dq_accumulate ? *o + a : a;
+    }
+}
+
+extern "C" int cst_dot_attn_bwd(const float* dout, long lddo, const float* q, long ldq, const float* mem, const float* p,
+                                float* dq, long lddq, int dq_accumulate, float* dmem, int B, int L, int D, void* stream) {
+    CST_REQUIRE(dout && q && mem && p && dq && dmem, "cst_dot_attn_bwd: null pointer");
+    CST_REQUIRE(B > 0 && L > 0 && L <= MHA_SMAX && D > 0, "cst_dot_attn_bwd: L=%d unsupported (max %d)", L, MHA_SMAX);
+    hipLaunchKernelGGL(dot_attn_bwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, dout, lddo, q, ldq, mem, p,
+                       dq, lddq, dq_accumulate, dmem, L, D, 1.0f / sqrtf((float)D));
+    CST_LAUNCH_CHECK("cst_dot_attn_bwd");
+    return CST_OK;
+}

@@ -1,0 +1,109 @@
+// Shared helpers for the gfx950 kernels of libcst_hip.so (internal header, not the C ABI:
+// the ABI is include/cst_hip.h).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#define CST_OK 0
+#define CST_ERR_ARG 1
+#define CST_ERR_LAUNCH 2
+
+void cst_set_error(const char* fmt, ...);
+
+#define CST_REQUIRE(cond, ...)                 \
+    do {                                       \
+        if (!(cond)) {                         \
+            cst_set_error(__VA_ARGS__);        \
+            return CST_ERR_ARG;                \
+        }                                      \
+    } while (0)
+
+#define CST_LAUNCH_CHECK(name)                                                    \
+    do {                                                                          \
+        hipError_t e__ = hipGetLastError();                                       \
+        if (e__ != hipSuccess) {                                                  \
+            cst_set_error("%s: launch failed: %s", name, hipGetErrorString(e__)); \
+            return CST_ERR_LAUNCH;                                                \
+        }                                                                         \
+    } while (0)
+
+#define CST_WAVE 64
+
+// ---- dropout RNG contract (mirrors oracle/rng.py bit for bit) --------------------------------
+__host__ __device__ __forceinline__ uint32_t cst_mix32(uint32_t seed, uint32_t stream, uint32_t idx) {
+    uint32_t x = idx ^ (stream * 0x9E3779B1u);
+    x = x * 0x85EBCA6Bu + seed;
+    x ^= x >> 16;
+    x *= 0x7FEB352Du;
+    x ^= x >> 15;
+    x *= 0x846CA68Bu;
+    x ^= x >> 16;
+    return x;
+}
+
+struct CstDrop {          // p == 0 -> disabled
+    float p;              // drop probability
+    float scale;          // 1/(1-p)
+    uint32_t thresh;      // floor(p * 2^24)
+    uint32_t seed;        // host part of the seed
+    uint32_t stream;      // call-site id
+    const uint32_t* seed_dev;   // optional device word added to seed (graph replay)
+};
+
+static inline CstDrop cst_make_drop(float p, uint32_t seed, uint32_t stream, const void* seed_dev) {
+    CstDrop d;
+    d.p = p;
+    d.scale = p > 0.f ? 1.0f / (1.0f - p) : 1.0f;
+    d.thresh = p > 0.f ? (uint32_t)floorf(p * 16777216.0f) : 0u;
+    d.seed = seed;
+    d.stream = stream;
+    d.seed_dev = (const uint32_t*)seed_dev;
+    return d;
+}
+
+__device__ __forceinline__ uint32_t cst_drop_seed(const CstDrop& d) {
+    return d.seed + (d.seed_dev ? *d.seed_dev : 0u);
+}
+
+__device__ __forceinline__ float cst_drop_mask(const CstDrop& d, uint32_t seed, uint32_t idx) {
+    return ((cst_mix32(seed, d.stream, idx) >> 8) >= d.thresh) ? d.scale : 0.0f;
+}
+
+// ---- wave / block reductions -----------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// block-wide reductions for blockDim.x multiple of 64, <= 1024.  `red` is >= 16 floats of LDS.
+__device__ __forceinline__ float block_sum(float v, float* red) {
+    v = wave_sum(v);
+    const int w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[w] = v;
+    __syncthreads();
+    float r = 0.f;
+    for (int i = 0; i < nw; ++i) r += red[i];
+    return r;
+}
+__device__ __forceinline__ float block_max(float v, float* red) {
+    v = wave_max(v);
+    const int w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[w] = v;
+    __syncthreads();
+    float r = red[0];
+    for (int i = 1; i < nw; ++i) r = fmaxf(r, red[i]);
+    return r;
+}
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
+
+static inline int cst_div_up(long a, long b) { return (int)((a + b - 1) / b); }

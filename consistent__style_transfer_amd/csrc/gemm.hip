@@ -1,0 +1,319 @@
+// MFMA GEMM for gfx950:  C[M,N] = epilogue( alpha * op(A)[M,K] . op(B)[K,N] )
+//
+// Every dense contraction of the hot path goes through this kernel: QKV / out-proj / FFN
+// projections of the encoder layers (mlm.py:20-22, match.py:18-20), the vocabulary
+// projections (mlm.py:24, rnn.py:38), the soft-input embedding products (rnn.py:61,85,
+// mlm.py:31, match.py:28, classifier.py:27, discriminator.py:39), the LSTM gate projections
+// (rnn.py:25-33), the im2col'ed convolutions and the highway layer -- forward, dgrad and wgrad.
+//
+// Operand layouts (fp32 in HBM, row-major with a leading dimension):
+//   A "K-major"  : A[m*lda + k]      (an activation matrix used as is)
+//   A "MN-major" : A[k*lda + m]      (the same matrix used transposed: wgrad)
+//   B "K-major"  : B[n*ldb + k]      (a torch Linear weight [out,in] used as is: forward)
+//   B "MN-major" : B[k*ldb + n]      (the weight used transposed: dgrad; activations in wgrad)
+// so no operand is ever transposed in HBM.  Tiles are staged global -> registers -> LDS as
+// [row][k] images (k contiguous, padded) whatever the HBM layout; MN-major tiles are transposed
+// in registers (4x4 patches) on the way.  Two arithmetic modes:
+//   bf16 : v_mfma_f32_16x16x32_bf16, operands rounded to bf16 while staging, fp32 accumulate
+//   f32  : v_mfma_f32_16x16x4_f32, exact fp32 products (the parity mode)
+// 256 threads = 4 waves in a 2x2 grid; tile BMxBN = 128x128 or 64x64, BK = 32.
+#include "cst_common.h"
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+typedef __attribute__((ext_vector_type(8))) unsigned short u16x8_t;
+
+struct GemmArgs {
+    const float* A; const float* B; float* C;
+    const float* bias;      // [N] or null
+    const float* addend;    // [M, ldadd] or null (added before the activation)
+    const float* aux;       // [M, ldaux] gate source for act 3/4
+    long lda, ldb, ldc, ldadd, ldaux;
+    long sA, sB, sC, sBias, sAdd, sAux;   // batch strides (elements)
+    int M, N, K;
+    int act;                // 0 none, 1 relu, 2 leaky(0.1), 3 gate aux>0 ? v*gate_scale : 0, 4 gate aux>0 ? v : 0.1 v
+    int accumulate;         // C += result
+    int vecA, vecB;         // 16-byte vector loads legal for this operand
+    float alpha, gate_scale;
+    CstDrop drop;           // epilogue dropout over the logical [M,N] index space
+};
+
+__device__ __forceinline__ unsigned short f2bf(float f) {
+    // round-to-nearest-even; NaN stays NaN via the hardware convert
+    __bf16 b = (__bf16)f;
+    return __builtin_bit_cast(unsigned short, b);
+}
+
+constexpr int BK = 32;
+
+template <bool F32> struct LdsElem { typedef unsigned short type; static constexpr int PAD = 8; };
+template <> struct LdsElem<true> { typedef float type; static constexpr int PAD = 4; };
+
+// ---- global -> register staging --------------------------------------------------------------
+// K-major operand: tile [ROWS][BK]; each thread owns float4 chunks along k.
+template <int ROWS>
+struct StageK {
+    static constexpr int CHUNKS = ROWS * (BK / 4);            // float4 chunks in the tile
+    static constexpr int PER_T = (CHUNKS + 255) / 256;
+    float4 v[PER_T];
+    __device__ __forceinline__ void load(const float* __restrict__ P, long ld, int row0, int k0, int rows, int K, int vec) {
+#pragma unroll
+        for (int i = 0; i < PER_T; ++i) {
+            const int idx = threadIdx.x + 256 * i;
+            const int r = idx / (BK / 4), c = (idx % (BK / 4)) * 4;
+            float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (idx < CHUNKS && row0 + r < rows) {
+                const float* p = P + (long)(row0 + r) * ld + k0 + c;
+                if (vec && k0 + c + 3 < K) {
+                    t = *reinterpret_cast<const float4*>(p);
+                } else {
+                    if (k0 + c + 0 < K) t.x = p[0];
+                    if (k0 + c + 1 < K) t.y = p[1];
+                    if (k0 + c + 2 < K) t.z = p[2];
+                    if (k0 + c + 3 < K) t.w = p[3];
+                }
+            }
+            v[i] = t;
+        }
+    }
+    template <bool F32, int LDS_LD>
+    __device__ __forceinline__ void store(typename LdsElem<F32>::type* S) {
+#pragma unroll
+        for (int i = 0; i < PER_T; ++i) {
+            const int idx = threadIdx.x + 256 * i;
+            if (idx < CHUNKS) {
+                const int r = idx / (BK / 4), c = (idx % (BK / 4)) * 4;
+                if constexpr (F32) {
+                    *reinterpret_cast<float4*>(&S[r * LDS_LD + c]) = v[i];
+                } else {
+                    uint2 pk;
+                    pk.x = (uint32_t)f2bf(v[i].x) | ((uint32_t)f2bf(v[i].y) << 16);
+                    pk.y = (uint32_t)f2bf(v[i].z) | ((uint32_t)f2bf(v[i].w) << 16);
+                    *reinterpret_cast<uint2*>(&S[r * LDS_LD + c]) = pk;
+                }
+            }
+        }
+    }
+};
+
+// MN-major operand: HBM tile is [BK][ROWS] (rows contiguous); each thread owns 4(k) x 4(row)
+// patches, loaded as 4 float4 along the contiguous dimension and transposed in registers.
+template <int ROWS>
+struct StageMN {
+    static constexpr int PATCHES = (BK / 4) * (ROWS / 4);
+    static constexpr int PER_T = (PATCHES + 255) / 256;
+    float4 v[PER_T][4];
+    __device__ __forceinline__ void load(const float* __restrict__ P, long ld, int row0, int k0, int rows, int K, int vec) {
+#pragma unroll
+        for (int i = 0; i < PER_T; ++i) {
+            const int p = threadIdx.x + 256 * i;
+            const int rg = (p % (ROWS / 4)) * 4, kg = (p / (ROWS / 4)) * 4;
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (p < PATCHES && k0 + kg + kk < K) {
+                    const float* q = P + (long)(k0 + kg + kk) * ld + row0 + rg;
+                    if (vec && row0 + rg + 3 < rows) {
+                        t = *reinterpret_cast<const float4*>(q);
+                    } else {
+                        if (row0 + rg + 0 < rows) t.x = q[0];
+                        if (row0 + rg + 1 < rows) t.y = q[1];
+                        if (row0 + rg + 2 < rows) t.z = q[2];
+                        if (row0 + rg + 3 < rows) t.w = q[3];
+                    }
+                }
+                v[i][kk] = t;
+            }
+        }
+    }
+    template <bool F32, int LDS_LD>
+    __device__ __forceinline__ void store(typename LdsElem<F32>::type* S) {
+#pragma unroll
+        for (int i = 0; i < PER_T; ++i) {
+            const int p = threadIdx.x + 256 * i;
+            if (p < PATCHES) {
+                const int rg = (p % (ROWS / 4)) * 4, kg = (p / (ROWS / 4)) * 4;
+                const float a[4][4] = {{v[i][0].x, v[i][1].x, v[i][2].x, v[i][3].x},
+                                       {v[i][0].y, v[i][1].y, v[i][2].y, v[i][3].y},
+                                       {v[i][0].z, v[i][1].z, v[i][2].z, v[i][3].z},
+                                       {v[i][0].w, v[i][1].w, v[i][2].w, v[i][3].w}};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if constexpr (F32) {
+                        *reinterpret_cast<float4*>(&S[(rg + j) * LDS_LD + kg]) = make_float4(a[j][0], a[j][1], a[j][2], a[j][3]);
+                    } else {
+                        uint2 pk;
+                        pk.x = (uint32_t)f2bf(a[j][0]) | ((uint32_t)f2bf(a[j][1]) << 16);
+                        pk.y = (uint32_t)f2bf(a[j][2]) | ((uint32_t)f2bf(a[j][3]) << 16);
+                        *reinterpret_cast<uint2*>(&S[(rg + j) * LDS_LD + kg]) = pk;
+                    }
+                }
+            }
+        }
+    }
+};
+
+template <int ROWS, bool KMAJ> struct StageSel { typedef StageK<ROWS> type; };
+template <int ROWS> struct StageSel<ROWS, false> { typedef StageMN<ROWS> type; };
+
+template <int BM, int BN, bool F32, bool A_KMAJ, bool B_KMAJ>
+__global__ __launch_bounds__(256) void cst_gemm_kernel(GemmArgs g) {
+    typedef typename LdsElem<F32>::type elem_t;
+    constexpr int LDS_LD = BK + LdsElem<F32>::PAD;
+    constexpr int TM = BM / 32, TN = BN / 32;      // 16x16 tiles per wave in each direction
+    __shared__ __attribute__((aligned(16))) elem_t As[BM * LDS_LD];
+    __shared__ __attribute__((aligned(16))) elem_t Bs[BN * LDS_LD];
+
+    const int tilesM = (g.M + BM - 1) / BM;
+    const int tm = blockIdx.x % tilesM, tn = blockIdx.x / tilesM;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const long bz = blockIdx.z;
+    const float* A = g.A + bz * g.sA;
+    const float* B = g.B + bz * g.sB;
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int lr = lane & 15, lq = lane >> 4;
+
+    f32x4_t acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+    typename StageSel<BM, A_KMAJ>::type sa;
+    typename StageSel<BN, B_KMAJ>::type sb;
+    sa.load(A, g.lda, m0, 0, g.M, g.K, g.vecA);
+    sb.load(B, g.ldb, n0, 0, g.N, g.K, g.vecB);
+
+    const int nk = (g.K + BK - 1) / BK;
+    for (int kt = 0; kt < nk; ++kt) {
+        sa.template store<F32, LDS_LD>(As);
+        sb.template store<F32, LDS_LD>(Bs);
+        __syncthreads();
+        if (kt + 1 < nk) {
+            sa.load(A, g.lda, m0, (kt + 1) * BK, g.M, g.K, g.vecA);
+            sb.load(B, g.ldb, n0, (kt + 1) * BK, g.N, g.K, g.vecB);
+        }
+        if constexpr (!F32) {
+            bf16x8_t af[TM], bfr[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+                af[i] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u16x8_t*>(&As[(wm * (BM / 2) + i * 16 + lr) * LDS_LD + lq * 8]));
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                bfr[j] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u16x8_t*>(&Bs[(wn * (BN / 2) + j * 16 + lr) * LDS_LD + lq * 8]));
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+        } else {
+            // k order inside the tile is permuted identically for A and B: MFMA (kk,e) consumes
+            // k = 16*kk + 4*lq + e from lane group lq -- each k exactly once.
+#pragma unroll
+            for (int kk = 0; kk < BK / 16; ++kk) {
+                float4 af[TM], bfr[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+                    af[i] = *reinterpret_cast<const float4*>(&As[(wm * (BM / 2) + i * 16 + lr) * LDS_LD + kk * 16 + lq * 4]);
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    bfr[j] = *reinterpret_cast<const float4*>(&Bs[(wn * (BN / 2) + j * 16 + lr) * LDS_LD + kk * 16 + lq * 4]);
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i].x, bfr[j].x, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i].y, bfr[j].y, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i].z, bfr[j].z, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i].w, bfr[j].w, acc[i][j], 0, 0, 0);
+                    }
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue: C/D layout of the 16x16 MFMA: col = lane&15, row = 4*(lane>>4) + reg ----
+    float* C = g.C + bz * g.sC;
+    const float* bias = g.bias ? g.bias + bz * g.sBias : nullptr;
+    const float* addend = g.addend ? g.addend + bz * g.sAdd : nullptr;
+    const float* aux = g.aux ? g.aux + bz * g.sAux : nullptr;
+    const uint32_t dseed = g.drop.p > 0.f ? cst_drop_seed(g.drop) : 0u;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = n0 + wn * (BN / 2) + j * 16 + lr;
+            if (n >= g.N) continue;
+            const float bv = bias ? bias[n] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = m0 + wm * (BM / 2) + i * 16 + lq * 4 + r;
+                if (m >= g.M) continue;
+                float v = g.alpha * acc[i][j][r] + bv;
+                if (addend) v += addend[(long)m * g.ldadd + n];
+                if (g.act == 1) v = v > 0.f ? v : 0.f;
+                else if (g.act == 2) v = v > 0.f ? v : 0.1f * v;
+                else if (g.act == 3) v = aux[(long)m * g.ldaux + n] > 0.f ? v * g.gate_scale : 0.f;
+                else if (g.act == 4) v = aux[(long)m * g.ldaux + n] > 0.f ? v : 0.1f * v;
+                if (g.drop.p > 0.f) v *= cst_drop_mask(g.drop, dseed, (uint32_t)((long)m * g.N + n + bz * (long)g.M * g.N));
+                float* cp = C + (long)m * g.ldc + n;
+                if (g.accumulate) v += *cp;
+                *cp = v;
+            }
+        }
+    }
+}
+
+template <int BM, int BN>
+static void launch_cfg(const GemmArgs& g, int f32, int akm, int bkm, int batch, hipStream_t st) {
+    dim3 grid(cst_div_up(g.M, BM) * cst_div_up(g.N, BN), 1, batch), block(256);
+#define CST_GEMM_CASE(F, AK, BKM)                                                              \
+    if (f32 == F && akm == AK && bkm == BKM) {                                                 \
+        hipLaunchKernelGGL((cst_gemm_kernel<BM, BN, (bool)F, (bool)AK, (bool)BKM>), grid, block, 0, st, g); \
+        return;                                                                                \
+    }
+    CST_GEMM_CASE(0, 1, 1) CST_GEMM_CASE(0, 1, 0) CST_GEMM_CASE(0, 0, 1) CST_GEMM_CASE(0, 0, 0)
+    CST_GEMM_CASE(1, 1, 1) CST_GEMM_CASE(1, 1, 0) CST_GEMM_CASE(1, 0, 1) CST_GEMM_CASE(1, 0, 0)
+#undef CST_GEMM_CASE
+}
+
+static int vec_ok(const float* p, long ld, long stride) {
+    return (((uintptr_t)p & 15) == 0) && (ld % 4 == 0) && (stride % 4 == 0);
+}
+
+extern "C" int cst_gemm(const float* A, long lda, int a_kmajor, const float* B, long ldb, int b_kmajor,
+                        float* C, long ldc, int M, int N, int K,
+                        const float* bias, const float* addend, long ldadd,
+                        const float* aux, long ldaux, int act, float gate_scale,
+                        int accumulate, float alpha, int precision_f32,
+                        int batch, long sA, long sB, long sC, long sBias, long sAdd, long sAux,
+                        float drop_p, uint32_t drop_seed, uint32_t drop_stream, const void* drop_seed_dev,
+                        int tile, void* stream) {
+    CST_REQUIRE(A && B && C, "cst_gemm: null operand");
+    CST_REQUIRE(M > 0 && N > 0 && K > 0 && batch > 0, "cst_gemm: bad shape M=%d N=%d K=%d batch=%d", M, N, K, batch);
+    CST_REQUIRE(lda >= (a_kmajor ? K : M), "cst_gemm: lda=%ld too small", lda);
+    CST_REQUIRE(ldb >= (b_kmajor ? K : N), "cst_gemm: ldb=%ld too small", ldb);
+    CST_REQUIRE(ldc >= N, "cst_gemm: ldc=%ld < N=%d", ldc, N);
+    CST_REQUIRE(act >= 0 && act <= 4, "cst_gemm: bad act %d", act);
+    CST_REQUIRE(!(act >= 3) || aux, "cst_gemm: gate activation needs aux");
+    CST_REQUIRE(!addend || ldadd >= N, "cst_gemm: ldadd too small");
+    CST_REQUIRE(!aux || ldaux >= N, "cst_gemm: ldaux too small");
+    GemmArgs g;
+    g.A = A; g.B = B; g.C = C; g.bias = bias; g.addend = addend; g.aux = aux;
+    g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.ldadd = ldadd; g.ldaux = ldaux;
+    g.sA = sA; g.sB = sB; g.sC = sC; g.sBias = sBias; g.sAdd = sAdd; g.sAux = sAux;
+    g.M = M; g.N = N; g.K = K; g.act = act; g.accumulate = accumulate;
+    g.vecA = vec_ok(A, lda, sA); g.vecB = vec_ok(B, ldb, sB);
+    g.alpha = alpha; g.gate_scale = gate_scale;
+    g.drop = cst_make_drop(drop_p, drop_seed, drop_stream, drop_seed_dev);
+    // tile choice: big tiles only when they still fill the 256 CUs
+    long big = (long)cst_div_up(M, 128) * cst_div_up(N, 128) * batch;
+    int use_big = tile == 128 || (tile == 0 && big >= 192);
+    if (tile == 64) use_big = 0;
+    if (use_big) launch_cfg<128, 128>(g, precision_f32 ? 1 : 0, a_kmajor ? 1 : 0, b_kmajor ? 1 : 0, batch, (hipStream_t)stream);
+    else launch_cfg<64, 64>(g, precision_f32 ? 1 : 0, a_kmajor ? 1 : 0, b_kmajor ? 1 : 0, batch, (hipStream_t)stream);
+    CST_LAUNCH_CHECK("cst_gemm");
+    return CST_OK;
+}

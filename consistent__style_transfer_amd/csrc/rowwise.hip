@@ -1,0 +1,521 @@
+// HBM-bound row kernels over (rows, V) or (rows, d) fp32 matrices:
+//   * fused token cross-entropy forward+backward  (nn.CrossEntropyLoss at main_pretrain.py:73,
+//     main_warmup.py:52, main_optimize.py:109,139 -- mean over rows, PAD rows included)
+//   * temperature softmax + argmax over the vocabulary and its backward (rnn.py:83-85, 52-53)
+//   * row argmax (rnn.py:92, main_optimize.py:104,131,162)
+//   * residual + dropout + LayerNorm forward / backward (nn.TransformerEncoderLayer post-LN)
+//   * column sums (bias gradients)
+// One 256-thread block owns one vocabulary row and keeps it in registers between the reduction
+// and the write, so a row is read from HBM once and written once (2 passes of algorithmic
+// traffic).  Reductions are wavefront shuffles + one LDS hop.
+#include "cst_common.h"
+
+#define ROW_THREADS 256
+
+// ---------------------------------------------------------------------------------------------
+// row loader: NV4 float4 per thread when the row is 16-byte addressable, else scalar strided.
+// ---------------------------------------------------------------------------------------------
+template <int NV4>
+struct RowRegs {
+    float4 v[NV4];
+    __device__ __forceinline__ void load(const float* __restrict__ row, int V, float fill) {
+#pragma unroll
+        for (int i = 0; i < NV4; ++i) {
+            const int c = (threadIdx.x + ROW_THREADS * i) * 4;
+            v[i] = (c < V) ? *reinterpret_cast<const float4*>(row + c) : make_float4(fill, fill, fill, fill);
+        }
+    }
+    __device__ __forceinline__ void store(float* __restrict__ row, int V) const {
+#pragma unroll
+        for (int i = 0; i < NV4; ++i) {
+            const int c = (threadIdx.x + ROW_THREADS * i) * 4;
+            if (c < V) *reinterpret_cast<float4*>(row + c) = v[i];
+        }
+    }
+};
+
+__device__ __forceinline__ float f4max(float4 a) { return fmaxf(fmaxf(a.x, a.y), fmaxf(a.z, a.w)); }
+
+// ---------------------------------------------------------------------------------------------
+// token CE, vector path
+// ---------------------------------------------------------------------------------------------
+template <int NV4>
+__global__ __launch_bounds__(ROW_THREADS) void ce_vec_kernel(const float* __restrict__ logits, long ld,
+                                                             const int64_t* __restrict__ target, int V,
+                                                             float* __restrict__ row_loss,
+                                                             float* dlogits, long ldd, float gscale) {
+    __shared__ float red[16];
+    const long r = blockIdx.x;
+    const float* row = logits + r * ld;
+    RowRegs<NV4> x;
+    x.load(row, V, -INFINITY);
+    float m = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < NV4; ++i) m = fmaxf(m, f4max(x.v[i]));
+    m = block_max(m, red);
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV4; ++i) {
+        x.v[i].x = expf(x.v[i].x - m); x.v[i].y = expf(x.v[i].y - m);
+        x.v[i].z = expf(x.v[i].z - m); x.v[i].w = expf(x.v[i].w - m);
+        s += (x.v[i].x + x.v[i].y) + (x.v[i].z + x.v[i].w);
+    }
+    s = block_sum(s, red);
+    const long t = target[r];
+    const bool valid = t >= 0 && t < V;
+    if (threadIdx.x == 0) row_loss[r] = valid ? (logf(s) + m - row[t]) : 0.f;
+    if (dlogits) {
+        const float inv = gscale / s;
+        __syncthreads();          // row[t] read above before an in-place overwrite
+#pragma unroll
+        for (int i = 0; i < NV4; ++i) {
+            const int c = (threadIdx.x + ROW_THREADS * i) * 4;
+            float4 g = make_float4(x.v[i].x * inv, x.v[i].y * inv, x.v[i].z * inv, x.v[i].w * inv);
+            if (valid && t >= c && t < c + 4) {
+                if (t == c) g.x -= gscale; else if (t == c + 1) g.y -= gscale;
+                else if (t == c + 2) g.z -= gscale; else g.w -= gscale;
+            }
+            x.v[i] = g;
+        }
+        x.store(dlogits + r * ldd, V);
+    }
+}
+
+// generic path (any V / alignment): three strided sweeps, still one block per row
+__global__ __launch_bounds__(ROW_THREADS) void ce_generic_kernel(const float* __restrict__ logits, long ld,
+                                                                 const int64_t* __restrict__ target, int V,
+                                                                 float* __restrict__ row_loss,
+                                                                 float* dlogits, long ldd, float gscale) {
+    __shared__ float red[16];
+    const long r = blockIdx.x;
+    const float* row = logits + r * ld;
+    float m = -INFINITY;
+    for (int c = threadIdx.x; c < V; c += ROW_THREADS) m = fmaxf(m, row[c]);
+    m = block_max(m, red);
+    float s = 0.f;
+    for (int c = threadIdx.x; c < V; c += ROW_THREADS) s += expf(row[c] - m);
+    s = block_sum(s, red);
+    const long t = target[r];
+    const bool valid = t >= 0 && t < V;
+    if (threadIdx.x == 0) row_loss[r] = valid ? (logf(s) + m - row[t]) : 0.f;
+    if (dlogits) {
+        __syncthreads();
+        const float inv = gscale / s;
+        float* drow = dlogits + r * ldd;
+        for (int c = threadIdx.x; c < V; c += ROW_THREADS) {
+            float g = expf(row[c] - m) * inv;
+            if (valid && c == t) g -= gscale;
+            drow[c] = g;
+        }
+    }
+}
+
+static bool row_vec_ok(const void* p, long ld, int V) {
+    return (((uintptr_t)p & 15) == 0) && (ld % 4 == 0) && (V % 4 == 0) && V <= ROW_THREADS * 4 * 32;
+}
+
+#define ROW_DISPATCH(V, KERNEL, ...)                                                    \
+    do {                                                                                \
+        const int nv4 = cst_div_up(V, ROW_THREADS * 4);                                 \
+        if (nv4 <= 1) hipLaunchKernelGGL((KERNEL<1>), __VA_ARGS__);                      \
+        else if (nv4 <= 2) hipLaunchKernelGGL((KERNEL<2>), __VA_ARGS__);                 \
+        else if (nv4 <= 4) hipLaunchKernelGGL((KERNEL<4>), __VA_ARGS__);                 \
+        else if (nv4 <= 6) hipLaunchKernelGGL((KERNEL<6>), __VA_ARGS__);                 \
+        else if (nv4 <= 10) hipLaunchKernelGGL((KERNEL<10>), __VA_ARGS__);               \
+        else if (nv4 <= 16) hipLaunchKernelGGL((KERNEL<16>), __VA_ARGS__);               \
+        else hipLaunchKernelGGL((KERNEL<32>), __VA_ARGS__);                              \
+    } while (0)
+
+extern "C" int cst_token_ce(const float* logits, long ld, const int64_t* target, int R, int V,
+                            float* row_loss, float* dlogits, long ldd, float grad_scale, void* stream) {
+    CST_REQUIRE(logits && target && row_loss, "cst_token_ce: null pointer");
+    CST_REQUIRE(R > 0 && V > 0 && ld >= V, "cst_token_ce: bad shape R=%d V=%d ld=%ld", R, V, ld);
+    CST_REQUIRE(!dlogits || ldd >= V, "cst_token_ce: ldd too small");
+    hipStream_t st = (hipStream_t)stream;
+    if (row_vec_ok(logits, ld, V) && (!dlogits || row_vec_ok(dlogits, ldd, V))) {
+        ROW_DISPATCH(V, ce_vec_kernel, dim3(R), dim3(ROW_THREADS), 0, st, logits, ld, target, V, row_loss, dlogits, ldd, grad_scale);
+    } else {
+        hipLaunchKernelGGL(ce_generic_kernel, dim3(R), dim3(ROW_THREADS), 0, st, logits, ld, target, V, row_loss, dlogits, ldd, grad_scale);
+    }
+    CST_LAUNCH_CHECK("cst_token_ce");
+    return CST_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// block argmax helper: first (lowest) index among equal maxima
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void block_argmax(float& bv, int& bi, float* redv, int* redi) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(bv, o, 64);
+        const int oi = __shfl_xor(bi, o, 64);
+        if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+    }
+    const int w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) { redv[w] = bv; redi[w] = bi; }
+    __syncthreads();
+    bv = redv[0]; bi = redi[0];
+    for (int i = 1; i < nw; ++i)
+        if (redv[i] > bv || (redv[i] == bv && redi[i] < bi)) { bv = redv[i]; bi = redi[i]; }
+}
+
+__device__ __forceinline__ void upd(float v, int i, float& bv, int& bi) {
+    if (v > bv || (v == bv && i < bi)) { bv = v; bi = i; }
+}
+
+// ---------------------------------------------------------------------------------------------
+// temperature softmax + argmax(p)
+// ---------------------------------------------------------------------------------------------
+template <int NV4>
+__global__ __launch_bounds__(ROW_THREADS) void softmax_tau_vec_kernel(const float* __restrict__ logits, long ld, float inv_tau,
+                                                                      float* __restrict__ p, long ldp,
+                                                                      int64_t* __restrict__ amax, int V) {
+    __shared__ float red[16];
+    __shared__ int redi[16];
+    const long r = blockIdx.x;
+    RowRegs<NV4> x;
+    x.load(logits + r * ld, V, -INFINITY);
+    float m = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < NV4; ++i) {
+        // the reference divides by tau first (rnn.py:83): softmax(logits / tau)
+        x.v[i].x *= inv_tau; x.v[i].y *= inv_tau; x.v[i].z *= inv_tau; x.v[i].w *= inv_tau;
+        m = fmaxf(m, f4max(x.v[i]));
+    }
+    m = block_max(m, red);
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV4; ++i) {
+        x.v[i].x = expf(x.v[i].x - m); x.v[i].y = expf(x.v[i].y - m);
+        x.v[i].z = expf(x.v[i].z - m); x.v[i].w = expf(x.v[i].w - m);
+        s += (x.v[i].x + x.v[i].y) + (x.v[i].z + x.v[i].w);
+    }
+    s = block_sum(s, red);
+    float bv = -INFINITY; int bi = 0x7fffffff;
+#pragma unroll
+    for (int i = 0; i < NV4; ++i) {
+        const int c = (threadIdx.x + ROW_THREADS * i) * 4;
+        x.v[i].x /= s; x.v[i].y /= s; x.v[i].z /= s; x.v[i].w /= s;
+        if (c < V) { upd(x.v[i].x, c, bv, bi); upd(x.v[i].y, c + 1, bv, bi); upd(x.v[i].z, c + 2, bv, bi); upd(x.v[i].w, c + 3, bv, bi); }
+    }
+    x.store(p + r * ldp, V);
+    if (amax) {
+        block_argmax(bv, bi, red, redi);
+        if (threadIdx.x == 0) amax[r] = bi;
+    }
+}
+
+__global__ __launch_bounds__(ROW_THREADS) void softmax_tau_generic_kernel(const float* __restrict__ logits, long ld, float inv_tau,
+                                                                          float* __restrict__ p, long ldp,
+                                                                          int64_t* __restrict__ amax, int V) {
+    __shared__ float red[16];
+    __shared__ int redi[16];
+    const long r = blockIdx.x;
+    const float* row = logits + r * ld;
+    float m = -INFINITY;
+    for (int c = threadIdx.x; c < V; c += ROW_THREADS) m = fmaxf(m, row[c] * inv_tau);
+    m = block_max(m, red);
+    float s = 0.f;
+    for (int c = threadIdx.x; c < V; c += ROW_THREADS) s += expf(row[c] * inv_tau - m);
+    s = block_sum(s, red);
+    float bv = -INFINITY; int bi = 0x7fffffff;
+    for (int c = threadIdx.x; c < V; c += ROW_THREADS) {
+        const float q = expf(row[c] * inv_tau - m) / s;
+        p[r * ldp + c] = q;
+        upd(q, c, bv, bi);
+    }
+    if (amax) {
+        block_argmax(bv, bi, red, redi);
+        if (threadIdx.x == 0) amax[r] = bi;
+    }
+}
+
+extern "C" int cst_softmax_tau(const float* logits, long ld, float inv_tau, float* p, long ldp,
+                               int64_t* argmax_out, int R, int V, void* stream) {
+    CST_REQUIRE(logits && p, "cst_softmax_tau: null pointer");
+    CST_REQUIRE(R > 0 && V > 0 && ld >= V && ldp >= V, "cst_softmax_tau: bad shape");
+    hipStream_t st = (hipStream_t)stream;
+    if (row_vec_ok(logits, ld, V) && row_vec_ok(p, ldp, V)) {
+        ROW_DISPATCH(V, softmax_tau_vec_kernel, dim3(R), dim3(ROW_THREADS), 0, st, logits, ld, inv_tau, p, ldp, argmax_out, V);
+    } else {
+        hipLaunchKernelGGL(softmax_tau_generic_kernel, dim3(R), dim3(ROW_THREADS), 0, st, logits, ld, inv_tau, p, ldp, argmax_out, V);
+    }
+    CST_LAUNCH_CHECK("cst_softmax_tau");
+    return CST_OK;
+}
+
+// backward: dx = inv_tau * p * (dp - sum(dp * p));  dx may alias dp
+template <int NV4>
+__global__ __launch_bounds__(ROW_THREADS) void softmax_tau_bwd_vec_kernel(const float* __restrict__ p, long ldp,
+                                                                          const float* dp, long lddp, float inv_tau,
+                                                                          float* dx, long lddx, int V) {
+    __shared__ float red[16];
+    const long r = blockIdx.x;
+    RowRegs<NV4> q, g;
+    q.load(p + r * ldp, V, 0.f);
+    g.load(dp + r * lddp, V, 0.f);
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV4; ++i) s += (q.v[i].x * g.v[i].x + q.v[i].y * g.v[i].y) + (q.v[i].z * g.v[i].z + q.v[i].w * g.v[i].w);
+    s = block_sum(s, red);
+#pragma unroll
+    for (int i = 0; i < NV4; ++i) {
+        g.v[i].x = inv_tau * q.v[i].x * (g.v[i].x - s); g.v[i].y = inv_tau * q.v[i].y * (g.v[i].y - s);
+        g.v[i].z = inv_tau * q.v[i].z * (g.v[i].z - s); g.v[i].w = inv_tau * q.v[i].w * (g.v[i].w - s);
+    }
+    g.store(dx + r * lddx, V);
+}
+
+__global__ __launch_bounds__(ROW_THREADS) void softmax_tau_bwd_generic_kernel(const float* __restrict__ p, long ldp,
+                                                                              const float* dp, long lddp, float inv_tau,
+                                                                              float* dx, long lddx, int V) {
+    __shared__ float red[16];
+    const long r = blockIdx.x;
+    float s = 0.f;
+    for (int c = threadIdx.x; c < V; c += ROW_THREADS) s += p[r * ldp + c] * dp[r * lddp + c];
+    s = block_sum(s, red);
+    for (int c = threadIdx.x; c < V; c += ROW_THREADS)
+        dx[r * lddx + c] = inv_tau * p[r * ldp + c] * (dp[r * lddp + c] - s);
+}
+
+extern "C" int cst_softmax_tau_bwd(const float* p, long ldp, const float* dp, long lddp, float inv_tau,
+                                   float* dx, long lddx, int R, int V, void* stream) {
+    CST_REQUIRE(p && dp && dx, "cst_softmax_tau_bwd: null pointer");
+    CST_REQUIRE(R > 0 && V > 0 && ldp >= V && lddp >= V && lddx >= V, "cst_softmax_tau_bwd: bad shape");
+    hipStream_t st = (hipStream_t)stream;
+    if (row_vec_ok(p, ldp, V) && row_vec_ok(dp, lddp, V) && row_vec_ok(dx, lddx, V) && V <= ROW_THREADS * 4 * 16) {
+        const int nv4 = cst_div_up(V, ROW_THREADS * 4);
+        if (nv4 <= 1) hipLaunchKernelGGL((softmax_tau_bwd_vec_kernel<1>), dim3(R), dim3(ROW_THREADS), 0, st, p, ldp, dp, lddp, inv_tau, dx, lddx, V);
+        else if (nv4 <= 4) hipLaunchKernelGGL((softmax_tau_bwd_vec_kernel<4>), dim3(R), dim3(ROW_THREADS), 0, st, p, ldp, dp, lddp, inv_tau, dx, lddx, V);
+        else if (nv4 <= 10) hipLaunchKernelGGL((softmax_tau_bwd_vec_kernel<10>), dim3(R), dim3(ROW_THREADS), 0, st, p, ldp, dp, lddp, inv_tau, dx, lddx, V);
+        else hipLaunchKernelGGL((softmax_tau_bwd_vec_kernel<16>), dim3(R), dim3(ROW_THREADS), 0, st, p, ldp, dp, lddp, inv_tau, dx, lddx, V);
+    } else {
+        hipLaunchKernelGGL(softmax_tau_bwd_generic_kernel, dim3(R), dim3(ROW_THREADS), 0, st, p, ldp, dp, lddp, inv_tau, dx, lddx, V);
+    }
+    CST_LAUNCH_CHECK("cst_softmax_tau_bwd");
+    return CST_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// row argmax (first index among equal maxima), int64 out
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(ROW_THREADS) void argmax_kernel(const float* __restrict__ x, long ld, int V, int vec,
+                                                             int64_t* __restrict__ out) {
+    __shared__ float red[16];
+    __shared__ int redi[16];
+    const long r = blockIdx.x;
+    const float* row = x + r * ld;
+    float bv = -INFINITY; int bi = 0x7fffffff;
+    if (vec) {
+        for (int c = threadIdx.x * 4; c < V; c += ROW_THREADS * 4) {
+            const float4 t = *reinterpret_cast<const float4*>(row + c);
+            upd(t.x, c, bv, bi); upd(t.y, c + 1, bv, bi); upd(t.z, c + 2, bv, bi); upd(t.w, c + 3, bv, bi);
+        }
+    } else {
+        for (int c = threadIdx.x; c < V; c += ROW_THREADS) upd(row[c], c, bv, bi);
+    }
+    block_argmax(bv, bi, red, redi);
+    if (threadIdx.x == 0) out[r] = bi == 0x7fffffff ? 0 : bi;
+}
+
+extern "C" int cst_argmax_rows(const float* x, long ld, int R, int V, int64_t* out, void* stream) {
+    CST_REQUIRE(x && out && R > 0 && V > 0 && ld >= V, "cst_argmax_rows: bad arguments");
+    const int vec = (((uintptr_t)x & 15) == 0) && (ld % 4 == 0) && (V % 4 == 0);
+    hipLaunchKernelGGL(argmax_kernel, dim3(R), dim3(ROW_THREADS), 0, (hipStream_t)stream, x, ld, V, vec, out);
+    CST_LAUNCH_CHECK("cst_argmax_rows");
+    return CST_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// z = res + dropout(x) ; y = LayerNorm(z) * gamma + beta.   One wavefront per row of d <= 1024.
+// ---------------------------------------------------------------------------------------------
+#define LN_MAXE 16
+__global__ __launch_bounds__(256) void add_layernorm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ res,
+                                                                const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                float eps, float* z, float* __restrict__ y,
+                                                                float* __restrict__ mean, float* __restrict__ rstd,
+                                                                int T, int d, CstDrop drop) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= T) return;
+    const uint32_t dseed = drop.p > 0.f ? cst_drop_seed(drop) : 0u;
+    float v[LN_MAXE];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXE; ++i) {
+        const int c = lane + 64 * i;
+        float t = 0.f;
+        if (c < d) {
+            t = x[row * d + c];
+            if (drop.p > 0.f) t *= cst_drop_mask(drop, dseed, (uint32_t)(row * d + c));
+            if (res) t += res[row * d + c];
+        }
+        v[i] = t;
+        s += t;
+    }
+    const float mu = wave_sum(s) / (float)d;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXE; ++i) {
+        const int c = lane + 64 * i;
+        const float t = (c < d) ? v[i] - mu : 0.f;
+        q += t * t;
+    }
+    const float rs = 1.0f / sqrtf(wave_sum(q) / (float)d + eps);
+#pragma unroll
+    for (int i = 0; i < LN_MAXE; ++i) {
+        const int c = lane + 64 * i;
+        if (c < d) {
+            if (z) z[row * d + c] = v[i];
+            y[row * d + c] = (v[i] - mu) * rs * gamma[c] + beta[c];
+        }
+    }
+    if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
+}
+
+extern "C" int cst_add_layernorm_fwd(const float* x, const float* res, const float* gamma, const float* beta, float eps,
+                                     float* z, float* y, float* mean, float* rstd, int T, int d,
+                                     float drop_p, uint32_t drop_seed, uint32_t drop_stream, const void* drop_seed_dev,
+                                     void* stream) {
+    CST_REQUIRE(x && gamma && beta && y && mean && rstd, "cst_add_layernorm_fwd: null pointer");
+    CST_REQUIRE(T > 0 && d > 0 && d <= 64 * LN_MAXE, "cst_add_layernorm_fwd: d=%d unsupported (max %d)", d, 64 * LN_MAXE);
+    CstDrop dr = cst_make_drop(drop_p, drop_seed, drop_stream, drop_seed_dev);
+    hipLaunchKernelGGL(add_layernorm_fwd_kernel, dim3(cst_div_up(T, 4)), dim3(256), 0, (hipStream_t)stream,
+                       x, res, gamma, beta, eps, z, y, mean, rstd, T, d, dr);
+    CST_LAUNCH_CHECK("cst_add_layernorm_fwd");
+    return CST_OK;
+}
+
+// backward: dz = rstd * (g - mean(g) - xhat * mean(g * xhat)), g = dy * gamma;
+// per-block partial column sums of dy*xhat (dgamma) and dy (dbeta) go to part[2][nblk][d].
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ z,
+                                                            const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                            const float* __restrict__ gamma, float* dz,
+                                                            float* __restrict__ part, int T, int d, int rows_per_block) {
+    __shared__ float sh[2][4][64 * LN_MAXE / 4];      // only used for d <= 256 per pass; see loop below
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    float ag[LN_MAXE], ab[LN_MAXE];
+#pragma unroll
+    for (int i = 0; i < LN_MAXE; ++i) { ag[i] = 0.f; ab[i] = 0.f; }
+    const long r0 = (long)blockIdx.x * rows_per_block;
+    for (long row = r0 + w; row < r0 + rows_per_block && row < T; row += 4) {
+        const float mu = mean[row], rs = rstd[row];
+        float xh[LN_MAXE], g[LN_MAXE];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < LN_MAXE; ++i) {
+            const int c = lane + 64 * i;
+            if (c < d) {
+                const float dyv = dy[row * d + c];
+                xh[i] = (z[row * d + c] - mu) * rs;
+                g[i] = dyv * gamma[c];
+                s1 += g[i]; s2 += g[i] * xh[i];
+                ag[i] += dyv * xh[i]; ab[i] += dyv;
+            } else { xh[i] = 0.f; g[i] = 0.f; }
+        }
+        s1 = wave_sum(s1) / (float)d; s2 = wave_sum(s2) / (float)d;
+#pragma unroll
+        for (int i = 0; i < LN_MAXE; ++i) {
+            const int c = lane + 64 * i;
+            if (c < d) dz[row * d + c] = rs * (g[i] - s1 - xh[i] * s2);
+        }
+    }
+    // reduce the 4 waves' partial sums through LDS, 4 column groups (of 64) at a time
+    const long nblk = gridDim.x;
+    for (int i0 = 0; i0 < LN_MAXE; i0 += 4) {
+        if (i0 * 64 >= d) break;
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { sh[0][w][i * 64 + lane] = ag[i0 + i]; sh[1][w][i * 64 + lane] = ab[i0 + i]; }
+        __syncthreads();
+        // 256 threads <-> 256 columns of this pass
+        const int c = i0 * 64 + threadIdx.x;
+        if (c < d) {
+            const float sg = (sh[0][0][threadIdx.x] + sh[0][1][threadIdx.x]) + (sh[0][2][threadIdx.x] + sh[0][3][threadIdx.x]);
+            const float sb = (sh[1][0][threadIdx.x] + sh[1][1][threadIdx.x]) + (sh[1][2][threadIdx.x] + sh[1][3][threadIdx.x]);
+            part[(0 * nblk + blockIdx.x) * d + c] = sg;
+            part[(1 * nblk + blockIdx.x) * d + c] = sb;
+        }
+    }
+}
+
+// out[c] (+)= sum_r X[r, c]   (r over M rows); grid (colgroups, rowsplits); atomics when split
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ X, long ld, int M, int N,
+                                                     float* __restrict__ out, int rows_per_split, int use_atomic, int accumulate) {
+    __shared__ float sh[4][64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane;
+    const long r0 = (long)blockIdx.y * rows_per_split;
+    float s = 0.f;
+    if (c < N)
+        for (long r = r0 + w; r < r0 + rows_per_split && r < M; r += 4) s += X[r * ld + c];
+    sh[w][lane] = s;
+    __syncthreads();
+    if (w == 0 && c < N) {
+        const float t = (sh[0][lane] + sh[1][lane]) + (sh[2][lane] + sh[3][lane]);
+        if (use_atomic) atomicAdd(out + c, t);
+        else out[c] = accumulate ? out[c] + t : t;
+    }
+}
+
+extern "C" int cst_colsum(const float* X, long ld, int M, int N, float* out, int accumulate, void* stream) {
+    CST_REQUIRE(X && out && M > 0 && N > 0 && ld >= N, "cst_colsum: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    const int cg = cst_div_up(N, 64);
+    int splits = 1;
+    if (M >= 512) { splits = 1024 / cg; if (splits < 1) splits = 1; if (splits > M / 64) splits = M / 64; if (splits < 1) splits = 1; }
+    const int rps = cst_div_up(M, splits);
+    const int use_atomic = splits > 1;
+    if (use_atomic && !accumulate) {
+        if (hipMemsetAsync(out, 0, sizeof(float) * N, st) != hipSuccess) { cst_set_error("cst_colsum: memset failed"); return CST_ERR_LAUNCH; }
+    }
+    hipLaunchKernelGGL(colsum_kernel, dim3(cg, splits), dim3(256), 0, st, X, ld, M, N, out, rps, use_atomic, accumulate);
+    CST_LAUNCH_CHECK("cst_colsum");
+    return CST_OK;
+}
+
+extern "C" long cst_layernorm_bwd_workspace_floats(int T, int d) {
+    const int nblk = T < 1024 ? cst_div_up(T, 4) : 256;
+    return 2L * nblk * d;
+}
+
+extern "C" int cst_layernorm_bwd(const float* dy, const float* z, const float* mean, const float* rstd, const float* gamma,
+                                 float* dz, float* dgamma, float* dbeta, int accumulate,
+                                 float* workspace, long workspace_floats, int T, int d, void* stream) {
+    CST_REQUIRE(dy && z && mean && rstd && gamma && dz && workspace, "cst_layernorm_bwd: null pointer");
+    CST_REQUIRE(T > 0 && d > 0 && d <= 64 * LN_MAXE, "cst_layernorm_bwd: d=%d unsupported", d);
+    const int nblk = T < 1024 ? cst_div_up(T, 4) : 256;
+    CST_REQUIRE(workspace_floats >= 2L * nblk * d, "cst_layernorm_bwd: workspace too small (%ld < %ld)", workspace_floats, 2L * nblk * d);
+    const int rpb = cst_div_up(T, nblk);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(nblk), dim3(256), 0, st, dy, z, mean, rstd, gamma, dz, workspace, T, d, rpb);
+    CST_LAUNCH_CHECK("cst_layernorm_bwd");
+    if (dgamma) {
+        int rc = cst_colsum(workspace, d, nblk, d, dgamma, accumulate, stream);
+        if (rc) return rc;
+    }
+    if (dbeta) {
+        int rc = cst_colsum(workspace + (long)nblk * d, d, nblk, d, dbeta, accumulate, stream);
+        if (rc) return rc;
+    }
+    return CST_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// out[0] = scale * sum(in[0..n))   (deterministic single-block reduction of per-row losses)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void reduce_sum_kernel(const float* __restrict__ in, long n, float scale, float* __restrict__ out, int accumulate) {
+    __shared__ float red[16];
+    float s = 0.f;
+    for (long i = threadIdx.x; i < n; i += 1024) s += in[i];
+    s = block_sum(s, red);
+    if (threadIdx.x == 0) out[0] = accumulate ? out[0] + s * scale : s * scale;
+}
+
+extern "C" int cst_reduce_sum(const float* in, long n, float scale, float* out, int accumulate, void* stream) {
+    CST_REQUIRE(in && out && n > 0, "cst_reduce_sum: bad arguments");
+    hipLaunchKernelGGL(reduce_sum_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, in, n, scale, out, accumulate);
+    CST_LAUNCH_CHECK("cst_reduce_sum");
+    return CST_OK;
+}

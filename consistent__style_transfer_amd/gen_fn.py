@@ -1,0 +1,271 @@
+"""DenoiseLSTM forward / backward as ONE autograd node over the HIP kernels.
+
+Restates reference src/model/rnn.py:55-98 (BiLSTM encoder, attention-LSTM decoder loop,
+temperature-softmax straight-through sampling, scheduled-sampling teacher forcing) with explicit
+back-propagation through time.  The per-step work is: one gate GEMM over [x_t | h_{t-1}], the
+fused LSTM cell, single-query attention, fn_1 (+LeakyReLU), fn_2 straight into the stacked
+(B,T,V) output, then softmax/argmax and the embedding gather for the next input.  Weight
+gradients are NOT accumulated step by step: per-step activations and gate gradients are kept and
+each weight gets one large wgrad GEMM after the loop.
+"""
+import torch
+
+from . import ops
+from ._lib import call
+from .ops import (NO_DROP, STREAM_G_EMB_IN, STREAM_G_FFN, STREAM_G_XT, act_bwd, argmax_rows, axpby, colsum, dgrad,
+                  dropout2d, embed_gather, embed_scatter_add, gemm, linear_fwd, softmax_tau, softmax_tau_bwd, wgrad)
+
+PARAM_KEYS = (
+    "start_embedding.weight", "token_embedding.weight", "enc_style_embedding.weight", "style_embedding.weight",
+    "encoder.weight_ih_l0", "encoder.weight_hh_l0", "encoder.bias_ih_l0", "encoder.bias_hh_l0",
+    "encoder.weight_ih_l0_reverse", "encoder.weight_hh_l0_reverse", "encoder.bias_ih_l0_reverse",
+    "encoder.bias_hh_l0_reverse",
+    "decoder.weight_ih_l0", "decoder.weight_hh_l0", "decoder.bias_ih_l0", "decoder.bias_hh_l0",
+    "transfer.weight", "fn_1.weight", "fn_1.bias", "fn_2.weight",
+)
+
+
+def _new(dev, *shape, dtype=torch.float32):
+    return torch.empty(*shape, device=dev, dtype=dtype)
+
+
+def _cell_fwd(gates, c_prev, h_out, c_out, h_out2, B, H):
+    call("cst_lstm_cell_fwd", gates, gates.stride(0), c_prev, c_prev.stride(0), h_out, h_out.stride(0),
+         c_out, c_out.stride(0), h_out2, h_out2.stride(0) if h_out2 is not None else 0, B, H)
+
+
+def _cell_bwd(gates, c_prev, c_new, dh, dh2, dc, dgates, dc_prev, B, H):
+    call("cst_lstm_cell_bwd", gates, gates.stride(0), c_prev, c_prev.stride(0), c_new, c_new.stride(0),
+         dh, dh.stride(0) if dh is not None else 0, dh2, dh2.stride(0) if dh2 is not None else 0,
+         dc, dc.stride(0) if dc is not None else 0, dgates, dgates.stride(0), dc_prev, dc_prev.stride(0), B, H)
+
+
+class GeneratorFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, inp, label_i, x, label, coins, cfg, *params):
+        """inp: (B,L') int64 ids or (B,L',V) fp32 probabilities; x: (B,T) int64 or None;
+        coins: (T,) int32 device tensor (1 = feed back argmax) or None;
+        cfg: dict(mode 'none'|'softmax', tau, max_len, drop Drop or NO_DROP)."""
+        P = dict(zip(PARAM_KEYS, params))
+        E_tok = P["token_embedding.weight"]
+        V, E = E_tok.shape
+        H = P["encoder.weight_hh_l0"].shape[1]
+        Hd = P["decoder.weight_hh_l0"].shape[1]
+        assert Hd == 2 * H, "decoder width must equal the BiLSTM memory width (rnn.py:46-50 dot attention)"
+        dev = E_tok.device
+        B, Lp = inp.shape[0], inp.shape[1]
+        mode, tau, drop = cfg["mode"], float(cfg["tau"]), cfg["drop"]
+        soft = mode == "softmax"
+        T = int(cfg["max_len"]) if x is None else x.shape[1]
+        inv_tau = 1.0 / tau
+        label_i = label_i.contiguous()
+        label = label.contiguous()
+
+        # ---- encoder input embedding (rnn.py:58-61) ------------------------------------------
+        emb = _new(dev, B * Lp, E)
+        if inp.dim() == 2:
+            ids_in = inp.contiguous().reshape(-1)
+            embed_gather(E_tok, emb, ids_a=ids_in, drop=drop.at(STREAM_G_EMB_IN))
+            in_drop = drop.at(STREAM_G_EMB_IN)
+        else:
+            ids_in = argmax_rows(inp.reshape(B * Lp, V))        # hard_sample(inp) @ E == row gather
+            embed_gather(E_tok, emb, ids_a=ids_in)
+            in_drop = NO_DROP
+
+        # ---- BiLSTM encoder (rnn.py:57,62) ---------------------------------------------------
+        h0cat = _new(dev, B, 2 * H)
+        embed_gather(P["enc_style_embedding.weight"], h0cat, ids_a=label_i)
+        memory = _new(dev, B, Lp, 2 * H)
+        hprev = _new(dev, 2, B, Lp, H)                # h_{t_prev} per (dir, b, t): B operand of dW_hh
+        genc = _new(dev, 2, Lp, B, 4 * H)             # gate activations
+        cenc = _new(dev, 2, Lp, B, H)
+        c_cat = _new(dev, B, 2 * H)
+        zeros_c = torch.zeros(B, H, device=dev, dtype=torch.float32)
+        mem2 = memory.view(B, Lp * 2 * H)
+        for d, suf in enumerate(("", "_reverse")):
+            w_ih, w_hh = P["encoder.weight_ih_l0" + suf], P["encoder.weight_hh_l0" + suf]
+            bsum = axpby(P["encoder.bias_ih_l0" + suf].view(1, -1), 1.0, P["encoder.bias_hh_l0" + suf].view(1, -1), 1.0).view(-1)
+            xp = linear_fwd(emb, w_ih, bsum).view(B, Lp * 4 * H)        # (B, L', 4H)
+            order = list(range(Lp)) if d == 0 else list(range(Lp - 1, -1, -1))
+            hp2 = hprev[d].view(B, Lp * H)
+            for n, t in enumerate(order):
+                if n == 0:
+                    h_in = h0cat[:, d * H:(d + 1) * H]
+                    c_in = zeros_c
+                    axpby(h_in, 1.0, out=hp2[:, t * H:(t + 1) * H])
+                else:
+                    tp = order[n - 1]
+                    h_in = mem2[:, tp * 2 * H + d * H: tp * 2 * H + (d + 1) * H]
+                    c_in = cenc[d, tp]
+                g = genc[d, t]
+                gemm(h_in, True, w_hh, True, g, B, 4 * H, H, addend=xp[:, t * 4 * H:(t + 1) * 4 * H])
+                last = n == Lp - 1
+                c_out = c_cat[:, d * H:(d + 1) * H] if last else cenc[d, t]
+                h_next = None if last else hp2[:, order[n + 1] * H:(order[n + 1] + 1) * H]
+                _cell_fwd(g, c_in, mem2[:, t * 2 * H + d * H: t * 2 * H + (d + 1) * H], c_out, h_next, B, H)
+
+        # ---- decoder initial state (rnn.py:67-69) --------------------------------------------
+        c0 = linear_fwd(c_cat, P["transfer.weight"], None, act=2)
+        h0d = _new(dev, B, Hd)
+        embed_gather(P["style_embedding.weight"], h0d, ids_a=label)
+        wcat = torch.cat([P["decoder.weight_ih_l0"], P["decoder.weight_hh_l0"]], dim=1).contiguous()   # (4Hd, E+Hd)
+        bdec = axpby(P["decoder.bias_ih_l0"].view(1, -1), 1.0, P["decoder.bias_hh_l0"].view(1, -1), 1.0).view(-1)
+        XH = _new(dev, T, B, E + Hd)                  # [x_t | h_{t-1}]
+        zero_ids = torch.zeros(B, device=dev, dtype=torch.int64)
+        embed_gather(P["start_embedding.weight"], XH[0][:, :E], ids_a=zero_ids)
+        axpby(h0d, 1.0, out=XH[0][:, E:])
+        gdec = _new(dev, T, B, 4 * Hd)
+        cdec = _new(dev, T, B, Hd)
+        iffn = _new(dev, T, B, Hd + 2 * H)            # [h_t | a_t]
+        iffn_d = _new(dev, T, B, Hd + 2 * H) if drop.p > 0 else iffn
+        patt = _new(dev, T, B, Lp)
+        r1 = _new(dev, B, T, Hd)
+        out = _new(dev, B, T, V)
+        ids_fb = _new(dev, T, B, dtype=torch.int64)
+        out2 = out.view(B, T * V)
+        r12 = r1.view(B, T * Hd)
+        x_c = x.contiguous() if x is not None else None
+        for s in range(T):
+            gemm(XH[s], True, wcat, True, gdec[s], B, 4 * Hd, E + Hd, bias=bdec)
+            c_in = c0 if s == 0 else cdec[s - 1]
+            h_next = XH[s + 1][:, E:] if s + 1 < T else None
+            _cell_fwd(gdec[s], c_in, iffn[s][:, :Hd], cdec[s], h_next, B, Hd)
+            call("cst_dot_attn_fwd", iffn[s][:, :Hd], Hd + 2 * H, memory, iffn[s][:, Hd:], Hd + 2 * H, patt[s], B, Lp, Hd)
+            if drop.p > 0:
+                dropout2d(iffn[s], drop.at(STREAM_G_FFN + s), out=iffn_d[s])
+            r1s = r12[:, s * Hd:(s + 1) * Hd]
+            linear_fwd(iffn_d[s], P["fn_1.weight"], P["fn_1.bias"], act=2, out=r1s)
+            o_s = out2[:, s * V:(s + 1) * V]
+            linear_fwd(r1s, P["fn_2.weight"], None, out=o_s)
+            if soft:
+                softmax_tau(o_s, inv_tau, o_s, ids_fb[s])
+            else:
+                argmax_rows(o_s, ids_fb[s])
+            if s + 1 < T:
+                xd = drop.at(STREAM_G_XT + s)
+                if soft or x_c is None:
+                    embed_gather(E_tok, XH[s + 1][:, :E], ids_a=ids_fb[s], drop=xd)
+                else:
+                    embed_gather(E_tok, XH[s + 1][:, :E], ids_a=ids_fb[s], ids_b=x_c[:, s], ldb=T,
+                                 coin=coins[s:s + 1], drop=xd)
+
+        ctx.cfg = (B, Lp, T, V, E, H, Hd, soft, inv_tau, drop, in_drop, inp.dim() == 3)
+        ctx.save_for_backward(*params, emb, ids_in, label_i, label, h0cat, memory, hprev, genc, cenc, c_cat, c0,
+                              wcat, XH, gdec, cdec, iffn, iffn_d, patt, r1, out, ids_fb, x_c, coins, zeros_c,
+                              inp if inp.dim() == 3 else None)
+        ctx.mark_non_differentiable(ids_fb)
+        return out, ids_fb
+
+    @staticmethod
+    def backward(ctx, dout, _dids):
+        B, Lp, T, V, E, H, Hd, soft, inv_tau, drop, in_drop, soft_in = ctx.cfg
+        sv = ctx.saved_tensors
+        n = len(PARAM_KEYS)
+        P = dict(zip(PARAM_KEYS, sv[:n]))
+        (emb, ids_in, label_i, label, h0cat, memory, hprev, genc, cenc, c_cat, c0, wcat, XH, gdec, cdec, iffn,
+         iffn_d, patt, r1, out, ids_fb, x_c, coins, zeros_c, inp3) = sv[n:]
+        dev = dout.device
+        E_tok = P["token_embedding.weight"]
+        dout = dout.contiguous()                      # (B,T,V); in softmax mode rewritten in place to dlogits
+        dout2 = dout.view(B, T * V)
+        out2 = out.view(B, T * V)
+        r12 = r1.view(B, T * Hd)
+        G = {k: None for k in PARAM_KEYS}
+        dE = torch.zeros(V, E, device=dev, dtype=torch.float32)
+        dmem = torch.zeros(B, Lp, 2 * H, device=dev, dtype=torch.float32)
+        dpre1 = _new(dev, T, B, Hd)
+        dgd = _new(dev, T, B, 4 * Hd)
+        diffn = _new(dev, B, Hd + 2 * H)
+        dXH = _new(dev, B, E + Hd)
+        dxe = _new(dev, B, E)
+        dc = _new(dev, B, Hd)
+        for s in range(T - 1, -1, -1):
+            dl = dout2[:, s * V:(s + 1) * V]
+            if s + 1 < T:
+                # gradient of the embedding that fed step s+1 (dropout STREAM_G_XT+s was applied to it)
+                xd = drop.at(STREAM_G_XT + s)
+                if xd.p > 0:
+                    dropout2d(dXH[:, :E], xd, out=dxe)
+                    g_x = dxe
+                else:
+                    g_x = dXH[:, :E]
+                if soft:
+                    # straight-through: d p_s += dx @ E^T ; dE += onehot(argmax)^T dx   (rnn.py:84-85)
+                    gemm(g_x, True, E_tok, True, dl, B, V, E, accumulate=True)
+                    embed_scatter_add(dE, g_x, ids_a=ids_fb[s])
+                elif x_c is None:
+                    embed_scatter_add(dE, g_x, ids_a=ids_fb[s])
+                else:
+                    embed_scatter_add(dE, g_x, ids_a=ids_fb[s], ids_b=x_c[:, s], ldb=T, coin=coins[s:s + 1])
+            if soft:
+                softmax_tau_bwd(out2[:, s * V:(s + 1) * V], dl, inv_tau, dl)
+            r1s = r12[:, s * Hd:(s + 1) * Hd]
+            dgrad(dl, P["fn_2.weight"], out=dpre1[s], aux=r1s, act=4)                     # through LeakyReLU
+            dgrad(dpre1[s], P["fn_1.weight"], out=diffn, drop=drop.at(STREAM_G_FFN + s))    # through dropout(i_ffn)
+            call("cst_dot_attn_bwd", diffn[:, Hd:], Hd + 2 * H, iffn[s][:, :Hd], Hd + 2 * H, memory, patt[s],
+                 diffn[:, :Hd], Hd + 2 * H, 1, dmem, B, Lp, Hd)
+            c_prev = c0 if s == 0 else cdec[s - 1]
+            last = s == T - 1
+            _cell_bwd(gdec[s], c_prev, cdec[s], diffn[:, :Hd], None if last else dXH[:, E:], None if last else dc,
+                      dgd[s], dc, B, Hd)
+            dgrad(dgd[s], wcat, out=dXH)
+        # step 0 input was the start embedding (no dropout), h_{-1} the style embedding
+        G["start_embedding.weight"] = colsum(dXH[:, :E]).view(1, E)
+        dstyle = torch.zeros_like(P["style_embedding.weight"])
+        embed_scatter_add(dstyle, dXH[:, E:], ids_a=label)
+        G["style_embedding.weight"] = dstyle
+        # transfer (rnn.py:68)
+        dpre_t = act_bwd(dc, c0, 0.1)
+        G["transfer.weight"] = wgrad(dpre_t, c_cat)
+        dc_cat = dgrad(dpre_t, P["transfer.weight"])
+        # batched weight gradients of the decoder
+        G["fn_2.weight"] = wgrad(dout.view(B * T, V), r1.view(B * T, Hd))
+        dp1 = dpre1.view(T * B, Hd)
+        G["fn_1.weight"] = wgrad(dp1, iffn_d.view(T * B, Hd + 2 * H))
+        G["fn_1.bias"] = colsum(dp1)
+        dg2 = dgd.view(T * B, 4 * Hd)
+        dwcat = wgrad(dg2, XH.view(T * B, E + Hd))
+        G["decoder.weight_ih_l0"] = dwcat[:, :E].contiguous()
+        G["decoder.weight_hh_l0"] = dwcat[:, E:].contiguous()
+        db = colsum(dg2)
+        G["decoder.bias_ih_l0"] = db
+        G["decoder.bias_hh_l0"] = db.clone()
+
+        # ---- encoder BPTT --------------------------------------------------------------------
+        dh0cat = _new(dev, B, 2 * H)
+        demb = _new(dev, B * Lp, E)
+        dmem2 = dmem.view(B, Lp * 2 * H)
+        dge = _new(dev, 2, B, Lp, 4 * H)
+        dhr = _new(dev, B, H)
+        dce = _new(dev, B, H)
+        for d, suf in enumerate(("", "_reverse")):
+            w_ih, w_hh = P["encoder.weight_ih_l0" + suf], P["encoder.weight_hh_l0" + suf]
+            order = list(range(Lp)) if d == 0 else list(range(Lp - 1, -1, -1))
+            dg2d = dge[d].view(B, Lp * 4 * H)
+            for n_ in range(Lp - 1, -1, -1):
+                t = order[n_]
+                lastf = n_ == Lp - 1
+                c_new = c_cat[:, d * H:(d + 1) * H] if lastf else cenc[d, t]
+                c_prev = zeros_c if n_ == 0 else cenc[d, order[n_ - 1]]
+                dgt = dg2d[:, t * 4 * H:(t + 1) * 4 * H]
+                _cell_bwd(genc[d, t], c_prev, c_new, dmem2[:, t * 2 * H + d * H: t * 2 * H + (d + 1) * H],
+                          None if lastf else dhr, dc_cat[:, d * H:(d + 1) * H] if lastf else dce, dgt, dce, B, H)
+                dgrad(dgt, w_hh, out=dh0cat[:, d * H:(d + 1) * H] if n_ == 0 else dhr)
+            dgf = dge[d].view(B * Lp, 4 * H)
+            G["encoder.weight_hh_l0" + suf] = wgrad(dgf, hprev[d].view(B * Lp, H))
+            G["encoder.weight_ih_l0" + suf] = wgrad(dgf, emb)
+            dbe = colsum(dgf)
+            G["encoder.bias_ih_l0" + suf] = dbe
+            G["encoder.bias_hh_l0" + suf] = dbe.clone()
+            dgrad(dgf, w_ih, out=demb, accumulate=d == 1)
+        dstyle_e = torch.zeros_like(P["enc_style_embedding.weight"])
+        embed_scatter_add(dstyle_e, dh0cat, ids_a=label_i)
+        G["enc_style_embedding.weight"] = dstyle_e
+        embed_scatter_add(dE, demb, ids_a=ids_in, drop=in_drop)
+        G["token_embedding.weight"] = dE
+        dinp = None
+        if soft_in and ctx.needs_input_grad[0]:
+            dinp = _new(dev, B * Lp, V)
+            gemm(demb, True, E_tok, True, dinp, B * Lp, V, E)            # straight-through of rnn.py:61
+            dinp = dinp.view(B, Lp, V)
+        return (dinp, None, None, None, None, None, *[G[k] for k in PARAM_KEYS])

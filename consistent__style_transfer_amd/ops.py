@@ -1,0 +1,589 @@
+"""Host-side operators: thin wrappers over the C ABI (include/cst_hip.h) plus the
+torch.autograd.Function glue that strings HIP forward and HIP backward kernels together.
+
+PyTorch supplies device memory, streams and the autograd tape only -- every number is computed
+by libcst_hip.so.  Nothing here falls back to torch arithmetic.
+"""
+import math
+
+import torch
+
+from ._lib import call, call_plain
+
+# ---- dropout call-site stream ids (mirrored by oracle/modules.py) ---------------------------
+STREAM_G_EMB_IN = 1
+STREAM_G_FFN = 100
+STREAM_G_XT = 200
+STREAM_TFM = 1000
+STREAM_CLS = 2000
+STREAM_DISC = 3000
+
+_STATE = {"f32": False}
+
+
+def set_precision(name):
+    """'bf16' (v_mfma_f32_16x16x32_bf16, fp32 accumulate) or 'f32' (exact v_mfma_f32_16x16x4_f32)."""
+    if name not in ("bf16", "f32"):
+        raise ValueError(name)
+    _STATE["f32"] = name == "f32"
+
+
+def get_precision():
+    return "f32" if _STATE["f32"] else "bf16"
+
+
+class Drop:
+    """Dropout descriptor handed to the kernels: p, host seed, call-site stream, device seed word."""
+    __slots__ = ("p", "seed", "stream", "seed_dev")
+
+    def __init__(self, p=0.0, seed=0, stream=0, seed_dev=None):
+        self.p, self.seed, self.stream, self.seed_dev = float(p), int(seed) & 0xFFFFFFFF, int(stream), seed_dev
+
+    def args(self):
+        return (self.p, self.seed, self.stream, self.seed_dev)
+
+    def at(self, stream):
+        return Drop(self.p, self.seed, stream, self.seed_dev)
+
+    @property
+    def scale(self):
+        return 1.0 / (1.0 - self.p) if self.p > 0 else 1.0
+
+
+NO_DROP = Drop()
+
+
+def _ld(t):
+    assert t.dim() == 2 and t.stride(1) == 1, f"need a row-major 2-D view, got strides {t.stride()}"
+    return t.stride(0)
+
+
+def _f32(t):
+    assert t.dtype == torch.float32 and t.is_cuda, "fp32 device tensor expected"
+    return t
+
+
+# =============================================================================================
+# raw wrappers
+# =============================================================================================
+def gemm(A, a_kmajor, B, b_kmajor, C, M, N, K, bias=None, addend=None, aux=None, act=0, gate_scale=1.0,
+         accumulate=False, alpha=1.0, drop=NO_DROP, tile=0):
+    """C[M,N] = epi(alpha * op(A) op(B)); A, B, C, addend, aux are row-major 2-D views."""
+    call("cst_gemm", _f32(A), _ld(A), int(a_kmajor), _f32(B), _ld(B), int(b_kmajor), _f32(C), _ld(C), M, N, K,
+         bias, addend, _ld(addend) if addend is not None else 0, aux, _ld(aux) if aux is not None else 0,
+         act, float(gate_scale), int(accumulate), float(alpha), int(_STATE["f32"]),
+         1, 0, 0, 0, 0, 0, 0, *drop.args(), tile)
+    return C
+
+
+def linear_fwd(x, W, b=None, act=0, drop=NO_DROP, out=None, addend=None, accumulate=False):
+    """y = act(x W^T + b) with x [M,K] view, W [N,K]."""
+    M, K = x.shape
+    N = W.shape[0]
+    if out is None:
+        out = torch.empty(M, N, device=x.device, dtype=torch.float32)
+    return gemm(x, True, W, True, out, M, N, K, bias=b, act=act, drop=drop, addend=addend, accumulate=accumulate)
+
+
+def dgrad(g, W, out=None, addend=None, aux=None, act=0, gate_scale=1.0, drop=NO_DROP, accumulate=False):
+    """dx[M,K] = g[M,N] W[N,K]."""
+    M, N = g.shape
+    K = W.shape[1]
+    if out is None:
+        out = torch.empty(M, K, device=g.device, dtype=torch.float32)
+    return gemm(g, True, W, False, out, M, K, N, addend=addend, aux=aux, act=act, gate_scale=gate_scale, drop=drop,
+                accumulate=accumulate)
+
+
+def wgrad(g, x, out=None, accumulate=False):
+    """dW[N,K] = g[M,N]^T x[M,K]."""
+    M, N = g.shape
+    K = x.shape[1]
+    if out is None:
+        out = torch.empty(N, K, device=g.device, dtype=torch.float32)
+    return gemm(g, False, x, False, out, N, K, M, accumulate=accumulate)
+
+
+def colsum(x, out=None, accumulate=False):
+    M, N = x.shape
+    if out is None:
+        out = torch.empty(N, device=x.device, dtype=torch.float32)
+    call("cst_colsum", x, _ld(x), M, N, out, int(accumulate))
+    return out
+
+
+def dropout2d(x, drop, out=None):
+    R, C = x.shape
+    if out is None:
+        out = torch.empty(R, C, device=x.device, dtype=torch.float32)
+    call("cst_dropout", x, _ld(x), out, _ld(out), R, C, *drop.args())
+    return out
+
+
+def axpby(a, alpha, b=None, beta=1.0, out=None):
+    R, C = a.shape
+    if out is None:
+        out = torch.empty(R, C, device=a.device, dtype=torch.float32)
+    call("cst_axpby", a, _ld(a), float(alpha), b, _ld(b) if b is not None else 0, float(beta), out, _ld(out), R, C)
+    return out
+
+
+def act_bwd(dy, y, slope, pos_scale=1.0, out=None):
+    assert dy.is_contiguous() and y.is_contiguous()
+    if out is None:
+        out = torch.empty_like(dy)
+    call("cst_act_bwd", dy, y, float(slope), float(pos_scale), out, dy.numel())
+    return out
+
+
+def argmax_rows(x, out=None):
+    R, V = x.shape
+    if out is None:
+        out = torch.empty(R, device=x.device, dtype=torch.int64)
+    call("cst_argmax_rows", x, _ld(x), R, V, out)
+    return out
+
+
+def softmax_tau(logits, inv_tau, p, argmax_out=None):
+    R, V = logits.shape
+    call("cst_softmax_tau", logits, _ld(logits), float(inv_tau), p, _ld(p), argmax_out, R, V)
+
+
+def softmax_tau_bwd(p, dp, inv_tau, dx):
+    R, V = p.shape
+    call("cst_softmax_tau_bwd", p, _ld(p), dp, _ld(dp), float(inv_tau), dx, _ld(dx), R, V)
+
+
+def embed_gather(table, out, ids_a=None, ids_b=None, ldb=1, coin=None, transposed=False, drop=NO_DROP, V=None):
+    R, E = out.shape
+    if V is None:
+        V = table.shape[1] if transposed else table.shape[0]
+    call("cst_embed_gather", ids_a, ids_b, ldb, coin, table, _ld(table), int(transposed), out, _ld(out), R, E, V,
+         *drop.args())
+    return out
+
+
+def embed_scatter_add(dtable, dout, ids_a=None, ids_b=None, ldb=1, coin=None, transposed=False, drop=NO_DROP, V=None):
+    R, E = dout.shape
+    if V is None:
+        V = dtable.shape[1] if transposed else dtable.shape[0]
+    call("cst_embed_scatter_add", ids_a, ids_b, ldb, coin, dout, _ld(dout), dtable, _ld(dtable), int(transposed),
+         R, E, V, *drop.args())
+
+
+def _i64(t):
+    assert t.dtype == torch.int64 and t.is_cuda and t.is_contiguous()
+    return t
+
+
+# =============================================================================================
+# Linear (+ activation + dropout)
+# =============================================================================================
+class LinearFn(torch.autograd.Function):
+    """y = dropout(act(x W^T + b)); act 0 none / 1 relu / 2 LeakyReLU(0.1)."""
+
+    @staticmethod
+    def forward(ctx, x, W, b, act, drop):
+        y = linear_fwd(x, W, b, act=act, drop=drop)
+        ctx.act, ctx.drop = act, drop
+        ctx.save_for_backward(x, W, y if (act or drop.p > 0) else None)
+        ctx.has_b = b is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, W, y = ctx.saved_tensors
+        g = dy.contiguous()
+        if ctx.act:
+            g = act_bwd(g, y, 0.0 if ctx.act == 1 else 0.1, ctx.drop.scale)
+        elif ctx.drop.p > 0:
+            g = dropout2d(g, ctx.drop)
+        dx = dgrad(g, W) if ctx.needs_input_grad[0] else None
+        dW = wgrad(g, x) if ctx.needs_input_grad[1] else None
+        db = colsum(g) if (ctx.has_b and ctx.needs_input_grad[2]) else None
+        return dx, dW, db, None, None
+
+
+def linear(x, W, b=None, act=0, drop=NO_DROP):
+    return LinearFn.apply(x, W, b, act, drop)
+
+
+class DropoutFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, drop):
+        ctx.drop = drop
+        return dropout2d(x, drop)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return dropout2d(dy.contiguous(), ctx.drop), None
+
+
+def dropout(x, drop):
+    if drop.p <= 0:
+        return x
+    return DropoutFn.apply(x, drop)
+
+
+# =============================================================================================
+# transformer encoder layer (post-LN, ReLU) as one autograd node
+# =============================================================================================
+def _ln_fwd(x, res, gamma, beta, drop, z, y, mean, rstd, eps=1e-5):
+    T, d = x.shape
+    call("cst_add_layernorm_fwd", x, res, gamma, beta, eps, z, y, mean, rstd, T, d, *drop.args())
+
+
+def _ln_bwd(dy, z, mean, rstd, gamma, want_param_grads):
+    T, d = dy.shape
+    dz = torch.empty_like(dy)
+    nws = call_plain("cst_layernorm_bwd_workspace_floats", T, d)
+    ws = torch.empty(nws, device=dy.device, dtype=torch.float32)
+    dg = torch.empty(d, device=dy.device, dtype=torch.float32) if want_param_grads else None
+    db = torch.empty(d, device=dy.device, dtype=torch.float32) if want_param_grads else None
+    call("cst_layernorm_bwd", dy, z, mean, rstd, gamma, dz, dg, db, 0, ws, nws, T, d)
+    return dz, dg, db
+
+
+class EncoderLayerFn(torch.autograd.Function):
+    """nn.TransformerEncoderLayer(d_model, nhead) as mlm.py:20-22 / match.py:18-20 configure it:
+    x = LN1(x + drop(out_proj(MHA(x)))); x = LN2(x + drop(W2 drop(relu(W1 x))))."""
+
+    @staticmethod
+    def forward(ctx, x, in_w, in_b, out_w, out_b, l1_w, l1_b, l2_w, l2_b, n1_w, n1_b, n2_w, n2_b,
+                B, S, H, drop, layer):
+        T, d = x.shape
+        F = l1_w.shape[0]
+        dev = x.device
+        sb = STREAM_TFM + 10 * layer
+        new = lambda *s: torch.empty(*s, device=dev, dtype=torch.float32)
+        qkv = linear_fwd(x, in_w, in_b)
+        att, lse = new(T, d), new(B * H * S)
+        call("cst_mha_fwd", qkv, att, lse, B, S, H, d // H, *drop.at(sb + 0).args())
+        z1 = linear_fwd(att, out_w, out_b)
+        y1, m1, r1 = new(T, d), new(T), new(T)
+        _ln_fwd(z1, x, n1_w, n1_b, drop.at(sb + 1), z1, y1, m1, r1)
+        h = linear_fwd(y1, l1_w, l1_b, act=1, drop=drop.at(sb + 2))
+        z2 = linear_fwd(h, l2_w, l2_b)
+        y2, m2, r2 = new(T, d), new(T), new(T)
+        _ln_fwd(z2, y1, n2_w, n2_b, drop.at(sb + 3), z2, y2, m2, r2)
+        ctx.save_for_backward(x, in_w, out_w, l1_w, l2_w, n1_w, n2_w, qkv, lse, att, z1, m1, r1, y1, h, z2, m2, r2)
+        ctx.cfg = (B, S, H, drop, sb)
+        return y2
+
+    @staticmethod
+    def backward(ctx, dy2):
+        x, in_w, out_w, l1_w, l2_w, n1_w, n2_w, qkv, lse, att, z1, m1, r1, y1, h, z2, m2, r2 = ctx.saved_tensors
+        B, S, H, drop, sb = ctx.cfg
+        T, d = x.shape
+        wg = ctx.needs_input_grad[1]                       # weights trainable? (frozen critics: dgrad only)
+        dy2 = dy2.contiguous()
+        dz2, dn2w, dn2b = _ln_bwd(dy2, z2, m2, r2, n2_w, wg)
+        df = dropout2d(dz2, drop.at(sb + 3)) if drop.p > 0 else dz2
+        dh = dgrad(df, l2_w, aux=h, act=3, gate_scale=drop.scale)              # relu' and dropout2' fused
+        dl2w = wgrad(df, h) if wg else None
+        dl2b = colsum(df) if wg else None
+        dy1 = dgrad(dh, l1_w, addend=dz2)
+        dl1w = wgrad(dh, y1) if wg else None
+        dl1b = colsum(dh) if wg else None
+        dz1, dn1w, dn1b = _ln_bwd(dy1, z1, m1, r1, n1_w, wg)
+        do = dropout2d(dz1, drop.at(sb + 1)) if drop.p > 0 else dz1
+        datt = dgrad(do, out_w)
+        doutw = wgrad(do, att) if wg else None
+        doutb = colsum(do) if wg else None
+        dqkv = torch.empty_like(qkv)
+        call("cst_mha_bwd", qkv, datt, lse, dqkv, B, S, H, d // H, *drop.at(sb + 0).args())
+        dx = dgrad(dqkv, in_w, addend=dz1) if ctx.needs_input_grad[0] else None
+        dinw = wgrad(dqkv, x) if wg else None
+        dinb = colsum(dqkv) if wg else None
+        return (dx, dinw, dinb, doutw, doutb, dl1w, dl1b, dl2w, dl2b, dn1w, dn1b, dn2w, dn2b,
+                None, None, None, None, None)
+
+
+# =============================================================================================
+# token + position (+ segment) embedding of one or two sequences (MLM / Matcher front end)
+# =============================================================================================
+class TpsEmbedFn(torch.autograd.Function):
+    """x[b, off+l] = (Etok[ids] | probs @ Etok) + Epos[l] (+ Eseg[seg]) for up to two segments laid
+    side by side on the sequence axis (mlm.py:27-38; match.py:24-39)."""
+
+    @staticmethod
+    def forward(ctx, s1, s2, Etok, Epos, Eseg):
+        segs = [s for s in (s1, s2) if s is not None]
+        B = segs[0].shape[0]
+        V, d = Etok.shape
+        S = sum(s.shape[1] for s in segs)
+        x = torch.empty(B, S, d, device=Etok.device, dtype=torch.float32)
+        off = 0
+        for i, s in enumerate(segs):
+            L = s.shape[1]
+            seg_row = Eseg[i] if Eseg is not None else None
+            if s.dim() == 2:
+                call("cst_tps_embed_fwd", _i64(s), None, Etok, Epos, seg_row, x, B, L, d, S, off, V)
+            elif s.dim() == 3:
+                pre = torch.empty(B * L, d, device=Etok.device, dtype=torch.float32)
+                gemm(s.reshape(B * L, V), True, Etok, False, pre, B * L, d, V)
+                call("cst_tps_embed_fwd", None, pre, Etok, Epos, seg_row, x, B, L, d, S, off, V)
+            else:
+                raise Exception          # the reference's bare `raise Exception` (mlm.py:33, match.py:30)
+            off += L
+        ctx.save_for_backward(s1, s2, Etok)
+        ctx.shape = (B, S, d, V, Epos.shape[0], Eseg is not None)
+        return x
+
+    @staticmethod
+    def backward(ctx, dx):
+        s1, s2, Etok = ctx.saved_tensors
+        B, S, d, V, npos, has_seg = ctx.shape
+        dx = dx.contiguous()
+        dev = dx.device
+        wg = ctx.needs_input_grad[2]
+        dEtok = torch.zeros(V, d, device=dev, dtype=torch.float32) if wg else None
+        dEpos = torch.zeros(npos, d, device=dev, dtype=torch.float32) if wg else None
+        dEseg = torch.zeros(2, d, device=dev, dtype=torch.float32) if (wg and has_seg) else None
+        grads = [None, None]
+        off = 0
+        for i, s in enumerate((s1, s2)):
+            if s is None:
+                continue
+            L = s.shape[1]
+            dseg_row = dEseg[i] if dEseg is not None else None
+            if s.dim() == 2:
+                if wg:
+                    call("cst_tps_embed_bwd", dx, s, None, dEtok, dEpos, dseg_row, B, L, d, S, off, V)
+            else:
+                dpre = torch.empty(B * L, d, device=dev, dtype=torch.float32)
+                call("cst_tps_embed_bwd", dx, None, dpre, None, dEpos, dseg_row, B, L, d, S, off, V)
+                p2 = s.reshape(B * L, V)
+                if ctx.needs_input_grad[i]:
+                    dp = torch.empty(B * L, V, device=dev, dtype=torch.float32)
+                    gemm(dpre, True, Etok, True, dp, B * L, V, d)
+                    grads[i] = dp.view(B, L, V)
+                if wg:
+                    gemm(p2, False, dpre, False, dEtok, V, d, B * L, accumulate=True)
+            off += L
+        return grads[0], grads[1], dEtok, dEpos, dEseg
+
+
+class SeqMaxFn(torch.autograd.Function):
+    """x.max(dim=1) over the sequence axis of [B,S,d] (match.py:41)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        B, S, d = x.shape
+        out = torch.empty(B, d, device=x.device, dtype=torch.float32)
+        arg = torch.empty(B, d, device=x.device, dtype=torch.int32)
+        call("cst_seqmax_fwd", x.contiguous(), out, d, arg, B, S, d)
+        ctx.save_for_backward(arg)
+        ctx.shape = (B, S, d)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (arg,) = ctx.saved_tensors
+        B, S, d = ctx.shape
+        dout = dout.contiguous()
+        dx = torch.empty(B, S, d, device=dout.device, dtype=torch.float32)
+        call("cst_seqmax_bwd", dout, d, arg, None, 0, 0, dx, B, S, d)
+        return dx
+
+
+# =============================================================================================
+# losses
+# =============================================================================================
+class TokenCEFn(torch.autograd.Function):
+    """weight * mean_r CE(logits[r], target[r]); the forward kernel also produces dlogits (fused
+    single pass: one read of the logits, one write of the gradient).  `unit_grad` promises that
+    the incoming gradient of the returned scalar is exactly 1 (the loss enters a plain sum that is
+    backpropagated directly), which saves a scaling pass over (rows, V)."""
+
+    @staticmethod
+    def forward(ctx, logits, target, weight, unit_grad):
+        R, V = logits.shape
+        row = torch.empty(R, device=logits.device, dtype=torch.float32)
+        loss = torch.empty(1, device=logits.device, dtype=torch.float32)
+        dl = torch.empty(R, V, device=logits.device, dtype=torch.float32) if logits.requires_grad else None
+        call("cst_token_ce", logits, _ld(logits), _i64(target), R, V, row, dl, V, float(weight) / R)
+        call("cst_reduce_sum", row, R, float(weight) / R, loss, 0)
+        ctx.save_for_backward(dl)
+        ctx.unit = unit_grad
+        return loss
+
+    @staticmethod
+    def backward(ctx, gout):
+        (dl,) = ctx.saved_tensors
+        if ctx.unit:
+            return dl, None, None, None
+        out = torch.empty_like(dl)
+        call("cst_scale_dev", dl, gout.contiguous(), out, dl.numel())
+        return out, None, None, None
+
+
+def token_ce(logits2d, target, weight=1.0, unit_grad=False):
+    """F.cross_entropy(logits2d, target) * weight, mean over all rows (PAD rows count)."""
+    return TokenCEFn.apply(logits2d, target.reshape(-1), weight, unit_grad)
+
+
+class SmallLossFn(torch.autograd.Function):
+    """kind 0: weight * MSE(x, target or const);  kind 1: weight * BCEWithLogits(x, const)."""
+
+    @staticmethod
+    def forward(ctx, x, target, tconst, kind, weight):
+        x = x.contiguous()
+        loss = torch.empty(1, device=x.device, dtype=torch.float32)
+        dx = torch.empty_like(x) if x.requires_grad else None
+        call("cst_small_loss", x, target, float(tconst), kind, x.numel(), float(weight), loss, dx, float(weight))
+        ctx.save_for_backward(dx)
+        return loss
+
+    @staticmethod
+    def backward(ctx, gout):
+        (dx,) = ctx.saved_tensors
+        out = torch.empty_like(dx)
+        call("cst_scale_dev", dx, gout.contiguous(), out, dx.numel())
+        return out, None, None, None, None
+
+
+def mse_loss(x, target=None, const=0.0, weight=1.0):
+    return SmallLossFn.apply(x, target, const, 0, weight)
+
+
+def bce_logits_loss(x, const, weight=1.0):
+    return SmallLossFn.apply(x, None, const, 1, weight)
+
+
+# =============================================================================================
+# convolution bank = im2col + MFMA GEMM (bias, relu) + max over time, all branches into one
+# feature matrix (TextCNN classifier.py:30-34; RelGAN_D discriminator.py:41-44)
+# =============================================================================================
+class ConvBankFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, e, mode, R, *wb):
+        """e [B,L,E]; mode 0 TextCNN (pad k-1), mode 1 RelGAN_D (R representations).
+        wb = (w0, b0, w1, b1, ...) with w_i [F_i,1,k_i,E or E/R].  Returns [B or B*R, sum F_i]."""
+        B, L, E = e.shape
+        e = e.contiguous()
+        ws, bs = wb[0::2], wb[1::2]
+        G = B if mode == 0 else B * R
+        Ftot = sum(w.shape[0] for w in ws)
+        dev = e.device
+        feats = torch.empty(G, Ftot, device=dev, dtype=torch.float32)
+        saved, off = [], 0
+        for w, b in zip(ws, bs):
+            F_, k = w.shape[0], w.shape[2]
+            T = L + k - 1 if mode == 0 else L - k + 1
+            KE = k * (E if mode == 0 else E // R)
+            col = torch.empty(G * T, KE, device=dev, dtype=torch.float32)
+            call("cst_im2col", e, col, B, L, E, k, mode, R)
+            y = linear_fwd(col, w.reshape(F_, KE), b, act=1)
+            arg = torch.empty(G, F_, device=dev, dtype=torch.int32)
+            call("cst_seqmax_fwd", y, feats[:, off:], Ftot, arg, G, T, F_)
+            saved += [col, arg]
+            off += F_
+        ctx.save_for_backward(feats, *ws, *saved)
+        ctx.cfg = (B, L, E, mode, R, len(ws))
+        return feats
+
+    @staticmethod
+    def backward(ctx, dfeats):
+        B, L, E, mode, R, n = ctx.cfg
+        feats = ctx.saved_tensors[0]
+        ws = ctx.saved_tensors[1:1 + n]
+        saved = ctx.saved_tensors[1 + n:]
+        dfeats = dfeats.contiguous()
+        G, Ftot = feats.shape
+        dev = dfeats.device
+        de = torch.empty(B, L, E, device=dev, dtype=torch.float32) if ctx.needs_input_grad[0] else None
+        grads, off = [], 0
+        wg = ctx.needs_input_grad[3]
+        for i, w in enumerate(ws):
+            col, arg = saved[2 * i], saved[2 * i + 1]
+            F_, k = w.shape[0], w.shape[2]
+            T = col.shape[0] // G
+            KE = col.shape[1]
+            dy = torch.empty(G * T, F_, device=dev, dtype=torch.float32)
+            call("cst_seqmax_bwd", dfeats[:, off:], Ftot, arg, feats[:, off:], Ftot, 1, dy, G, T, F_)
+            w2 = w.reshape(F_, KE)
+            grads += [wgrad(dy, col).view_as(w) if wg else None, colsum(dy) if wg else None]
+            if de is not None:
+                dcol = dgrad(dy, w2)
+                call("cst_col2im", dcol, de, B, L, E, k, mode, R, int(i > 0))
+            off += F_
+        return (de, None, None, *grads)
+
+
+class HighwayFn(torch.autograd.Function):
+    """sigmoid(h) * relu(h) + (1 - sigmoid(h)) * pred   (discriminator.py:46)."""
+
+    @staticmethod
+    def forward(ctx, h, pred):
+        out = torch.empty_like(h)
+        call("cst_highway_fwd", h, pred, out, h.numel())
+        ctx.save_for_backward(h, pred)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        h, pred = ctx.saved_tensors
+        dh, dp = torch.empty_like(h), torch.empty_like(h)
+        call("cst_highway_bwd", dout.contiguous(), h, pred, dh, dp, h.numel())
+        return dh, dp
+
+
+class EmbedFn(torch.autograd.Function):
+    """rows of `table` selected by ids (nn.Embedding), or columns when `transposed`
+    (the one-hot input path of RelGAN_D, discriminator.py:39 with main_optimize.py:117)."""
+
+    @staticmethod
+    def forward(ctx, ids, table, transposed):
+        ids = _i64(ids.reshape(-1))
+        E = table.shape[0] if transposed else table.shape[1]
+        out = torch.empty(ids.numel(), E, device=table.device, dtype=torch.float32)
+        embed_gather(table, out, ids_a=ids, transposed=transposed)
+        ctx.save_for_backward(ids)
+        ctx.cfg = (tuple(table.shape), transposed)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (ids,) = ctx.saved_tensors
+        shape, transposed = ctx.cfg
+        dt = torch.zeros(*shape, device=dout.device, dtype=torch.float32)
+        embed_scatter_add(dt, dout.contiguous(), ids_a=ids, transposed=transposed)
+        return None, dt, None
+
+
+class SoftEmbedFn(torch.autograd.Function):
+    """probs[R,V] @ table, table given as [V,E] (nn.Embedding.weight: rnn.py:61, mlm.py:31,
+    match.py:28, classifier.py:27) or as the [E,V] weight of a bias-free Linear (discriminator.py:39)."""
+
+    @staticmethod
+    def forward(ctx, p, table, table_is_ev):
+        R, V = p.shape
+        E = table.shape[0] if table_is_ev else table.shape[1]
+        out = torch.empty(R, E, device=p.device, dtype=torch.float32)
+        gemm(p, True, table, bool(table_is_ev), out, R, E, V)
+        ctx.save_for_backward(p, table)
+        ctx.ev = table_is_ev
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        p, table = ctx.saved_tensors
+        dout = dout.contiguous()
+        R, V = p.shape
+        E = dout.shape[1]
+        dp = dt = None
+        if ctx.needs_input_grad[0]:
+            dp = torch.empty(R, V, device=p.device, dtype=torch.float32)
+            gemm(dout, True, table, not ctx.ev, dp, R, V, E)
+        if ctx.needs_input_grad[1]:
+            dt = torch.empty_like(table)
+            if ctx.ev:
+                gemm(dout, False, p, False, dt, E, V, R)
+            else:
+                gemm(p, False, dout, False, dt, V, E, R)
+        return dp, dt, None
+
+
+def soft_embed(p2d, table, table_is_ev=False):
+    return SoftEmbedFn.apply(p2d, table, table_is_ev)

@@ -1,0 +1,168 @@
+/* libcst_hip.so -- C ABI of the MI355X (gfx950) kernels behind the three-stage style-transfer
+ * training path (reference: src/main_pretrain.py -> main_warmup.py -> main_optimize.py and
+ * src/model/{rnn,mlm,match,classifier,discriminator}.py of iptmt/consistent__style_transfer).
+ *
+ * The reference has no FFI of its own: its L0 is torch ops called from src/model/*.py
+ * (SURVEY.md section 1).  This header is the boundary the build introduces beneath that Python
+ * module API; each entry point names the reference call sites whose arithmetic it replaces.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every pointer is a DEVICE pointer (hipMalloc'ed memory,
+ *     e.g. torch tensor.data_ptr()) unless its name ends in _host;
+ *   - matrices are fp32 row-major with an explicit leading dimension in ELEMENTS; token ids
+ *     are int64 (loader.py:63-68 builds torch.long tensors);
+ *   - `stream` is a hipStream_t passed as void*; calls are asynchronous and ordered only by
+ *     that stream; nothing synchronises, allocates or frees (graph-capture safe);
+ *   - the caller owns every buffer; workspace sizes come from the *_workspace_floats twins;
+ *   - return value: 0 ok, 1 argument error, 2 launch error; cst_last_error() gives the text;
+ *     nothing throws across the boundary;
+ *   - dropout: (p, seed, stream_id, seed_dev) -- keep(idx) <=> (mix32(seed + *seed_dev,
+ *     stream_id, idx) >> 8) >= floor(p * 2^24), idx = row-major element index of the tensor the
+ *     mask applies to (oracle/rng.py is the same integer arithmetic); p = 0 disables;
+ *   - one process per GPU; re-entrant across processes, not across threads on one stream.
+ */
+#ifndef CST_HIP_H
+#define CST_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+const char* cst_last_error(void);
+int cst_abi_version(void);
+
+/* C[M,N] = epilogue(alpha * op(A)[M,K] . op(B)[K,N]) on the matrix cores.
+ * a_kmajor: A is [M,lda] (1) or [K,lda] (0);  b_kmajor: B is [N,ldb] (1, a torch Linear weight
+ * used as in F.linear) or [K,ldb] (0).  Epilogue order: +bias[n], +addend[m,n], act
+ * (0 none, 1 relu, 2 LeakyReLU(0.1), 3 aux>0 ? v*gate_scale : 0, 4 aux>0 ? v : 0.1 v),
+ * dropout over index m*N+n, optional C += v.  precision_f32 = 1 uses v_mfma_f32_16x16x4_f32
+ * (exact fp32), 0 uses v_mfma_f32_16x16x32_bf16 with fp32 accumulation.  batch > 1 repeats with
+ * the element strides s*.  tile: 0 auto, 64 or 128.
+ * Replaces: nn.Linear / F.linear / tensor.matmul at rnn.py:35-38,61,79-80,85; mlm.py:24,31,45;
+ * match.py:22,28,43; classifier.py:21,27,37; discriminator.py:28,35-37,39,45,48-49; the packed
+ * in_proj / out_proj / linear1 / linear2 of nn.TransformerEncoderLayer (mlm.py:20-22,
+ * match.py:18-20); nn.LSTM's gate projections (rnn.py:25-33); conv-as-GEMM for classifier.py:18
+ * and discriminator.py:21-24; and all their autograd backward products. */
+int cst_gemm(const float* A, long lda, int a_kmajor, const float* B, long ldb, int b_kmajor,
+             float* C, long ldc, int M, int N, int K,
+             const float* bias, const float* addend, long ldadd,
+             const float* aux, long ldaux, int act, float gate_scale,
+             int accumulate, float alpha, int precision_f32,
+             int batch, long sA, long sB, long sC, long sBias, long sAdd, long sAux,
+             float drop_p, uint32_t drop_seed, uint32_t drop_stream, const void* drop_seed_dev,
+             int tile, void* stream);
+
+/* Fused token cross-entropy forward + backward: row_loss[r] = logsumexp(x_r) - x_r[target_r];
+ * dlogits = grad_scale * (softmax(x_r) - onehot(target_r)) (may alias logits; null = forward
+ * only).  Rows with a target outside [0,V) contribute 0.  Replaces nn.CrossEntropyLoss at
+ * main_pretrain.py:71,73; main_warmup.py:52; main_optimize.py:106,109,137,139 (the mean is
+ * cst_reduce_sum with scale 1/R -- PAD rows count, ignore_index stays at its default). */
+int cst_token_ce(const float* logits, long ld, const int64_t* target, int R, int V,
+                 float* row_loss, float* dlogits, long ldd, float grad_scale, void* stream);
+
+/* p = softmax(logits * inv_tau) over V, argmax_out[r] = first index of max(p) (may be null).
+ * rnn.py:83 (softmax(logits / tau)) and the argmax inside hard_sample, rnn.py:52-53. */
+int cst_softmax_tau(const float* logits, long ld, float inv_tau, float* p, long ldp,
+                    int64_t* argmax_out, int R, int V, void* stream);
+/* dx = inv_tau * p * (dp - sum(dp * p)); dx may alias dp. */
+int cst_softmax_tau_bwd(const float* p, long ldp, const float* dp, long lddp, float inv_tau,
+                        float* dx, long lddx, int R, int V, void* stream);
+/* out[r] = first index of the row maximum (rnn.py:92; main_optimize.py:104,131,162). */
+int cst_argmax_rows(const float* x, long ld, int R, int V, int64_t* out, void* stream);
+
+/* z = res + dropout(x); y = LayerNorm(z) (eps inside the sqrt, biased variance); z may alias x or
+ * be null.  norm1/norm2 of nn.TransformerEncoderLayer with its dropout1/dropout2 and residuals. */
+int cst_add_layernorm_fwd(const float* x, const float* res, const float* gamma, const float* beta, float eps,
+                          float* z, float* y, float* mean, float* rstd, int T, int d,
+                          float drop_p, uint32_t drop_seed, uint32_t drop_stream, const void* drop_seed_dev,
+                          void* stream);
+long cst_layernorm_bwd_workspace_floats(int T, int d);
+int cst_layernorm_bwd(const float* dy, const float* z, const float* mean, const float* rstd, const float* gamma,
+                      float* dz, float* dgamma, float* dbeta, int accumulate,
+                      float* workspace, long workspace_floats, int T, int d, void* stream);
+/* out[c] (+)= sum_r X[r,c]  (bias gradients). */
+int cst_colsum(const float* X, long ld, int M, int N, float* out, int accumulate, void* stream);
+/* out[0] (+)= scale * sum(in[0..n)), one block, deterministic. */
+int cst_reduce_sum(const float* in, long n, float scale, float* out, int accumulate, void* stream);
+
+/* Unmasked multi-head self-attention core, qkv [B,S,3d] -> out [B,S,d], lse [B,H,S]; S <= 64,
+ * head dim in {8,32,64,96}; attention dropout on the probabilities (index ((b*H+h)*S+i)*S+j).
+ * nn.MultiheadAttention inside nn.TransformerEncoderLayer (mlm.py:20-22,43; match.py:18-20,39). */
+int cst_mha_fwd(const float* qkv, float* out, float* lse, int B, int S, int H, int hd,
+                float drop_p, uint32_t drop_seed, uint32_t drop_stream, const void* drop_seed_dev, void* stream);
+int cst_mha_bwd(const float* qkv, const float* dout, const float* lse, float* dqkv, int B, int S, int H, int hd,
+                float drop_p, uint32_t drop_seed, uint32_t drop_stream, const void* drop_seed_dev, void* stream);
+
+/* Single-query dot attention (rnn.py:46-50,76): out = softmax(q mem^T / sqrt(D)) mem; p [B,L] kept. */
+int cst_dot_attn_fwd(const float* q, long ldq, const float* mem, float* out, long ldo, float* p,
+                     int B, int L, int D, void* stream);
+/* dq (+)= ..., dmem += ... (dmem accumulates across decode steps; zero it first). */
+int cst_dot_attn_bwd(const float* dout, long lddo, const float* q, long ldq, const float* mem, const float* p,
+                     float* dq, long lddq, int dq_accumulate, float* dmem, int B, int L, int D, void* stream);
+
+/* LSTM cell (gate order i,f,g,o as nn.LSTM, rnn.py:25-33): gates [B,4H] pre-activation in,
+ * activations out (kept for backward); h_out2 optional second copy of h. */
+int cst_lstm_cell_fwd(float* gates, long ldg, const float* c_prev, long ldcp, float* h_out, long ldh,
+                      float* c_out, long ldc, float* h_out2, long ldh2, int B, int H, void* stream);
+int cst_lstm_cell_bwd(const float* gates, long ldg, const float* c_prev, long ldcp, const float* c_new, long ldcn,
+                      const float* dh, long lddh, const float* dh2, long lddh2, const float* dc, long lddc,
+                      float* dgates, long lddg, float* dc_prev, long lddcp, int B, int H, void* stream);
+
+/* out[r,:] = table[id(r)] * dropmask, id(r) = (*coin_dev) ? ids_a[r] : ids_b[r*ldb] (either list may
+ * be null); transposed reads table[c*ldt + id].  nn.Embedding at rnn.py:59,95; classifier.py:25;
+ * the one-hot path of discriminator.py:39 (main_optimize.py:117); the scheduled-sampling choice
+ * of rnn.py:91-95 is made on the device. */
+int cst_embed_gather(const int64_t* ids_a, const int64_t* ids_b, long ldb, const int* coin_dev,
+                     const float* table, long ldt, int transposed, float* out, long ldo, int R, int E, int V,
+                     float drop_p, uint32_t drop_seed, uint32_t drop_stream, const void* drop_seed_dev, void* stream);
+int cst_embed_scatter_add(const int64_t* ids_a, const int64_t* ids_b, long ldb, const int* coin_dev,
+                          const float* dout, long ldo, float* dtable, long ldt, int transposed, int R, int E, int V,
+                          float drop_p, uint32_t drop_seed, uint32_t drop_stream, const void* drop_seed_dev, void* stream);
+
+/* x[b, off+l, :] = (Etok[ids[b,l]] | pre[b,l,:]) + Epos[l] (+ seg_row)   (mlm.py:27-38; match.py:24-34). */
+int cst_tps_embed_fwd(const int64_t* ids, const float* pre, const float* Etok, const float* Epos, const float* seg_row,
+                      float* x, int B, int L, int d, int S, int off, int V, void* stream);
+int cst_tps_embed_bwd(const float* dx, const int64_t* ids, float* dpre, float* dEtok, float* dEpos, float* dseg_row,
+                      int B, int L, int d, int S, int off, int V, void* stream);
+
+/* im2col for the two convolution stacks: mode 0 = TextCNN (classifier.py:18,30: k x E window,
+ * zero padding k-1), mode 1 = RelGAN_D (discriminator.py:21-24,41: k x (E/R) window, stride E/R). */
+int cst_im2col(const float* e, float* col, int B, int L, int E, int k, int mode, int R, void* stream);
+int cst_col2im(const float* dcol, float* de, int B, int L, int E, int k, int mode, int R, int accumulate, void* stream);
+
+/* max over the middle axis of x [G,T,F] with argmax (classifier.py:32; discriminator.py:42; match.py:41). */
+int cst_seqmax_fwd(const float* x, float* out, long ldo, int* arg, int G, int T, int F, void* stream);
+int cst_seqmax_bwd(const float* dout, long ldd, const int* arg, const float* y, long ldy, int relu_gate,
+                   float* dx, int G, int T, int F, void* stream);
+
+int cst_dropout(const float* x, long ldx, float* out, long ldo, int R, int C,
+                float drop_p, uint32_t drop_seed, uint32_t drop_stream, const void* drop_seed_dev, void* stream);
+int cst_axpby(const float* a, long lda, float alpha, const float* b, long ldb, float beta,
+              float* out, long ldo, int R, int C, void* stream);
+/* out = x * (*s_dev): chain rule through a scalar loss whose upstream gradient lives on the device. */
+int cst_scale_dev(const float* x, const float* s_dev, float* out, long n, void* stream);
+/* dx = y > 0 ? dy * pos_scale : slope * dy */
+int cst_act_bwd(const float* dy, const float* y, float slope, float pos_scale, float* dx, long n, void* stream);
+/* highway gate of discriminator.py:45-46. */
+int cst_highway_fwd(const float* h, const float* pred, float* out, long n, void* stream);
+int cst_highway_bwd(const float* dout, const float* h, const float* pred, float* dh, float* dpred, long n, void* stream);
+
+/* loss[0] = weight * mean(...): kind 0 = MSE vs t (or the constant tconst when t is null)
+ * (main_pretrain.py:72; main_optimize.py:107), kind 1 = BCE-with-logits vs tconst
+ * (main_optimize.py:108,122-123); dx = gscale * d mean / dx. */
+int cst_small_loss(const float* x, const float* t, float tconst, int kind, long n, float weight, float* loss,
+                   float* dx, float gscale, void* stream);
+
+/* Trainer(gradient_clip_val) + torch.optim.Adam (main_pretrain.py:61-64,139; main_warmup.py:41-43,103;
+ * main_optimize.py:73-88,211), all on the device: out += sum(g^2); g *= min(1, max_norm/(sqrt(sumsq)+1e-6));
+ * Adam with bias correction from the device step counter. */
+int cst_sumsq_accumulate(const float* g, long n, float* out, void* stream);
+int cst_clip_scale(float* g, long n, const float* sumsq_dev, float max_norm, void* stream);
+int cst_adam_step(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2, float eps,
+                  const int* step_dev, void* stream);
+int cst_add_i32(int* p, int inc, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CST_HIP_H */

@@ -1,0 +1,398 @@
+"""GPU parity of the individual HIP kernels (called through the C ABI) against plain fp32 torch
+on the CPU.  Tolerances: the f32 MFMA mode and all VALU kernels are exact fp32 arithmetic in a
+different summation order (rtol 2e-4); the bf16 MFMA mode rounds operands to 8 significant bits
+(rtol 3e-2 of the output scale)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from oracle import rng as orng  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def ops():
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    from consistent__style_transfer_amd import ops as o
+    return o
+
+
+def dev(t):
+    return t.cuda()
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed + sum(shape))
+    return (torch.randn(*shape, generator=g) * scale).float()
+
+
+def close(a, b, rtol, atol, msg=""):
+    np.testing.assert_allclose(a.detach().cpu().numpy(), b.detach().cpu().numpy(), rtol=rtol, atol=atol, err_msg=msg)
+
+
+# ------------------------------------------------------------------------------------------ GEMM
+@pytest.mark.parametrize("prec", ["f32", "bf16"])
+@pytest.mark.parametrize("shape", [(37, 53, 19), (256, 512, 128), (700, 390, 100), (1024, 768, 96), (130, 10000, 64),
+                                   (64, 64, 10000)])
+@pytest.mark.parametrize("akm,bkm", [(1, 1), (1, 0), (0, 1), (0, 0)])
+def test_gemm_layouts(ops, prec, shape, akm, bkm):
+    ops.set_precision(prec)
+    M, N, K = shape
+    A = rnd(M, K, seed=1)
+    B = rnd(K, N, seed=2)
+    ref = A @ B
+    Ad = dev(A if akm else A.t().contiguous())
+    Bd = dev(B.t().contiguous() if bkm else B)
+    C = torch.full((M, N), float("nan"), device="cuda")
+    ops.gemm(Ad, akm, Bd, bkm, C, M, N, K)
+    tol = 2e-4 if prec == "f32" else 2e-2
+    close(C, ref, tol, tol * math.sqrt(K), f"{shape} {akm}{bkm}")
+    ops.set_precision("bf16")
+
+
+@pytest.mark.parametrize("tile", [64, 128])
+def test_gemm_epilogues(ops, tile):
+    ops.set_precision("f32")
+    M, N, K = 150, 90, 70
+    A, W = rnd(M, K, seed=3), rnd(N, K, seed=4)
+    bias, add, aux = rnd(N, seed=5), rnd(M, N, seed=6), rnd(M, N, seed=7)
+    base = A @ W.t() + bias + add
+    for act, ref in ((0, base), (1, torch.relu(base)), (2, F.leaky_relu(base, 0.1)),
+                     (3, torch.where(aux > 0, base * 1.5, torch.zeros_like(base))),
+                     (4, torch.where(aux > 0, base, 0.1 * base))):
+        C = torch.empty(M, N, device="cuda")
+        ops.gemm(dev(A), 1, dev(W), 1, C, M, N, K, bias=dev(bias), addend=dev(add), aux=dev(aux), act=act,
+                 gate_scale=1.5, tile=tile)
+        close(C, ref, 2e-4, 2e-4, f"act {act}")
+    # accumulate + alpha + strided C
+    big = torch.ones(M, N + 10, device="cuda")
+    ops.gemm(dev(A), 1, dev(W), 1, big[:, 3:3 + N], M, N, K, accumulate=True, alpha=0.5, tile=tile)
+    close(big[:, 3:3 + N], 1.0 + 0.5 * (A @ W.t()), 2e-4, 2e-4)
+    assert float(big[:, :3].sum()) == 3 * M and float(big[:, 3 + N:].sum()) == 7 * M
+    # dropout epilogue == oracle mask
+    d = ops.Drop(0.3, 1234, 77)
+    C = torch.empty(M, N, device="cuda")
+    ops.gemm(dev(A), 1, dev(W), 1, C, M, N, K, drop=d, tile=tile)
+    mask = torch.from_numpy(orng.dropout_mask(1234, 77, (M, N), 0.3))
+    close(C, (A @ W.t()) * mask, 2e-4, 2e-4)
+    ops.set_precision("bf16")
+
+
+def test_linear_autograd(ops):
+    ops.set_precision("f32")
+    x, W, b = rnd(33, 20, seed=1), rnd(17, 20, seed=2), rnd(17, seed=3)
+    for act in (0, 1, 2):
+        xr, Wr, br = (t.clone().requires_grad_(True) for t in (x, W, b))
+        y = xr @ Wr.t() + br
+        y = torch.relu(y) if act == 1 else (F.leaky_relu(y, 0.1) if act == 2 else y)
+        (y * rnd(33, 17, seed=9)).sum().backward()
+        xg, Wg, bg = (dev(t).requires_grad_(True) for t in (x, W, b))
+        yg = ops.linear(xg, Wg, bg, act=act)
+        (yg * dev(rnd(33, 17, seed=9))).sum().backward()
+        close(yg, y, 2e-4, 2e-5)
+        close(xg.grad, xr.grad, 2e-4, 2e-5)
+        close(Wg.grad, Wr.grad, 2e-4, 2e-5)
+        close(bg.grad, br.grad, 2e-4, 2e-5)
+    ops.set_precision("bf16")
+
+
+# --------------------------------------------------------------------------------- row kernels
+@pytest.mark.parametrize("R,V", [(7, 53), (64, 1000), (33, 10000), (5, 10003), (3, 40000)])
+def test_token_ce(ops, R, V):
+    x = rnd(R, V, seed=1, scale=3.0)
+    t = torch.randint(0, V, (R,), generator=torch.Generator().manual_seed(5))
+    xr = x.clone().requires_grad_(True)
+    ref = F.cross_entropy(xr, t) * 0.7
+    ref.backward()
+    xg = dev(x).requires_grad_(True)
+    loss = ops.token_ce(xg, dev(t), weight=0.7)
+    loss.backward()
+    close(loss.reshape(()), ref, 1e-5, 1e-6)
+    close(xg.grad, xr.grad, 1e-4, 1e-8)
+    # strided rows (a (B,T,V) slice) and unit_grad path
+    big = dev(rnd(R, 3 * V, seed=2, scale=2.0))
+    view = big[:, V:2 * V].detach().requires_grad_(True) if V % 4 == 0 else None
+    if view is not None:
+        l2 = ops.token_ce(view, dev(t), unit_grad=True)
+        l2.backward()
+        vr = big[:, V:2 * V].cpu().clone().requires_grad_(True)
+        r2 = F.cross_entropy(vr, t)
+        r2.backward()
+        close(l2.reshape(()), r2, 1e-5, 1e-6)
+        close(view.grad, vr.grad, 1e-4, 1e-8)
+
+
+@pytest.mark.parametrize("R,V,tau", [(6, 53, 0.1), (40, 10000, 0.1), (9, 10000, 1.0), (4, 4099, 0.5)])
+def test_softmax_tau(ops, R, V, tau):
+    x = rnd(R, V, seed=3, scale=2.0)
+    ref = torch.softmax(x / tau, -1)
+    p = torch.empty(R, V, device="cuda")
+    am = torch.empty(R, dtype=torch.int64, device="cuda")
+    ops.softmax_tau(dev(x), 1.0 / tau, p, am)
+    close(p, ref, 2e-4, 1e-9)
+    assert torch.equal(am.cpu(), p.cpu().argmax(-1))
+    assert torch.equal(am.cpu(), ref.argmax(-1))
+    am2 = ops.argmax_rows(dev(x))
+    assert torch.equal(am2.cpu(), x.argmax(-1))
+    dp = rnd(R, V, seed=4)
+    pr = ref.clone().requires_grad_(False)
+    xr = x.clone().requires_grad_(True)
+    (torch.softmax(xr / tau, -1) * dp).sum().backward()
+    dx = torch.empty(R, V, device="cuda")
+    ops.softmax_tau_bwd(p, dev(dp), 1.0 / tau, dx)
+    close(dx, xr.grad, 5e-4, 1e-7)
+
+
+def test_argmax_ties_first_index(ops):
+    x = torch.zeros(3, 1000)
+    x[0, 17] = x[0, 500] = 2.0
+    x[1, 999] = 1.0
+    assert ops.argmax_rows(dev(x)).cpu().tolist() == [17, 999, 0]
+
+
+@pytest.mark.parametrize("T,d", [(10, 32), (257, 512), (64, 768), (5, 1024), (9, 100)])
+def test_add_layernorm(ops, T, d):
+    from consistent__style_transfer_amd.ops import _ln_bwd, _ln_fwd
+    x, res, g, b = rnd(T, d, seed=1), rnd(T, d, seed=2), 1 + 0.1 * rnd(d, seed=3), rnd(d, seed=4)
+    drop = ops.Drop(0.1, 99, 1001)
+    mask = torch.from_numpy(orng.dropout_mask(99, 1001, (T, d), 0.1))
+    xr, rr, gr, br = (t.clone().requires_grad_(True) for t in (x, res, g, b))
+    zr = rr + xr * mask
+    yr = F.layer_norm(zr, (d,), gr, br, 1e-5)
+    w = rnd(T, d, seed=5)
+    (yr * w).sum().backward()
+    z, y = torch.empty(T, d, device="cuda"), torch.empty(T, d, device="cuda")
+    mean, rstd = torch.empty(T, device="cuda"), torch.empty(T, device="cuda")
+    _ln_fwd(dev(x), dev(res), dev(g), dev(b), drop, z, y, mean, rstd)
+    close(y, yr, 2e-4, 2e-5)
+    close(z, zr, 1e-6, 1e-6)
+    dz, dg, db = _ln_bwd(dev(w), z, mean, rstd, dev(g), True)
+    close(dz, rr.grad, 5e-4, 5e-5)
+    close(dg, gr.grad, 5e-4, 5e-4)
+    close(db, br.grad, 5e-4, 5e-4)
+
+
+def test_colsum_and_reduce(ops):
+    from consistent__style_transfer_amd._lib import call
+    for M, N in ((5, 7), (4608, 2048), (1000, 130)):
+        x = rnd(M, N, seed=1)
+        close(ops.colsum(dev(x)), x.sum(0), 2e-4, 2e-3)
+        acc = torch.ones(N, device="cuda")
+        ops.colsum(dev(x), out=acc, accumulate=True)
+        close(acc, 1 + x.sum(0), 2e-4, 2e-3)
+    out = torch.zeros(1, device="cuda")
+    call("cst_reduce_sum", dev(x.reshape(-1)), x.numel(), 0.5, out, 0)
+    close(out, (0.5 * x.sum()).reshape(1), 1e-4, 1e-2)
+
+
+# ----------------------------------------------------------------------------------- attention
+@pytest.mark.parametrize("B,S,H,hd,p", [(2, 6, 4, 8, 0.0), (3, 13, 2, 32, 0.1), (2, 36, 8, 64, 0.0), (2, 36, 8, 64, 0.1),
+                                        (1, 60, 8, 64, 0.0), (2, 18, 8, 96, 0.1), (1, 64, 2, 64, 0.0)])
+def test_mha(ops, B, S, H, hd, p):
+    from consistent__style_transfer_amd._lib import call
+    d = H * hd
+    qkv = rnd(B, S, 3 * d, seed=1, scale=0.7)
+    q, k, v = (t.reshape(B, S, H, hd).permute(0, 2, 1, 3) for t in qkv.split(d, -1))
+    qkv_r = qkv.clone().requires_grad_(True)
+    qr, kr, vr = (t.reshape(B, S, H, hd).permute(0, 2, 1, 3) for t in qkv_r.split(d, -1))
+    att = torch.softmax(qr @ kr.transpose(-1, -2) / math.sqrt(hd), -1)
+    if p > 0:
+        att = att * torch.from_numpy(orng.dropout_mask(7, 1000, (B, H, S, S), p))
+    ref = (att @ vr).permute(0, 2, 1, 3).reshape(B, S, d)
+    w = rnd(B, S, d, seed=2)
+    (ref * w).sum().backward()
+    drop = ops.Drop(p, 7, 1000)
+    out, lse = torch.empty(B * S, d, device="cuda"), torch.empty(B * H * S, device="cuda")
+    call("cst_mha_fwd", dev(qkv), out, lse, B, S, H, hd, *drop.args())
+    close(out.view(B, S, d), ref, 3e-4, 3e-5)
+    dqkv = torch.empty(B * S, 3 * d, device="cuda")
+    call("cst_mha_bwd", dev(qkv), dev(w), lse, dqkv, B, S, H, hd, *drop.args())
+    close(dqkv.view(B, S, 3 * d), qkv_r.grad, 1e-3, 1e-4)
+
+
+@pytest.mark.parametrize("B,L,D", [(3, 5, 32), (7, 18, 512), (2, 30, 512), (2, 64, 96)])
+def test_dot_attn(ops, B, L, D):
+    from consistent__style_transfer_amd._lib import call
+    q, mem, w = rnd(B, D, seed=1), rnd(B, L, D, seed=2), rnd(B, D, seed=3)
+    qr, mr = q.clone().requires_grad_(True), mem.clone().requires_grad_(True)
+    a = torch.softmax(torch.einsum("bd,bld->bl", qr, mr) / math.sqrt(D), -1)
+    ref = torch.einsum("bl,bld->bd", a, mr)
+    (ref * w).sum().backward()
+    qd = dev(torch.cat([q, torch.zeros(B, 11)], 1))              # strided query rows
+    out, pr = torch.empty(B, D + 5, device="cuda"), torch.empty(B, L, device="cuda")
+    call("cst_dot_attn_fwd", qd, D + 11, dev(mem), out, D + 5, pr, B, L, D)
+    close(out[:, :D], ref, 3e-4, 3e-5)
+    close(pr, a, 3e-4, 1e-6)
+    dq, dmem = torch.ones(B, D, device="cuda"), torch.zeros(B, L, D, device="cuda")
+    call("cst_dot_attn_bwd", dev(w), D, qd, D + 11, dev(mem), pr, dq, D, 1, dmem, B, L, D)
+    close(dq, 1 + qr.grad, 5e-4, 5e-5)
+    close(dmem, mr.grad, 5e-4, 5e-5)
+
+
+# --------------------------------------------------------------------------------- LSTM cell
+def test_lstm_cell(ops):
+    from consistent__style_transfer_amd.gen_fn import _cell_bwd, _cell_fwd
+    B, H = 5, 24
+    g, c = rnd(B, 4 * H, seed=1), rnd(B, H, seed=2)
+    gr, cr = g.clone().requires_grad_(True), c.clone().requires_grad_(True)
+    i, f, gg, o = gr.split(H, 1)
+    c2 = torch.sigmoid(f) * cr + torch.sigmoid(i) * torch.tanh(gg)
+    h2 = torch.sigmoid(o) * torch.tanh(c2)
+    wh, wc = rnd(B, H, seed=3), rnd(B, H, seed=4)
+    ((h2 * wh).sum() + (c2 * wc).sum()).backward()
+    gd, cd = dev(g), dev(c)
+    h_out, c_out, h2nd = torch.empty(B, H + 3, device="cuda"), torch.empty(B, H, device="cuda"), torch.empty(B, H, device="cuda")
+    _cell_fwd(gd, cd, h_out[:, :H], c_out, h2nd, B, H)
+    close(h_out[:, :H], h2, 2e-5, 2e-6)
+    close(h2nd, h2, 2e-5, 2e-6)
+    close(c_out, c2, 2e-5, 2e-6)
+    dg, dcp = torch.empty(B, 4 * H, device="cuda"), torch.empty(B, H, device="cuda")
+    half = dev(wh * 0.25)
+    _cell_bwd(gd, cd, c_out, dev(wh * 0.75), half, dev(wc), dg, dcp, B, H)
+    close(dg, gr.grad, 2e-4, 2e-5)
+    close(dcp, cr.grad, 2e-4, 2e-5)
+
+
+# ---------------------------------------------------------------------- embedding / conv / pool
+def test_embed_gather_scatter(ops):
+    V, E, R = 37, 12, 20
+    tab = rnd(V, E, seed=1)
+    ida = torch.randint(0, V, (R,), generator=torch.Generator().manual_seed(1))
+    idb = torch.randint(0, V, (R, 3), generator=torch.Generator().manual_seed(2))
+    d = ops.Drop(0.2, 5, 201)
+    mask = torch.from_numpy(orng.dropout_mask(5, 201, (R, E), 0.2))
+    for coin in (0, 1):
+        out = torch.empty(R, E, device="cuda")
+        cd = torch.tensor([coin], dtype=torch.int32, device="cuda")
+        ops.embed_gather(dev(tab), out, ids_a=dev(ida), ids_b=dev(idb)[:, 1], ldb=3, coin=cd, drop=d)
+        sel = ida if coin else idb[:, 1]
+        close(out, tab[sel] * mask, 1e-6, 1e-7)
+        dt = torch.zeros(V, E, device="cuda")
+        g = rnd(R, E, seed=3)
+        ops.embed_scatter_add(dt, dev(g), ids_a=dev(ida), ids_b=dev(idb)[:, 1], ldb=3, coin=cd, drop=d)
+        ref = torch.zeros(V, E).index_add_(0, sel, g * mask)
+        close(dt, ref, 1e-5, 1e-6)
+    # transposed table (columns of an [E,V] Linear weight)
+    W = rnd(E, V, seed=4)
+    out = torch.empty(R, E, device="cuda")
+    ops.embed_gather(dev(W), out, ids_a=dev(ida), transposed=True)
+    close(out, W.t()[ida], 1e-6, 1e-7)
+
+
+def test_tps_embed(ops):
+    B, L1, L2, d, V = 3, 5, 4, 16, 29
+    Et, Ep, Es = (rnd(V, d, seed=1).requires_grad_(True), rnd(100, d, seed=2).requires_grad_(True),
+                  rnd(2, d, seed=3).requires_grad_(True))
+    x1 = torch.randint(0, V, (B, L1), generator=torch.Generator().manual_seed(3))
+    p2 = torch.softmax(rnd(B, L2, V, seed=4), -1).requires_grad_(True)
+    ref = torch.cat([Et[x1] + Ep[:L1] + Es[0], p2 @ Et + Ep[:L2] + Es[1]], 1)
+    w = rnd(B, L1 + L2, d, seed=5)
+    (ref * w).sum().backward()
+    ops.set_precision("f32")
+    Etg, Epg, Esg = (dev(t.detach()).requires_grad_(True) for t in (Et, Ep, Es))
+    p2g = dev(p2.detach()).requires_grad_(True)
+    out = ops.TpsEmbedFn.apply(dev(x1), p2g, Etg, Epg, Esg)
+    (out * dev(w)).sum().backward()
+    ops.set_precision("bf16")
+    close(out, ref, 2e-4, 2e-5)
+    for a, b in ((Etg, Et), (Epg, Ep), (Esg, Es), (p2g, p2)):
+        close(a.grad, b.grad, 3e-4, 3e-5)
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_conv_bank(ops, mode):
+    ops.set_precision("f32")
+    B, L, E, R = 3, 7, 16, 4
+    e = rnd(B, L, E, seed=1).requires_grad_(True)
+    if mode == 0:
+        convs = [torch.nn.Conv2d(1, 5, (k, E), padding=(k - 1, 0)) for k in (3, 4, 5)]
+        ys = [F.relu(c(e.unsqueeze(1))).squeeze(3) for c in convs]
+        ref = torch.cat([F.max_pool1d(y, y.size(2)).squeeze(2) for y in ys], 1)
+    else:
+        es = E // R
+        convs = [torch.nn.Conv2d(1, 6, (f, es), stride=(1, es)) for f in (2, 3, 4, 5)]
+        cons = [F.relu(c(e.unsqueeze(1))) for c in convs]
+        pools = [F.max_pool2d(c, (c.size(2), 1)).squeeze(2) for c in cons]
+        ref = torch.cat(pools, 1).permute(0, 2, 1).contiguous().view(B * R, -1)
+    w = rnd(*ref.shape, seed=2)
+    (ref * w).sum().backward()
+    eg = dev(e.detach()).requires_grad_(True)
+    wb = []
+    for c in convs:
+        wb += [dev(c.weight.detach()).requires_grad_(True), dev(c.bias.detach()).requires_grad_(True)]
+    out = ops.ConvBankFn.apply(eg, mode, R if mode else 1, *wb)
+    (out * dev(w)).sum().backward()
+    ops.set_precision("bf16")
+    close(out, ref, 2e-4, 2e-5)
+    close(eg.grad, e.grad, 3e-4, 3e-5)
+    for i, c in enumerate(convs):
+        close(wb[2 * i].grad, c.weight.grad, 3e-4, 3e-5)
+        close(wb[2 * i + 1].grad, c.bias.grad, 3e-4, 3e-5)
+
+
+def test_small_ops(ops):
+    from consistent__style_transfer_amd._lib import call
+    # highway
+    h, pr = rnd(9, 33, seed=1).requires_grad_(True), rnd(9, 33, seed=2).requires_grad_(True)
+    ref = torch.sigmoid(h) * F.relu(h) + (1 - torch.sigmoid(h)) * pr
+    w = rnd(9, 33, seed=3)
+    (ref * w).sum().backward()
+    hg, pg = dev(h.detach()).requires_grad_(True), dev(pr.detach()).requires_grad_(True)
+    out = ops.HighwayFn.apply(hg, pg)
+    (out * dev(w)).sum().backward()
+    close(out, ref, 1e-5, 1e-6)
+    close(hg.grad, h.grad, 1e-4, 1e-6)
+    close(pg.grad, pr.grad, 1e-4, 1e-6)
+    # losses
+    x, t = rnd(50, seed=4).requires_grad_(True), rnd(50, seed=5)
+    for ref_fn, mine in ((lambda: F.mse_loss(x, t) * 0.5, lambda xg: ops.mse_loss(xg, dev(t), weight=0.5)),
+                         (lambda: F.mse_loss(x, torch.full_like(x, 0.25)), lambda xg: ops.mse_loss(xg, None, 0.25)),
+                         (lambda: F.binary_cross_entropy_with_logits(x, torch.ones_like(x)), lambda xg: ops.bce_logits_loss(xg, 1.0)),
+                         (lambda: F.binary_cross_entropy_with_logits(x, torch.zeros_like(x)) * 2, lambda xg: ops.bce_logits_loss(xg, 0.0, 2.0))):
+        x.grad = None
+        r = ref_fn()
+        (r * 3.0).backward()
+        xg = dev(x.detach()).requires_grad_(True)
+        l = mine(xg)
+        (l * 3.0).sum().backward()
+        close(l.reshape(()), r, 1e-5, 1e-6)
+        close(xg.grad, x.grad, 1e-4, 1e-7)
+    # seq max
+    xs = rnd(4, 9, 20, seed=6).requires_grad_(True)
+    r = xs.max(1).values
+    (r * rnd(4, 20, seed=7)).sum().backward()
+    xg = dev(xs.detach()).requires_grad_(True)
+    o = ops.SeqMaxFn.apply(xg)
+    (o * dev(rnd(4, 20, seed=7))).sum().backward()
+    close(o, r, 0, 0)
+    close(xg.grad, xs.grad, 0, 0)
+    # dropout == oracle mask
+    xx = rnd(13, 40, seed=8)
+    y = ops.dropout2d(dev(xx), ops.Drop(0.5, 42, 2000))
+    close(y, xx * torch.from_numpy(orng.dropout_mask(42, 2000, (13, 40), 0.5)), 1e-6, 1e-7)
+
+
+def test_clip_and_adam(ops):
+    from consistent__style_transfer_amd._lib import call
+    n = 5000
+    p0, g0 = rnd(n, seed=1), rnd(n, seed=2) * 3
+    pr = p0.clone().requires_grad_(True)
+    opt = torch.optim.Adam([pr], lr=1e-3)
+    p, m, v = dev(p0), torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
+    step = torch.zeros(1, dtype=torch.int32, device="cuda")
+    for it in range(3):
+        pr.grad = g0.clone() * (it + 1)
+        torch.nn.utils.clip_grad_norm_([pr], 5.0)
+        opt.step()
+        g = dev(g0 * (it + 1))
+        ss = torch.zeros(1, device="cuda")
+        call("cst_sumsq_accumulate", g, n, ss)
+        call("cst_clip_scale", g, n, ss, 5.0)
+        close(g, pr.grad, 1e-5, 1e-6)
+        call("cst_add_i32", step, 1)
+        call("cst_adam_step", p, g, m, v, n, 1e-3, 0.9, 0.999, 1e-8, step)
+        close(p, pr, 1e-5, 1e-6)
