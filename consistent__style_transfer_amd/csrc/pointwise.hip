@@ -506,3 +506,34 @@ extern "C" int cst_add_i32(int* p, int inc, void* stream) {
     CST_LAUNCH_CHECK("cst_add_i32");
     return CST_OK;
 }
+
+// ---------------------------------------------------------------------------------------------
+// multi-tensor gather: flat[dst_off[t] + i] (+)= src_t[i] for every tensor t in one launch.
+// Chunk c covers elements [chunk_start[c], chunk_start[c] + CHUNK) of tensor chunk_tensor[c].
+// Moves the per-parameter gradients autograd produced into the flat gradient buffer that the
+// clip / Adam kernels and the RCCL all-reduce work on.
+// ---------------------------------------------------------------------------------------------
+#define MT_CHUNK 4096
+__global__ __launch_bounds__(256) void multi_accumulate_kernel(const float* const* __restrict__ srcs, const long* __restrict__ dst_off,
+                                                               const long* __restrict__ sizes, const int* __restrict__ chunk_tensor,
+                                                               const long* __restrict__ chunk_start, float* __restrict__ flat,
+                                                               int accumulate) {
+    const int t = chunk_tensor[blockIdx.x];
+    const float* src = srcs[t];
+    if (!src) return;
+    const long s0 = chunk_start[blockIdx.x], n = sizes[t];
+    float* dst = flat + dst_off[t];
+    for (long i = s0 + threadIdx.x; i < s0 + MT_CHUNK && i < n; i += 256)
+        dst[i] = accumulate ? dst[i] + src[i] : src[i];
+}
+
+extern "C" int cst_multi_accumulate(const void* srcs_dev, const long* dst_off_dev, const long* sizes_dev,
+                                    const int* chunk_tensor_dev, const long* chunk_start_dev, int nchunks,
+                                    float* flat, int accumulate, void* stream) {
+    CST_REQUIRE(srcs_dev && dst_off_dev && sizes_dev && chunk_tensor_dev && chunk_start_dev && flat && nchunks > 0,
+                "cst_multi_accumulate: bad arguments");
+    hipLaunchKernelGGL(multi_accumulate_kernel, dim3(nchunks), dim3(256), 0, (hipStream_t)stream,
+                       (const float* const*)srcs_dev, dst_off_dev, sizes_dev, chunk_tensor_dev, chunk_start_dev, flat, accumulate);
+    CST_LAUNCH_CHECK("cst_multi_accumulate");
+    return CST_OK;
+}

@@ -547,6 +547,8 @@ class EmbedFn(torch.autograd.Function):
     def backward(ctx, dout):
         (ids,) = ctx.saved_tensors
         shape, transposed = ctx.cfg
+        if not ctx.needs_input_grad[1]:
+            return None, None, None
         dt = torch.zeros(*shape, device=dout.device, dtype=torch.float32)
         embed_scatter_add(dt, dout.contiguous(), ids_a=ids, transposed=transposed)
         return None, dt, None

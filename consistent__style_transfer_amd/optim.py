@@ -1,0 +1,104 @@
+"""Flat-buffer Adam + global-norm clipping on the device (no host synchronisation).
+
+Restates what the reference gets from torch.optim.Adam (main_pretrain.py:61-64, main_warmup.py:41-43,
+main_optimize.py:73-76) and Trainer(gradient_clip_val=...) -> torch.nn.utils.clip_grad_norm_
+(main_pretrain.py:139, main_warmup.py:103, main_optimize.py:211).
+
+All parameters of a group live in ONE contiguous fp32 buffer (each nn.Parameter is a view into
+it) and so do their gradients, first and second moments.  One kernel launch each gathers the
+per-parameter gradients autograd produced (cst_multi_accumulate), sums squares, scales by the clip
+coefficient and applies Adam.  The flat gradient buffer is also what the data-parallel
+all-reduce operates on (parallel.py).
+"""
+import torch
+
+from ._lib import call
+
+MT_CHUNK = 4096
+
+
+class FlatGroup:
+    def __init__(self, params, lr, betas=(0.9, 0.999), eps=1e-8):
+        self.params = [p for p in params]
+        assert self.params, "empty parameter group"
+        dev = self.params[0].device
+        self.lr, self.betas, self.eps = lr, betas, eps
+        sizes = [p.numel() for p in self.params]
+        offs, tot = [], 0
+        for n in sizes:
+            offs.append(tot)
+            tot += (n + 3) // 4 * 4                      # keep every tensor 16-byte aligned
+        self.total = tot
+        self.offsets, self.sizes = offs, sizes
+        self.flat_p = torch.zeros(tot, device=dev, dtype=torch.float32)
+        for p, o, n in zip(self.params, offs, sizes):
+            self.flat_p[o:o + n].copy_(p.data.reshape(-1))
+            p.data = self.flat_p[o:o + n].view_as(p.data)
+        self.flat_g = torch.zeros(tot, device=dev, dtype=torch.float32)
+        self.m = torch.zeros(tot, device=dev, dtype=torch.float32)
+        self.v = torch.zeros(tot, device=dev, dtype=torch.float32)
+        self.step_dev = torch.zeros(1, device=dev, dtype=torch.int32)
+        self.has_grad = False                             # flat_g holds gradients not yet consumed by a step
+        ct, cs = [], []
+        for t, n in enumerate(sizes):
+            for s in range(0, n, MT_CHUNK):
+                ct.append(t)
+                cs.append(s)
+        self.nchunks = len(ct)
+        self.chunk_tensor = torch.tensor(ct, dtype=torch.int32, device=dev)
+        self.chunk_start = torch.tensor(cs, dtype=torch.int64, device=dev)
+        self.dst_off = torch.tensor(offs, dtype=torch.int64, device=dev)
+        self.sizes_dev = torch.tensor(sizes, dtype=torch.int64, device=dev)
+        self._src_host = torch.zeros(len(sizes), dtype=torch.int64).pin_memory() if dev.type == "cuda" else None
+        self.srcs = torch.zeros(len(sizes), dtype=torch.int64, device=dev)
+        self._keep = None
+
+    def gather_grads(self, accumulate):
+        """Move p.grad of every parameter into the flat gradient buffer (+= when `accumulate`, the
+        reference's behaviour while an optimizer has not called zero_grad), then drop p.grad."""
+        grads = [p.grad for p in self.params]
+        if not accumulate:
+            if any(g is None for g in grads):
+                self.flat_g.zero_()
+        for i, g in enumerate(grads):
+            if g is not None and not g.is_contiguous():
+                grads[i] = g.contiguous()
+            self._src_host[i] = grads[i].data_ptr() if grads[i] is not None else 0
+        self.srcs.copy_(self._src_host, non_blocking=True)
+        self._keep = grads                                 # keep sources alive until the kernel ran
+        call("cst_multi_accumulate", self.srcs, self.dst_off, self.sizes_dev, self.chunk_tensor, self.chunk_start,
+             self.nchunks, self.flat_g, int(accumulate))
+        for p in self.params:
+            p.grad = None
+        self.has_grad = True
+
+    def sumsq_into(self, out):
+        call("cst_sumsq_accumulate", self.flat_g, self.total, out)
+
+    def clip(self, sumsq, max_norm):
+        call("cst_clip_scale", self.flat_g, self.total, sumsq, float(max_norm))
+
+    def step(self):
+        call("cst_add_i32", self.step_dev, 1)
+        call("cst_adam_step", self.flat_p, self.flat_g, self.m, self.v, self.total, float(self.lr),
+             float(self.betas[0]), float(self.betas[1]), float(self.eps), self.step_dev)
+
+    def zero_grad(self):
+        self.flat_g.zero_()
+        self.has_grad = False
+
+    def grad_of(self, p):
+        i = next(k for k, q in enumerate(self.params) if q is p)
+        return self.flat_g[self.offsets[i]:self.offsets[i] + self.sizes[i]].view_as(p)
+
+
+def clip_groups(groups, max_norm, scratch):
+    """clip_grad_norm_ over every group that currently holds gradients (one global norm)."""
+    live = [g for g in groups if g.has_grad]
+    if not live or max_norm is None or max_norm <= 0:
+        return
+    scratch.zero_()
+    for g in live:
+        g.sumsq_into(scratch)
+    for g in live:
+        g.clip(scratch, max_norm)

@@ -1,0 +1,222 @@
+"""The three training stages as step functions over the HIP-backed modules, with the optimiser and
+Trainer semantics the reference obtains from pytorch_lightning restated as this build's own
+contract:
+
+  * per batch, per optimizer in order: only that optimizer's parameters require grad (critics stay
+    frozen in the generator step yet gradient flows through them); training_step -> backward ->
+    clip_grad_norm_ over every parameter that currently holds a gradient (including the
+    discriminator's accumulating gradients during the generator step) -> optimizer_step hook;
+  * optimize stage: generator steps + zero_grad every batch, discriminator only when
+    batch_idx % 4 == 0, its gradients accumulating in between (main_optimize.py:78-88);
+  * all losses are means; token CE counts PAD targets.
+
+Reference: src/main_pretrain.py:49-77, src/main_warmup.py:36-58, src/main_optimize.py:69-141.
+"""
+import random
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from .model import MLM, DenoiseLSTM, Matcher, RelGAN_D, TextCNN
+from .optim import FlatGroup, clip_groups
+
+
+def _set_requires_grad(params, flag):
+    for p in params:
+        p.requires_grad_(flag)
+
+
+def _scalar(t):
+    return t.reshape(())
+
+
+class PretrainStage(nn.Module):
+    """main_pretrain.py PretrainModel: joint training of TextCNN (CE), Matcher (MSE against the WMD
+    label) and MLM (token CE) with Adam(lr 1e-4), clip 5.0; per-model early-freeze flags."""
+    clip = 5.0
+
+    def __init__(self, n_vocab, n_class=2, lr=1e-4):
+        super().__init__()
+        self.classifier = TextCNN(n_vocab, n_class=n_class)
+        self.matcher = Matcher(n_vocab)
+        self.denoiser = MLM(n_vocab, n_class=n_class)
+        self.flags = {"cls": True, "mat": True, "dn": True}
+        self.named_models = {"cls": self.classifier, "mat": self.matcher, "dn": self.denoiser}
+        self.best_eval = {name: float("inf") for name in self.flags}
+        self.lr = lr
+        self.groups = None
+
+    def setup_optim(self):
+        dev = next(self.parameters()).device
+        self.groups = {k: FlatGroup(m.parameters(), self.lr) for k, m in self.named_models.items()}
+        self._scratch = torch.zeros(1, device=dev, dtype=torch.float32)
+
+    def losses(self, batch, seed=None):
+        """(s_loss, c_loss, dn_loss) -- main_pretrain.py:66-77; a frozen model contributes None."""
+        x, nx_1, nx_2, nx, label, c_label = batch
+        s = c = dn = None
+        if self.flags["cls"]:
+            s = ops.token_ce(self.classifier(x, seed=seed), label)
+        if self.flags["mat"]:
+            c = ops.mse_loss(self.matcher(nx_1, nx_2, seed=seed), c_label)
+        if self.flags["dn"]:
+            lg = self.denoiser(nx, seed=seed)
+            dn = ops.token_ce(lg.view(-1, lg.size(-1)), x.reshape(-1), unit_grad=True)
+        return s, c, dn
+
+    def train_step(self, batch, seed=None, reducer=None):
+        s, c, dn = self.losses(batch, seed)
+        terms = [t for t in (s, c, dn) if t is not None]
+        total = terms[0]
+        for t in terms[1:]:
+            total = total + t
+        total.backward()
+        live = [self.groups[k] for k in self.flags if self.flags[k]]
+        for g in live:
+            g.gather_grads(False)
+        if reducer is not None:
+            reducer(live)
+        clip_groups(live, self.clip, self._scratch)
+        for g in live:
+            g.step()
+            g.zero_grad()
+        return {"s_loss": s, "c_loss": c, "dn_loss": dn, "loss": total}
+
+
+class WarmupStage(nn.Module):
+    """main_warmup.py WarmupModel: generator denoising auto-encoding, Adam(lr 1e-3), clip 1.0."""
+    clip = 1.0
+
+    def __init__(self, n_vocab, n_class=2, max_len=18, lr=1e-3):
+        super().__init__()
+        self.generator = DenoiseLSTM(n_vocab, n_class, max_len)
+        self.lr = lr
+        self.group = None
+
+    def setup_optim(self):
+        self.group = FlatGroup(self.generator.parameters(), self.lr)
+        self._scratch = torch.zeros(1, device=self.group.flat_p.device, dtype=torch.float32)
+
+    def loss(self, batch, coins=None, seed=None):
+        nx, x, labels = batch
+        lg = self.generator(nx, labels, x, labels, coins=coins, seed=seed)      # main_warmup.py:47-48
+        return ops.token_ce(lg.view(-1, lg.size(-1)), x.reshape(-1), unit_grad=True)
+
+    def train_step(self, batch, coins=None, seed=None, reducer=None):
+        loss = self.loss(batch, coins, seed)
+        loss.backward()
+        self.group.gather_grads(False)
+        if reducer is not None:
+            reducer([self.group])
+        clip_groups([self.group], self.clip, self._scratch)
+        self.group.step()
+        self.group.zero_grad()
+        return {"dn_loss": loss, "loss": loss}
+
+
+class OptimizeStage(nn.Module):
+    """main_optimize.py GenerationTuner: two-optimizer adversarial fine-tuning."""
+    clip = 1.0
+
+    def __init__(self, n_vocab, n_class=2, max_len=18, w_s=0.1, w_c=0.5, w_adv=1.0, w_bt=1.0, tau=0.1, gap=0.0,
+                 lr=1e-5):
+        super().__init__()
+        self.classifier = TextCNN(n_vocab, n_class=n_class)
+        self.matcher = Matcher(n_vocab)
+        self.nt_checker = MLM(n_vocab, n_class)
+        self.disc = RelGAN_D(n_vocab)
+        self.generator = DenoiseLSTM(n_vocab, n_class, max_len)
+        self.ws, self.wc, self.w_adv, self.w_bt, self.tau, self.gap = w_s, w_c, w_adv, w_bt, tau, gap
+        self.lr = lr
+        self.n_vocab = n_vocab
+
+    def setup_optim(self):
+        self.g_group = FlatGroup(self.generator.parameters(), self.lr)
+        self.d_group = FlatGroup(self.disc.parameters(), self.lr)
+        self._scratch = torch.zeros(1, device=self.g_group.flat_p.device, dtype=torch.float32)
+        self._all = list(self.parameters())
+
+    def forward(self, x, src_labels, tgt_labels, tau, seed=None):
+        return self.generator(x, src_labels, None, tgt_labels, res_type="softmax", tau=tau, seed=seed)
+
+    # ---- optimizer_idx 0 (main_optimize.py:96-113) ------------------------------------------
+    def g_losses(self, batch, coins=None, seed=None):
+        x, labels = batch
+        sample_p = self.forward(x, labels, 1 - labels, self.tau, seed=seed)
+        s_logits = self.classifier(sample_p, seed=seed)
+        c_logits = self.matcher(sample_p, x, seed=seed)
+        was_training = self.disc.training
+        self.disc.eval()                                                      # main_optimize.py:102
+        adv_logits = self.disc(sample_p)
+        self.disc.train(was_training)
+        with torch.no_grad():
+            tokens = self.generator.last_ids.t().contiguous()                 # == sample_p.argmax(-1)
+        bk_logits = self.generator(tokens, 1 - labels, x, labels, coins=coins,
+                                   seed=None if seed is None else seed + 1)
+        s_loss = ops.token_ce(s_logits, 1 - labels, weight=1.0)
+        c_loss = ops.mse_loss(c_logits, None, self.gap)
+        g_loss = ops.bce_logits_loss(adv_logits, 1.0)
+        bk_loss = ops.token_ce(bk_logits.view(-1, bk_logits.size(-1)), x.reshape(-1), weight=self.w_bt, unit_grad=True)
+        loss = bk_loss + self.wc * c_loss + self.w_adv * g_loss + self.ws * s_loss
+        return {"loss": loss, "G": g_loss, "STI": s_loss, "CP_logits": c_logits, "BK": bk_loss / self.w_bt if self.w_bt else bk_loss,
+                "sample_ids": tokens}
+
+    # ---- optimizer_idx 1 (main_optimize.py:115-124) -----------------------------------------
+    def d_losses(self, batch, seed=None):
+        x, labels = batch
+        t_logits = self.disc(x, seed=seed)                                    # ids fast path == one_hot(x).float()
+        with torch.no_grad():
+            x_ = self.forward(x, labels, 1 - labels, self.tau, seed=None if seed is None else seed + 2)
+        f_logits = self.disc(x_, seed=None if seed is None else seed + 3)
+        d_loss = 0.5 * (ops.bce_logits_loss(t_logits, 1.0) + ops.bce_logits_loss(f_logits, 0.0))
+        return {"loss": self.w_adv * d_loss, "D": d_loss}
+
+    def train_step(self, batch, batch_idx, coins=None, seed=None, reducer=None):
+        logs = {}
+        # generator step
+        _set_requires_grad(self._all, False)
+        _set_requires_grad(self.g_group.params, True)
+        r = self.g_losses(batch, coins, seed)
+        r["loss"].backward()
+        self.g_group.gather_grads(False)
+        if reducer is not None:
+            reducer([self.g_group])
+        clip_groups([self.g_group, self.d_group], self.clip, self._scratch)
+        self.g_group.step()
+        self.g_group.zero_grad()
+        logs.update(G=r["G"], STI=r["STI"], BK=r["BK"], CP_logits=r["CP_logits"], g_total=r["loss"])
+        # discriminator step
+        _set_requires_grad(self._all, False)
+        _set_requires_grad(self.d_group.params, True)
+        self.disc.train(self.training)                                        # main_optimize.py:116
+        d = self.d_losses(batch, seed)
+        d["loss"].backward()
+        self.d_group.gather_grads(self.d_group.has_grad)                       # accumulates until zero_grad
+        if reducer is not None and batch_idx % 4 == 0:
+            reducer([self.d_group])
+        clip_groups([self.g_group, self.d_group], self.clip, self._scratch)
+        if batch_idx % 4 == 0:                                                # main_optimize.py:85-88
+            self.d_group.step()
+            self.d_group.zero_grad()
+        logs.update(D=d["D"])
+        return logs
+
+    # ---- validation_step (main_optimize.py:127-141) -----------------------------------------
+    @torch.no_grad()
+    def val_loss(self, batch):
+        x, labels = batch
+        self.forward(x, labels, 1 - labels, self.tau)
+        tokens = self.generator.last_ids.t().contiguous()
+        s_loss = ops.token_ce(self.classifier(tokens), 1 - labels)
+        c_logits = self.matcher(tokens, x)
+        nt = self.nt_checker(tokens)
+        nt_loss = ops.token_ce(nt.view(-1, nt.size(-1)), tokens.reshape(-1))
+        return _scalar(nt_loss) + _scalar(s_loss) + c_logits.mean()
+
+    # ---- test_step (main_optimize.py:157-164) -----------------------------------------------
+    @torch.no_grad()
+    def transfer(self, batch):
+        x, labels = batch
+        self.generator(x, labels, None, 1 - labels)
+        return self.generator.last_ids.t().contiguous()                       # (B, max_len) greedy ids

@@ -161,6 +161,11 @@ int cst_clip_scale(float* g, long n, const float* sumsq_dev, float max_norm, voi
 int cst_adam_step(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2, float eps,
                   const int* step_dev, void* stream);
 int cst_add_i32(int* p, int inc, void* stream);
+/* flat[dst_off[t] + i] (+)= srcs[t][i] for all tensors in one launch (null source = skipped);
+ * chunk tables (4096 elements per chunk) are built by the host once per parameter set. */
+int cst_multi_accumulate(const void* srcs_dev, const long* dst_off_dev, const long* sizes_dev,
+                         const int* chunk_tensor_dev, const long* chunk_start_dev, int nchunks,
+                         float* flat, int accumulate, void* stream);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,84 @@
+"""Oracle training loops: the three stages stepped with torch.optim.Adam + clip_grad_norm_ on the
+CPU, following the Trainer semantics written down in consistent__style_transfer_amd/stages.py.
+
+TEST INFRASTRUCTURE (see oracle/__init__.py); also the `cpu_baseline` that bench.py times.
+Pinned by tests/golden/curves_*.npz (the same loops run on the imported reference modules).
+"""
+import torch
+
+from . import steps as S
+
+
+def _params(P):
+    return [p for p in P.values()]
+
+
+def _clip(param_sets, max_norm):
+    ps = [p for P in param_sets for p in P.values() if p.grad is not None]
+    if ps:
+        torch.nn.utils.clip_grad_norm_(ps, max_norm)
+
+
+def _req(on, all_sets):
+    for P in all_sets:
+        for p in P.values():
+            p.requires_grad_(False)
+    for P in on:
+        for p in P.values():
+            p.requires_grad_(True)
+
+
+class OracleOptimize:
+    def __init__(self, Pg, Pc, Pm, Pnt, Pd, hp, n_head, max_len, lr=1e-5):
+        self.Pg, self.Pc, self.Pm, self.Pnt, self.Pd = Pg, Pc, Pm, Pnt, Pd
+        self.hp, self.n_head, self.max_len = hp, n_head, max_len
+        self.all = (Pg, Pc, Pm, Pnt, Pd)
+        _req((Pg, Pd), self.all)
+        self.og = torch.optim.Adam(_params(Pg), lr=lr)
+        self.od = torch.optim.Adam(_params(Pd), lr=lr)
+
+    def step(self, batch, batch_idx, coins):
+        _req((self.Pg,), self.all)
+        r = S.optimize_g_losses(self.Pg, self.Pc, self.Pm, self.Pd, batch, coins, self.hp, self.n_head, self.max_len)
+        r["loss"].backward()
+        _clip(self.all, 1.0)
+        self.og.step()
+        self.og.zero_grad()
+        _req((self.Pd,), self.all)
+        d = S.optimize_d_losses(self.Pg, self.Pd, batch, self.hp, self.max_len)
+        d["loss"].backward()
+        _clip(self.all, 1.0)
+        if batch_idx % 4 == 0:
+            self.od.step()
+            self.od.zero_grad()
+        return [r["loss"].item(), r["G"].item(), r["STI"].item(), r["CP"].item(), r["BK"].item(), d["D"].item()]
+
+
+class OracleWarmup:
+    def __init__(self, Pg, lr=1e-3):
+        self.Pg = Pg
+        _req((Pg,), (Pg,))
+        self.opt = torch.optim.Adam(_params(Pg), lr=lr)
+
+    def step(self, batch, coins):
+        loss = S.warmup_loss(self.Pg, batch, coins)
+        loss.backward()
+        _clip((self.Pg,), 1.0)
+        self.opt.step()
+        self.opt.zero_grad()
+        return loss.item()
+
+
+class OraclePretrain:
+    def __init__(self, Pc, Pm, Pd, n_head, lr=1e-4):
+        self.Pc, self.Pm, self.Pd, self.n_head = Pc, Pm, Pd, n_head
+        _req((Pc, Pm, Pd), (Pc, Pm, Pd))
+        self.opt = torch.optim.Adam(_params(Pc) + _params(Pm) + _params(Pd), lr=lr)
+
+    def step(self, batch):
+        s, c, dn = S.pretrain_losses(self.Pc, self.Pm, self.Pd, batch, self.n_head)
+        (s + c + dn).backward()
+        _clip((self.Pc, self.Pm, self.Pd), 5.0)
+        self.opt.step()
+        self.opt.zero_grad()
+        return [s.item(), c.item(), dn.item()]

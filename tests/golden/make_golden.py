@@ -279,6 +279,122 @@ def step_goldens(name, c):
     return out
 
 
+def curve_goldens(name, c, steps):
+    """Multi-step loss curves of the three stages in deterministic mode (dropout 0, recorded
+    coins, seeded batches), with the Trainer semantics restated from pytorch_lightning 0.6/0.7 as
+    the build's contract: per optimizer, only its parameters require
+    grad; backward; clip_grad_norm_ over every parameter that holds a gradient; G steps every
+    batch, D steps and zeroes only when batch_idx % 4 == 0 (main_optimize.py:78-88).
+    lr is raised to 1e-3 for optimize/pretrain so that 20 steps visibly move the losses."""
+    out = {}
+    V, B, L = c["V"], c["B"], c["L"]
+    ce, mse, bce = nn.CrossEntropyLoss(), nn.MSELoss(), nn.BCEWithLogitsLoss()
+    hp = dict(w_s=0.1, w_c=0.5, w_adv=1.0, w_bt=1.0, tau=0.1, gap=0.0)
+
+    def batch_of(it):
+        x = det_tokens(B, L, V, 100 + it)
+        labels = torch.tensor([(i + it) % 2 for i in range(B)], dtype=torch.long)
+        return x, labels
+
+    def clip(mods, val):
+        ps = [p for m in mods for p in m.parameters() if p.grad is not None]
+        torch.nn.utils.clip_grad_norm_(ps, val)
+
+    def req(mods_on, mods_all):
+        for m in mods_all:
+            for p in m.parameters():
+                p.requires_grad_(False)
+        for m in mods_on:
+            for p in m.parameters():
+                p.requires_grad_(True)
+
+    # ---- optimize ------------------------------------------------------------------------
+    G, C, Mt, Dn, D = build(c)
+    allm = (G, C, Mt, Dn, D)
+    og = torch.optim.Adam(G.parameters(), lr=1e-3)
+    od = torch.optim.Adam(D.parameters(), lr=1e-3)
+    rows = []
+    for it in range(steps):
+        x, labels = batch_of(it)
+        req((G,), allm)
+        sample_p = G(x, labels, None, 1 - labels, res_type="softmax", tau=hp["tau"])
+        s_logits, c_logits = C(sample_p), Mt(sample_p, x)
+        D.eval()
+        adv = D(sample_p)
+        random.seed(1000 + it)
+        bk = G(sample_p.argmax(-1), 1 - labels, x, labels)
+        s_loss = ce(s_logits, 1 - labels)
+        c_loss = mse(c_logits, c_logits.new_full([c_logits.size(0)], hp["gap"]))
+        g_loss = bce(adv, adv.new_full(adv.shape, 1))
+        bk_loss = ce(bk.reshape(-1, bk.size(-1)), x.reshape(-1))
+        loss = hp["w_bt"] * bk_loss + hp["w_c"] * c_loss + hp["w_adv"] * g_loss + hp["w_s"] * s_loss
+        loss.backward()
+        clip(allm, 1.0)
+        og.step()
+        og.zero_grad()
+        req((D,), allm)
+        D.train()
+        t_logits = D(F.one_hot(x, V).float())
+        with torch.no_grad():
+            x_ = G(x, labels, None, 1 - labels, res_type="softmax", tau=hp["tau"])
+        f_logits = D(x_)
+        d_loss = 0.5 * (bce(t_logits, t_logits.new_full(t_logits.shape, 1)) + bce(f_logits, f_logits.new_full(f_logits.shape, 0)))
+        (hp["w_adv"] * d_loss).backward()
+        clip(allm, 1.0)
+        if it % 4 == 0:
+            od.step()
+            od.zero_grad()
+        rows.append([loss.item(), g_loss.item(), s_loss.item(), c_logits.mean().item(), bk_loss.item(), d_loss.item()])
+    out["optimize.curve"] = np.array(rows)
+    out["optimize.coin_seeds"] = np.array([1000 + it for it in range(steps)])
+    out["optimize.coins"] = np.array([coins_for(1000 + it, L) for it in range(steps)], dtype=np.int64)
+    out["optimize.final.fn_1.bias"] = np32(G.fn_1.bias)
+    out["optimize.final.out2logits.weight"] = np32(D.out2logits.weight)
+
+    # ---- warmup --------------------------------------------------------------------------
+    G, C, Mt, Dn, D = build(c)
+    for p in G.parameters():
+        p.requires_grad_(True)
+    ow = torch.optim.Adam(G.parameters(), lr=1e-3)
+    rows = []
+    for it in range(steps):
+        x, labels = batch_of(it)
+        nx = det_tokens(B, L - 1, V, 300 + it)
+        random.seed(2000 + it)
+        lg = G(nx, labels, x, labels)
+        loss = ce(lg.reshape(-1, lg.size(-1)), x.reshape(-1))
+        loss.backward()
+        clip((G,), 1.0)
+        ow.step()
+        ow.zero_grad()
+        rows.append(loss.item())
+    out["warmup.curve"] = np.array(rows)
+    out["warmup.coins"] = np.array([coins_for(2000 + it, L) for it in range(steps)], dtype=np.int64)
+
+    # ---- pretrain ------------------------------------------------------------------------
+    G, C, Mt, Dn, D = build(c)
+    ps = list(C.parameters()) + list(Mt.parameters()) + list(Dn.parameters())
+    for p in ps:
+        p.requires_grad_(True)
+    op = torch.optim.Adam(ps, lr=1e-3)
+    rows = []
+    for it in range(steps):
+        x, labels = batch_of(it)
+        nx1, nx2, nx3 = det_tokens(B, L, V, 400 + it), det_tokens(B, L - 1, V, 500 + it), det_tokens(B, L, V, 600 + it)
+        c_label = torch.from_numpy(np.random.RandomState(700 + it).uniform(0, 1.5, size=(B,)).astype(np.float32))
+        s_loss = ce(C(x), labels)
+        c_loss = mse(Mt(nx1, nx2), c_label)
+        dl = Dn(nx3)
+        dn_loss = ce(dl.reshape(-1, dl.size(-1)), x.reshape(-1))
+        (s_loss + c_loss + dn_loss).backward()
+        clip((C, Mt, Dn), 5.0)
+        op.step()
+        op.zero_grad()
+        rows.append([s_loss.item(), c_loss.item(), dn_loss.item()])
+    out["pretrain.curve"] = np.array(rows)
+    return out
+
+
 def main():
     for name, c in CONFIGS.items():
         mg = module_goldens(name, c)
@@ -302,6 +418,8 @@ def main():
                       f, indent=0, sort_keys=True)
         sg = step_goldens(name, c)
         np.savez_compressed(os.path.join(HERE, f"steps_{name}.npz"), **sg)
+        cg = curve_goldens(name, c, 20 if name == "tiny" else 6)
+        np.savez_compressed(os.path.join(HERE, f"curves_{name}.npz"), **cg)
         print(name, "modules:", len(mg), "arrays;", "steps:", len(sg), "arrays")
 
 

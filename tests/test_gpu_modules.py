@@ -170,7 +170,7 @@ def test_generator(cst, name, prec):
             run_grads(G, tag, m, lossw(tag, y), prec)
         else:
             assert y.shape == G[tag + ".out"].shape and torch.isfinite(y).all()
-            np.testing.assert_allclose(y.sum(-1).cpu().numpy(), 1.0, rtol=1e-4)
+            np.testing.assert_allclose(y.detach().sum(-1).cpu().numpy(), 1.0, rtol=1e-4)
     # (c) greedy decode: exact ids in f32 mode
     with torch.no_grad():
         y = m(x, labels, None, 1 - labels)

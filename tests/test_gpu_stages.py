@@ -1,0 +1,154 @@
+"""GPU: the three stage step functions and the build's own optimiser loop against the golden
+single-step losses and multi-step loss curves recorded from the reference modules.
+
+Tolerance: north_star asks for the main_optimize loss curve within 1e-3 of the reference; in the
+exact-fp32 MFMA mode every logged scalar of all 20 steps is held to atol 1e-3 (rtol 2e-3); in the
+bf16 MFMA mode to atol 3e-2."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from curve_inputs import HP, opt_batch, pre_batch, warm_batch  # noqa: E402
+from helpers import CONFIGS, SEEDS, load_golden  # noqa: E402
+from oracle.detinit import det_state_dict  # noqa: E402
+from test_gpu_modules import set_constants  # noqa: E402
+
+
+def _load(mod, which):
+    mod.load_state_dict(det_state_dict({k: v.shape for k, v in mod.state_dict().items()}, SEEDS[which]))
+
+
+def cu(batch):
+    return tuple(t.cuda() for t in batch)
+
+
+def make_opt(name, lr=1e-3):
+    from consistent__style_transfer_amd import model, stages
+    c = CONFIGS[name]
+    set_constants(model, c)
+    st = stages.OptimizeStage(c["V"], 2, c["max_len"], lr=lr, **HP)
+    for attr, which in (("generator", "G"), ("classifier", "cls"), ("matcher", "mat"), ("nt_checker", "dn"), ("disc", "disc")):
+        _load(getattr(st, attr), which)
+    st = st.cuda()
+    st.eval()                              # deterministic mode: dropout off everywhere
+    st.setup_optim()
+    return st
+
+
+@pytest.mark.parametrize("name", ["tiny", "ref"])
+def test_single_step_losses(name):
+    from consistent__style_transfer_amd import model, ops, stages
+    ops.set_precision("f32")
+    c, G = CONFIGS[name], load_golden("steps", name)
+    x, nx1, nx2, nx3 = (torch.from_numpy(G[k]).cuda() for k in ("x", "nx1", "nx2", "nx3"))
+    labels, c_label = torch.from_numpy(G["labels"]).cuda(), torch.from_numpy(G["c_label"]).cuda()
+    set_constants(model, c)
+    # pretrain
+    pre = stages.PretrainStage(c["V"], 2)
+    for attr, which in (("classifier", "cls"), ("matcher", "mat"), ("denoiser", "dn")):
+        _load(getattr(pre, attr), which)
+    pre = pre.cuda().eval()
+    s, cl, dn = pre.losses((x, nx1, nx2, nx3, labels, c_label))
+    np.testing.assert_allclose([s.item(), cl.item(), dn.item()], G["pretrain.losses"], rtol=1e-3)
+    (s + cl + dn).backward()
+    gn = [float(torch.sqrt(sum((p.grad.double() ** 2).sum() for p in m.parameters()))) for m in (pre.classifier, pre.matcher, pre.denoiser)]
+    np.testing.assert_allclose(gn, G["pretrain.gnorm"], rtol=5e-3)
+    # warmup
+    wu = stages.WarmupStage(c["V"], 2, c["max_len"])
+    _load(wu.generator, "G")
+    wu = wu.cuda().eval()
+    w = wu.loss((nx2, x, labels), coins=G["warmup.coins"])
+    np.testing.assert_allclose(w.item(), G["warmup.loss"][0], rtol=1e-3)
+    w.backward()
+    gn = float(torch.sqrt(sum((p.grad.double() ** 2).sum() for p in wu.generator.parameters())))
+    np.testing.assert_allclose(gn, G["warmup.gnorm"][0], rtol=5e-3)
+    # optimize: generator and discriminator steps, validation, greedy ids
+    st = make_opt(name, lr=1e-5)
+    r = st.g_losses((x, labels), coins=G["optimize.coins"])
+    got = [r["loss"].item(), r["G"].item(), r["STI"].item(), r["CP_logits"].mean().item(), r["BK"].item()]
+    np.testing.assert_allclose(got, G["optimize.g.losses"], rtol=2e-3, atol=1e-4)
+    assert np.array_equal(r["sample_ids"].cpu().numpy(), G["optimize.g.sample_ids"])
+    for p in st.parameters():
+        p.requires_grad_(False)
+    for p in st.generator.parameters():
+        p.requires_grad_(True)
+    r = st.g_losses((x, labels), coins=G["optimize.coins"])
+    r["loss"].backward()
+    gn = float(torch.sqrt(sum((p.grad.double() ** 2).sum() for p in st.generator.parameters())))
+    np.testing.assert_allclose(gn, G["optimize.g.gnorm"][0], rtol=1e-2)
+    np.testing.assert_allclose(st.generator.fn_1.bias.grad.cpu().numpy(), G["optimize.g.grad.fn_1.bias"], rtol=2e-2, atol=1e-4)
+    for p in st.parameters():
+        p.requires_grad_(False)
+        p.grad = None
+    for p in st.disc.parameters():
+        p.requires_grad_(True)
+    d = st.d_losses((x, labels))
+    np.testing.assert_allclose(d["D"].item(), G["optimize.d.losses"][0], rtol=1e-3)
+    d["loss"].backward()
+    gn = float(torch.sqrt(sum((p.grad.double() ** 2).sum() for p in st.disc.parameters())))
+    np.testing.assert_allclose(gn, G["optimize.d.gnorm"][0], rtol=5e-3)
+    v = st.val_loss((x, labels))
+    np.testing.assert_allclose(v.item(), G["optimize.val"][0], rtol=2e-3)
+    ops.set_precision("bf16")
+
+
+@pytest.mark.parametrize("prec,atol", [("f32", 1e-3), ("bf16", 3e-2)])
+def test_optimize_loss_curve(prec, atol):
+    from consistent__style_transfer_amd import ops
+    ops.set_precision(prec)
+    name = "tiny"
+    c, G = CONFIGS[name], load_golden("curves", name)
+    st = make_opt(name, lr=1e-3)
+    rows = []
+    for it in range(G["optimize.curve"].shape[0]):
+        lg = st.train_step(cu(opt_batch(c, it)), it, coins=G["optimize.coins"][it])
+        rows.append([lg["g_total"].item(), lg["G"].item(), lg["STI"].item(), lg["CP_logits"].mean().item(),
+                     lg["BK"].item(), lg["D"].item()])
+    np.testing.assert_allclose(np.array(rows), G["optimize.curve"], rtol=2e-3 if prec == "f32" else 3e-2, atol=atol)
+    if prec == "f32":
+        np.testing.assert_allclose(st.generator.fn_1.bias.detach().cpu().numpy(), G["optimize.final.fn_1.bias"], rtol=2e-3, atol=1e-4)
+        np.testing.assert_allclose(st.disc.out2logits.weight.detach().cpu().numpy(), G["optimize.final.out2logits.weight"],
+                                   rtol=2e-3, atol=1e-4)
+    ops.set_precision("bf16")
+
+
+def test_optimize_loss_curve_ref_config():
+    from consistent__style_transfer_amd import ops
+    ops.set_precision("f32")
+    name = "ref"
+    c, G = CONFIGS[name], load_golden("curves", name)
+    st = make_opt(name, lr=1e-3)
+    rows = []
+    for it in range(G["optimize.curve"].shape[0]):
+        lg = st.train_step(cu(opt_batch(c, it)), it, coins=G["optimize.coins"][it])
+        rows.append([lg["g_total"].item(), lg["G"].item(), lg["STI"].item(), lg["CP_logits"].mean().item(),
+                     lg["BK"].item(), lg["D"].item()])
+    np.testing.assert_allclose(np.array(rows), G["optimize.curve"], rtol=2e-3, atol=1e-3)
+    ops.set_precision("bf16")
+
+
+def test_warmup_and_pretrain_curves():
+    from consistent__style_transfer_amd import model, ops, stages
+    ops.set_precision("f32")
+    name = "tiny"
+    c, G = CONFIGS[name], load_golden("curves", name)
+    set_constants(model, c)
+    wu = stages.WarmupStage(c["V"], 2, c["max_len"], lr=1e-3)
+    _load(wu.generator, "G")
+    wu = wu.cuda().eval()
+    wu.setup_optim()
+    rows = [wu.train_step(cu(warm_batch(c, it)), coins=G["warmup.coins"][it])["loss"].item() for it in range(G["warmup.curve"].shape[0])]
+    np.testing.assert_allclose(rows, G["warmup.curve"], rtol=1e-3, atol=1e-3)
+    pre = stages.PretrainStage(c["V"], 2, lr=1e-3)
+    for attr, which in (("classifier", "cls"), ("matcher", "mat"), ("denoiser", "dn")):
+        _load(getattr(pre, attr), which)
+    pre = pre.cuda().eval()
+    pre.setup_optim()
+    rows = []
+    for it in range(G["pretrain.curve"].shape[0]):
+        r = pre.train_step(cu(pre_batch(c, it)))
+        rows.append([r["s_loss"].item(), r["c_loss"].item(), r["dn_loss"].item()])
+    np.testing.assert_allclose(np.array(rows), G["pretrain.curve"], rtol=2e-3, atol=1e-3)
+    ops.set_precision("bf16")
