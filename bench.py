@@ -1,0 +1,223 @@
+#!/usr/bin/env python3
+"""Throughput benchmark of the three-stage training path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run)
+
+One "step" = one pretrain step (TextCNN + Matcher + MLM) + one warmup step (DenoiseLSTM
+auto-encoding) + one optimize step (generator step + discriminator step) on one synthetic
+Yelp-shaped batch per stage (B sentences per GPU, seq <= 18, |V| = 10 000): the whole
+`main_pretrain -> main_warmup -> main_optimize` hot path including backward, gradient clipping and
+Adam.  `value` = sentences carried through all three stages per second, whole job (B*N / step time).
+Rank 0 prints ONE JSON line (see README/DESIGN for the field contract).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+import torch  # noqa: E402
+
+WORKLOADS = {
+    # BASELINE.json configs[1]: Yelp, 4-layer d=512 critics, batch 256, pretrain -> warmup -> optimize
+    "yelp_4l_d512_b256": dict(n_layer=4, d_model=512, n_head=8, B=256, L=18, V=10000),
+    # the reference's own constants (6-layer d=512)
+    "yelp_6l_d512_b256": dict(n_layer=6, d_model=512, n_head=8, B=256, L=18, V=10000),
+    # BASELINE.json configs[3] per-GPU shard: 6-layer d=768, 256 sentences per GPU
+    "yelp_6l_d768_b256": dict(n_layer=6, d_model=768, n_head=8, B=256, L=18, V=10000),
+    # BASELINE.json configs[0]-shaped small case
+    "yelp_2l_d256_b32": dict(n_layer=2, d_model=256, n_head=8, B=32, L=16, V=10000),
+}
+HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+MFMA_PEAK_TFLOPS = 2500.0        # dense bf16 MFMA peak (not the 2:1 sparse figure)
+
+
+def build_stages(w, device, lr_scale=1.0):
+    from consistent__style_transfer_amd import stages
+    from consistent__style_transfer_amd.model import match, mlm
+    mlm.d_model = match.d_model = w["d_model"]
+    mlm.n_head = match.n_head = w["n_head"]
+    mlm.n_layer = match.n_layer = w["n_layer"]
+    torch.manual_seed(1234)                      # identical random-init weights on every rank
+    pre = stages.PretrainStage(w["V"], 2).to(device)
+    wu = stages.WarmupStage(w["V"], 2, w["L"]).to(device)
+    opt = stages.OptimizeStage(w["V"], 2, w["L"]).to(device)
+    for s in (pre, wu, opt):
+        s.train()
+        s.setup_optim()
+    return pre, wu, opt
+
+
+def make_batches(w, rank, device, n=4):
+    from consistent__style_transfer_amd import synthetic as syn
+    B, L, V = w["B"], w["L"], w["V"]
+    out = []
+    for i in range(n):
+        seed = 1000 * (rank + 1) + i                   # rank offset for data only, never for coins
+        out.append((tuple(t.to(device) for t in syn.pretrain_batch(B, L, V, seed)),
+                    tuple(t.to(device) for t in syn.warmup_batch(B, L, V, seed)),
+                    tuple(t.to(device) for t in syn.optimize_batch(B, L, V, seed))))
+    return out
+
+
+def coins_for(step, L):
+    import random
+    r = random.Random(777 + step)                      # same sequence on every rank
+    return [r.random() < 0.5 for _ in range(L)]
+
+
+def run_step(stages_, batches, it, reducer):
+    pre, wu, opt = stages_
+    bp, bw, bo = batches[it % len(batches)]
+    L = bw[1].shape[1]
+    pre.train_step(bp, seed=3 * it, reducer=reducer)
+    wu.train_step(bw, coins=coins_for(2 * it, L), seed=3 * it + 1, reducer=reducer)
+    opt.train_step(bo, it, coins=coins_for(2 * it + 1, L), seed=3 * it + 2, reducer=reducer)
+
+
+def cpu_baseline(w, budget_s=25.0):
+    """The oracle's training loops (plain torch fp32) on the host cores, bounded sample of the same
+    workload: one pretrain + warmup + optimize step at a reduced batch."""
+    from consistent__style_transfer_amd import synthetic as syn
+    from oracle import train as OT
+    import json as _json
+    nthreads = torch.get_num_threads()
+    Bc = 8
+    L, V, d, nl, nh = w["L"], w["V"], w["d_model"], w["n_layer"], w["n_head"]
+    torch.manual_seed(0)
+
+    def P(shapes):
+        return {k: (torch.randn(*s) * 0.05) for k, s in shapes.items()}
+
+    # parameter shapes from the product modules (CPU construction, no kernels involved)
+    from consistent__style_transfer_amd import model
+    from consistent__style_transfer_amd.model import match, mlm
+    mlm.d_model = match.d_model = d
+    mlm.n_layer = match.n_layer = nl
+    shp = lambda m: {k: tuple(v.shape) for k, v in m.state_dict().items()}
+    Pg, Pc, Pm, Pd, Pdisc = (P(shp(model.DenoiseLSTM(V, 2, L))), P(shp(model.TextCNN(V, 2))), P(shp(model.Matcher(V))),
+                             P(shp(model.MLM(V, 2))), P(shp(model.RelGAN_D(V))))
+    for q in (Pm, Pd):
+        for k in q:
+            if k.endswith("norm1.weight") or k.endswith("norm2.weight"):
+                q[k] = torch.ones_like(q[k])
+    hp = dict(w_s=0.1, w_c=0.5, w_adv=1.0, w_bt=1.0, tau=0.1, gap=0.0)
+    tp = OT.OraclePretrain(Pc, Pm, Pd, nh)
+    tw = OT.OracleWarmup({k: v.clone() for k, v in Pg.items()})
+    to = OT.OracleOptimize(Pg, {k: v.clone() for k, v in Pc.items()}, {k: v.clone() for k, v in Pm.items()},
+                           {k: v.clone() for k, v in Pd.items()}, Pdisc, hp, nh, L)
+    bp, bw, bo = syn.pretrain_batch(Bc, L, V, 1), syn.warmup_batch(Bc, L, V, 1), syn.optimize_batch(Bc, L, V, 1)
+    coins = coins_for(0, L)
+
+    def one(it):
+        tp.step(bp)
+        tw.step(bw, coins)
+        to.step(bo, it, coins)
+
+    one(0)                                               # warm-up
+    t0 = time.time()
+    n = 0
+    while True:
+        one(n + 1)
+        n += 1
+        if time.time() - t0 > budget_s or n >= 20:
+            break
+    dt = (time.time() - t0) / n
+    return {"value": Bc / dt, "unit": "sentences/s", "cores": nthreads, "kind": "port",
+            "sample": f"oracle (plain torch fp32) pretrain+warmup+optimize steps at batch {Bc}, {n} timed steps, "
+                      f"{w['n_layer']}-layer d={w['d_model']} L={L} V={V}"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="yelp_4l_d512_b256", choices=sorted(WORKLOADS))
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--breakdown", action="store_true", help="print the per-entry-point time table to stderr")
+    args = ap.parse_args()
+
+    from consistent__style_transfer_amd import _lib, ops
+    from consistent__style_transfer_amd.parallel import GradReducer, init_distributed, max_over_ranks
+    rank, local, world = init_distributed()
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world} (launch N>1 with torch.distributed.run)"
+    assert torch.cuda.is_available(), "bench.py needs a GPU: the product path has no CPU fallback"
+    device = torch.device("cuda", local)
+    torch.cuda.set_device(device)
+    ops.set_precision(args.precision)
+    w = WORKLOADS[args.workload]
+    stages_ = build_stages(w, device)
+    batches = make_batches(w, rank, device)
+    reducer = GradReducer(world) if world > 1 else None
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for it in range(args.warmup):
+        run_step(stages_, batches, it, reducer)
+    barrier()
+    t0 = time.perf_counter()
+    for it in range(args.steps):
+        run_step(stages_, batches, args.warmup + it, reducer)
+    barrier()
+    dt = max_over_ranks(time.perf_counter() - t0, device)
+    ms_per_step = 1000.0 * dt / args.steps
+    value = w["B"] * world * args.steps / dt
+
+    roofline = None
+    table = None
+    if rank == 0 and not args.no_roofline:
+        timer = _lib.KernelTimer()
+        _lib.set_timer(timer)
+        nprof = min(3, args.steps)
+        for it in range(nprof):
+            run_step(stages_, batches, args.warmup + args.steps + it, None if world > 1 else reducer)
+        _lib.set_timer(None)
+        table = timer.summary()
+        g = table.get("cst_gemm")
+        if g and g["ms"] > 0:
+            ach = g["work"] / (g["ms"] * 1e-3) / 1e12
+            roofline = {"bound": "mfma", "kernel": "cst_gemm_kernel (all layouts; bf16 16x16x32 MFMA)",
+                        "achieved": ach, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / MFMA_PEAK_TFLOPS,
+                        "traffic": None, "launches_per_step": g["calls"] / nprof,
+                        "avg_launch_us": 1000.0 * g["ms"] / g["calls"],
+                        "flops_per_launch": g["work"] / g["calls"],
+                        "share_of_kernel_time": g["ms"] / sum(v["ms"] for v in table.values())}
+        if args.breakdown:
+            tot = sum(v["ms"] for v in table.values())
+            for k, v in sorted(table.items(), key=lambda kv: -kv[1]["ms"]):
+                print(f"{k:28s} calls/step {v['calls'] / nprof:8.1f}  ms/step {v['ms'] / nprof:9.3f}  {100 * v['ms'] / tot:5.1f}%",
+                      file=sys.stderr)
+    if world > 1:
+        torch.distributed.barrier()
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(w)
+
+    if rank == 0:
+        line = {
+            "metric": "train sentences/sec on Yelp-shaped batches (pretrain+warmup+optimize steps per batch)",
+            "value": value, "unit": "sentences/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": args.precision if args.precision == "bf16" else "f32", "data": "synthetic",
+            "config": {"workload": args.workload, "per_gpu_batch": w["B"], "global_batch": w["B"] * world,
+                       "seq_len": w["L"], "vocab": w["V"], "critic_layers": w["n_layer"], "d_model": w["d_model"],
+                       "parallelism": f"dp{world}", "stages": "pretrain+warmup+optimize(G+D)", "weights": "random-init"},
+            "roofline": roofline, "cpu_baseline": cpu,
+        }
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -86,10 +86,50 @@ def stream_ptr():
     return torch.cuda.current_stream().cuda_stream
 
 
+class KernelTimer:
+    """Optional per-entry-point timing with HIP events recorded on the launch stream (used by
+    bench.py's roofline leg; never active in the timed throughput region)."""
+
+    def __init__(self):
+        self.records = []           # (name, start_event, end_event, work) ; work = flops for cst_gemm
+
+    def summary(self):
+        torch.cuda.synchronize()
+        out = {}
+        for name, a, b, work in self.records:
+            d = out.setdefault(name, {"calls": 0, "ms": 0.0, "work": 0.0})
+            d["calls"] += 1
+            d["ms"] += a.elapsed_time(b)
+            d["work"] += work
+        return out
+
+
+TIMER = None
+
+
+def set_timer(t):
+    global TIMER
+    TIMER = t
+
+
+def _gemm_key(args):
+    # (A, lda, akm, B, ldb, bkm, C, ldc, M, N, K, ...) -> flops and a layout tag
+    M, N, K = args[8], args[9], args[10]
+    batch = args[21]
+    return 2.0 * M * N * K * batch
+
+
 def call(name, *args):
     """Invoke an int-status entry point on torch's current stream; raise on a non-zero status."""
     L = lib()
-    rc = L.fn[name](*[_ptr(a) for a in args], stream_ptr())
+    if TIMER is not None:
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        rc = L.fn[name](*[_ptr(x) for x in args], stream_ptr())
+        b.record()
+        TIMER.records.append((name, a, b, _gemm_key(args) if name == "cst_gemm" else 0.0))
+    else:
+        rc = L.fn[name](*[_ptr(a) for a in args], stream_ptr())
     if rc != 0:
         raise RuntimeError(f"{name} failed (status {rc}): {L.last_error()}")
 

@@ -1,0 +1,80 @@
+"""Data parallelism: one process per GPU, sentence minibatches sharded by rows, gradient
+all-reduce (average) over RCCL/xGMI on the flat gradient buffers of optim.FlatGroup.
+
+The reference has no distributed code; this is new.  Contract:
+  * the GLOBAL batch is built on the host exactly as collate_* does (noise functions mix tokens
+    across the whole batch), padded to the global maximum length, then rows are split evenly
+    (shard_batch); scheduled-sampling coins are identical on every rank, dropout streams differ;
+  * each FlatGroup's gradient buffer is all-reduced in buckets; the global grad-norm clip and Adam
+    then run on identical, already averaged gradients on every rank.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def init_distributed(backend=None):
+    """Initialise from the torchrun environment (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, local, world
+
+
+def shard_batch(batch, rank, world):
+    """Rows [rank*B/world, (rank+1)*B/world) of every tensor of a globally collated batch."""
+    if world == 1:
+        return batch
+    out = []
+    for t in batch:
+        B = t.shape[0]
+        assert B % world == 0, f"global batch {B} is not divisible by world size {world}"
+        n = B // world
+        out.append(t[rank * n:(rank + 1) * n].contiguous())
+    return tuple(out)
+
+
+class GradReducer:
+    """all-reduce(average) of FlatGroup gradients, bucketed so that several collectives are in
+    flight (RCCL runs them on its own stream; they overlap with the gather / sum-of-squares
+    kernels of later groups)."""
+
+    def __init__(self, world, bucket_elems=16 * 1024 * 1024):
+        self.world = world
+        self.bucket = bucket_elems
+        self.avg = dist.is_initialized() and dist.get_backend() == "nccl"
+
+    def __call__(self, groups):
+        if self.world == 1:
+            return
+        works = []
+        for g in groups:
+            flat = g.flat_g
+            for s in range(0, flat.numel(), self.bucket):
+                chunk = flat[s:s + self.bucket]
+                if self.avg:
+                    works.append(dist.all_reduce(chunk, op=dist.ReduceOp.AVG, async_op=True))
+                else:
+                    works.append(dist.all_reduce(chunk, op=dist.ReduceOp.SUM, async_op=True))
+        for w in works:
+            w.wait()
+        if not self.avg:
+            for g in groups:
+                g.flat_g.div_(self.world)          # gloo (CPU tests) has no AVG; RCCL path never comes here
+
+
+def max_over_ranks(value, device):
+    if not dist.is_initialized():
+        return value
+    t = torch.tensor([value], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
