@@ -106,9 +106,9 @@ def cpu_baseline(w, budget_s=25.0):
                 q[k] = torch.ones_like(q[k])
     hp = dict(w_s=0.1, w_c=0.5, w_adv=1.0, w_bt=1.0, tau=0.1, gap=0.0)
     tp = OT.OraclePretrain(Pc, Pm, Pd, nh)
-    tw = OT.OracleWarmup({k: v.clone() for k, v in Pg.items()})
-    to = OT.OracleOptimize(Pg, {k: v.clone() for k, v in Pc.items()}, {k: v.clone() for k, v in Pm.items()},
-                           {k: v.clone() for k, v in Pd.items()}, Pdisc, hp, nh, L)
+    tw = OT.OracleWarmup({k: v.detach().clone() for k, v in Pg.items()})
+    dc = lambda q: {k: v.detach().clone() for k, v in q.items()}
+    to = OT.OracleOptimize(Pg, dc(Pc), dc(Pm), dc(Pd), Pdisc, hp, nh, L)
     bp, bw, bo = syn.pretrain_batch(Bc, L, V, 1), syn.warmup_batch(Bc, L, V, 1), syn.optimize_batch(Bc, L, V, 1)
     coins = coins_for(0, L)
 
@@ -175,14 +175,18 @@ def main():
     roofline = None
     table = None
     if rank == 0 and not args.no_roofline:
-        timer = _lib.KernelTimer()
+        timer = _lib.KernelTimer(by_shape=args.breakdown)
         _lib.set_timer(timer)
         nprof = min(3, args.steps)
         for it in range(nprof):
             run_step(stages_, batches, args.warmup + args.steps + it, None if world > 1 else reducer)
         _lib.set_timer(None)
         table = timer.summary()
-        g = table.get("cst_gemm")
+        g = {"calls": 0, "ms": 0.0, "work": 0.0}
+        for k, v in table.items():
+            if k.startswith("cst_gemm"):
+                for f in g:
+                    g[f] += v[f]
         if g and g["ms"] > 0:
             ach = g["work"] / (g["ms"] * 1e-3) / 1e12
             roofline = {"bound": "mfma", "kernel": "cst_gemm_kernel (all layouts; bf16 16x16x32 MFMA)",
@@ -194,7 +198,8 @@ def main():
         if args.breakdown:
             tot = sum(v["ms"] for v in table.values())
             for k, v in sorted(table.items(), key=lambda kv: -kv[1]["ms"]):
-                print(f"{k:28s} calls/step {v['calls'] / nprof:8.1f}  ms/step {v['ms'] / nprof:9.3f}  {100 * v['ms'] / tot:5.1f}%",
+                tf = f"  {v['work'] / (v['ms'] * 1e-3) / 1e12:7.1f} TF/s" if v["work"] else ""
+                print(f"{k:44s} calls/step {v['calls'] / nprof:7.1f}  ms/step {v['ms'] / nprof:9.3f}  {100 * v['ms'] / tot:5.1f}%{tf}",
                       file=sys.stderr)
     if world > 1:
         torch.distributed.barrier()

@@ -90,7 +90,8 @@ class KernelTimer:
     """Optional per-entry-point timing with HIP events recorded on the launch stream (used by
     bench.py's roofline leg; never active in the timed throughput region)."""
 
-    def __init__(self):
+    def __init__(self, by_shape=False):
+        self.by_shape = by_shape
         self.records = []           # (name, start_event, end_event, work) ; work = flops for cst_gemm
 
     def summary(self):
@@ -127,7 +128,10 @@ def call(name, *args):
         a.record()
         rc = L.fn[name](*[_ptr(x) for x in args], stream_ptr())
         b.record()
-        TIMER.records.append((name, a, b, _gemm_key(args) if name == "cst_gemm" else 0.0))
+        key = name
+        if name == "cst_gemm" and TIMER.by_shape:
+            key = f"cst_gemm[{args[8]}x{args[9]}x{args[10]} a{args[2]}b{args[5]}]"
+        TIMER.records.append((key, a, b, _gemm_key(args) if name == "cst_gemm" else 0.0))
     else:
         rc = L.fn[name](*[_ptr(a) for a in args], stream_ptr())
     if rc != 0:

@@ -36,7 +36,25 @@ struct GemmArgs {
     int vecA, vecB;         // 16-byte vector loads legal for this operand
     float alpha, gate_scale;
     CstDrop drop;           // epilogue dropout over the logical [M,N] index space
+    int splits;             // split-K: blockIdx.y owns k in [y*k_per_split, (y+1)*k_per_split)
+    int k_per_split;        // multiple of BK
+    float* slab;            // [batch][splits][M][N] raw partial sums when splits > 1
 };
+
+// epilogue shared by the in-kernel path and the split-K reduction
+__device__ __forceinline__ void gemm_epilogue_store(const GemmArgs& g, float* C, const float* bias, const float* addend,
+                                                    const float* aux, uint32_t dseed, long bz, int m, int n, float acc) {
+    float v = g.alpha * acc + (bias ? bias[n] : 0.f);
+    if (addend) v += addend[(long)m * g.ldadd + n];
+    if (g.act == 1) v = v > 0.f ? v : 0.f;
+    else if (g.act == 2) v = v > 0.f ? v : 0.1f * v;
+    else if (g.act == 3) v = aux[(long)m * g.ldaux + n] > 0.f ? v * g.gate_scale : 0.f;
+    else if (g.act == 4) v = aux[(long)m * g.ldaux + n] > 0.f ? v : 0.1f * v;
+    if (g.drop.p > 0.f) v *= cst_drop_mask(g.drop, dseed, (uint32_t)((long)m * g.N + n + bz * (long)g.M * g.N));
+    float* cp = C + (long)m * g.ldc + n;
+    if (g.accumulate) v += *cp;
+    *cp = v;
+}
 
 __device__ __forceinline__ unsigned short f2bf(float f) {
     // round-to-nearest-even; NaN stays NaN via the hardware convert
@@ -183,17 +201,19 @@ __global__ __launch_bounds__(256) void cst_gemm_kernel(GemmArgs g) {
 
     typename StageSel<BM, A_KMAJ>::type sa;
     typename StageSel<BN, B_KMAJ>::type sb;
-    sa.load(A, g.lda, m0, 0, g.M, g.K, g.vecA);
-    sb.load(B, g.ldb, n0, 0, g.N, g.K, g.vecB);
+    const int kbeg = blockIdx.y * g.k_per_split;
+    const int kend = min(g.K, kbeg + g.k_per_split);
+    sa.load(A, g.lda, m0, kbeg, g.M, kend, g.vecA);
+    sb.load(B, g.ldb, n0, kbeg, g.N, kend, g.vecB);
 
-    const int nk = (g.K + BK - 1) / BK;
+    const int nk = (kend - kbeg + BK - 1) / BK;
     for (int kt = 0; kt < nk; ++kt) {
         sa.template store<F32, LDS_LD>(As);
         sb.template store<F32, LDS_LD>(Bs);
         __syncthreads();
         if (kt + 1 < nk) {
-            sa.load(A, g.lda, m0, (kt + 1) * BK, g.M, g.K, g.vecA);
-            sb.load(B, g.ldb, n0, (kt + 1) * BK, g.N, g.K, g.vecB);
+            sa.load(A, g.lda, m0, kbeg + (kt + 1) * BK, g.M, kend, g.vecA);
+            sb.load(B, g.ldb, n0, kbeg + (kt + 1) * BK, g.N, kend, g.vecB);
         }
         if constexpr (!F32) {
             bf16x8_t af[TM], bfr[TN];
@@ -235,6 +255,22 @@ __global__ __launch_bounds__(256) void cst_gemm_kernel(GemmArgs g) {
     }
 
     // ---- epilogue: C/D layout of the 16x16 MFMA: col = lane&15, row = 4*(lane>>4) + reg ----
+    if (g.splits > 1) {
+        float* slab = g.slab + ((bz * g.splits + blockIdx.y) * (long)g.M) * g.N;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int n = n0 + wn * (BN / 2) + j * 16 + lr;
+                if (n >= g.N) continue;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int m = m0 + wm * (BM / 2) + i * 16 + lq * 4 + r;
+                    if (m < g.M) slab[(long)m * g.N + n] = acc[i][j][r];
+                }
+            }
+        return;
+    }
     float* C = g.C + bz * g.sC;
     const float* bias = g.bias ? g.bias + bz * g.sBias : nullptr;
     const float* addend = g.addend ? g.addend + bz * g.sAdd : nullptr;
@@ -246,29 +282,36 @@ __global__ __launch_bounds__(256) void cst_gemm_kernel(GemmArgs g) {
         for (int j = 0; j < TN; ++j) {
             const int n = n0 + wn * (BN / 2) + j * 16 + lr;
             if (n >= g.N) continue;
-            const float bv = bias ? bias[n] : 0.f;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int m = m0 + wm * (BM / 2) + i * 16 + lq * 4 + r;
                 if (m >= g.M) continue;
-                float v = g.alpha * acc[i][j][r] + bv;
-                if (addend) v += addend[(long)m * g.ldadd + n];
-                if (g.act == 1) v = v > 0.f ? v : 0.f;
-                else if (g.act == 2) v = v > 0.f ? v : 0.1f * v;
-                else if (g.act == 3) v = aux[(long)m * g.ldaux + n] > 0.f ? v * g.gate_scale : 0.f;
-                else if (g.act == 4) v = aux[(long)m * g.ldaux + n] > 0.f ? v : 0.1f * v;
-                if (g.drop.p > 0.f) v *= cst_drop_mask(g.drop, dseed, (uint32_t)((long)m * g.N + n + bz * (long)g.M * g.N));
-                float* cp = C + (long)m * g.ldc + n;
-                if (g.accumulate) v += *cp;
-                *cp = v;
+                gemm_epilogue_store(g, C, bias, addend, aux, dseed, bz, m, n, acc[i][j][r]);
             }
         }
     }
 }
 
+// split-K second phase: sum the partial slabs in split order (deterministic) and apply the epilogue
+__global__ __launch_bounds__(256) void cst_gemm_splitk_reduce(GemmArgs g) {
+    const long bz = blockIdx.z;
+    float* C = g.C + bz * g.sC;
+    const float* bias = g.bias ? g.bias + bz * g.sBias : nullptr;
+    const float* addend = g.addend ? g.addend + bz * g.sAdd : nullptr;
+    const float* aux = g.aux ? g.aux + bz * g.sAux : nullptr;
+    const uint32_t dseed = g.drop.p > 0.f ? cst_drop_seed(g.drop) : 0u;
+    const long MN = (long)g.M * g.N;
+    const float* slab = g.slab + bz * g.splits * MN;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < MN; e += (long)gridDim.x * 256) {
+        float acc = 0.f;
+        for (int s = 0; s < g.splits; ++s) acc += slab[s * MN + e];
+        gemm_epilogue_store(g, C, bias, addend, aux, dseed, bz, (int)(e / g.N), (int)(e % g.N), acc);
+    }
+}
+
 template <int BM, int BN>
 static void launch_cfg(const GemmArgs& g, int f32, int akm, int bkm, int batch, hipStream_t st) {
-    dim3 grid(cst_div_up(g.M, BM) * cst_div_up(g.N, BN), 1, batch), block(256);
+    dim3 grid(cst_div_up(g.M, BM) * cst_div_up(g.N, BN), g.splits, batch), block(256);
 #define CST_GEMM_CASE(F, AK, BKM)                                                              \
     if (f32 == F && akm == AK && bkm == BKM) {                                                 \
         hipLaunchKernelGGL((cst_gemm_kernel<BM, BN, (bool)F, (bool)AK, (bool)BKM>), grid, block, 0, st, g); \
@@ -290,7 +333,7 @@ extern "C" int cst_gemm(const float* A, long lda, int a_kmajor, const float* B, 
                         int accumulate, float alpha, int precision_f32,
                         int batch, long sA, long sB, long sC, long sBias, long sAdd, long sAux,
                         float drop_p, uint32_t drop_seed, uint32_t drop_stream, const void* drop_seed_dev,
-                        int tile, void* stream) {
+                        int tile, int splitk, float* workspace, long workspace_floats, void* stream) {
     CST_REQUIRE(A && B && C, "cst_gemm: null operand");
     CST_REQUIRE(M > 0 && N > 0 && K > 0 && batch > 0, "cst_gemm: bad shape M=%d N=%d K=%d batch=%d", M, N, K, batch);
     CST_REQUIRE(lda >= (a_kmajor ? K : M), "cst_gemm: lda=%ld too small", lda);
@@ -312,8 +355,36 @@ extern "C" int cst_gemm(const float* A, long lda, int a_kmajor, const float* B, 
     long big = (long)cst_div_up(M, 128) * cst_div_up(N, 128) * batch;
     int use_big = tile == 128 || (tile == 0 && big >= 192);
     if (tile == 64) use_big = 0;
-    if (use_big) launch_cfg<128, 128>(g, precision_f32 ? 1 : 0, a_kmajor ? 1 : 0, b_kmajor ? 1 : 0, batch, (hipStream_t)stream);
-    else launch_cfg<64, 64>(g, precision_f32 ? 1 : 0, a_kmajor ? 1 : 0, b_kmajor ? 1 : 0, batch, (hipStream_t)stream);
+    // split-K: few output tiles and a long reduction -> partial slabs + a reduce/epilogue pass
+    long tiles = use_big ? big : (long)cst_div_up(M, 64) * cst_div_up(N, 64) * batch;
+    int splits = 1;
+    if (splitk > 1) splits = splitk;
+    else if (splitk == 0 && workspace && tiles < 128 && K >= 512) {
+        splits = (int)((512 + tiles - 1) / tiles);
+        if (splits > K / 128) splits = K / 128;
+    }
+    if (splits > 1) {
+        int kps = cst_div_up(cst_div_up(K, splits), BK) * BK;
+        splits = cst_div_up(K, kps);
+        while (splits > 1 && (long)batch * splits * M * N > workspace_floats) {
+            kps += BK;
+            splits = cst_div_up(K, kps);
+        }
+        g.k_per_split = kps;
+    }
+    if (splits <= 1) { splits = 1; g.k_per_split = cst_div_up(K, BK) * BK; }
+    CST_REQUIRE(splits == 1 || workspace, "cst_gemm: split-K needs a workspace");
+    g.splits = splits;
+    g.slab = workspace;
+    hipStream_t st = (hipStream_t)stream;
+    if (use_big) launch_cfg<128, 128>(g, precision_f32 ? 1 : 0, a_kmajor ? 1 : 0, b_kmajor ? 1 : 0, batch, st);
+    else launch_cfg<64, 64>(g, precision_f32 ? 1 : 0, a_kmajor ? 1 : 0, b_kmajor ? 1 : 0, batch, st);
     CST_LAUNCH_CHECK("cst_gemm");
+    if (splits > 1) {
+        long mn = (long)M * N;
+        int rb = (int)((mn + 255) / 256); if (rb > 2048) rb = 2048;
+        hipLaunchKernelGGL(cst_gemm_splitk_reduce, dim3(rb, 1, batch), dim3(256), 0, st, g);
+        CST_LAUNCH_CHECK("cst_gemm_splitk_reduce");
+    }
     return CST_OK;
 }

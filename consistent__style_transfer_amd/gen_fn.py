@@ -116,8 +116,10 @@ class GeneratorFn(torch.autograd.Function):
         axpby(h0d, 1.0, out=XH[0][:, E:])
         gdec = _new(dev, T, B, 4 * Hd)
         cdec = _new(dev, T, B, Hd)
-        iffn = _new(dev, T, B, Hd + 2 * H)            # [h_t | a_t]
-        iffn_d = _new(dev, T, B, Hd + 2 * H) if drop.p > 0 else iffn
+        W_ = Hd + 2 * H
+        iffn = _new(dev, B, T, W_)                    # [h_t | a_t], batch-major like `out`
+        iffn_d = _new(dev, B, T, W_) if drop.p > 0 else iffn
+        if2, ifd2 = iffn.view(B, T * W_), iffn_d.view(B, T * W_)
         patt = _new(dev, T, B, Lp)
         r1 = _new(dev, B, T, Hd)
         out = _new(dev, B, T, V)
@@ -129,12 +131,14 @@ class GeneratorFn(torch.autograd.Function):
             gemm(XH[s], True, wcat, True, gdec[s], B, 4 * Hd, E + Hd, bias=bdec)
             c_in = c0 if s == 0 else cdec[s - 1]
             h_next = XH[s + 1][:, E:] if s + 1 < T else None
-            _cell_fwd(gdec[s], c_in, iffn[s][:, :Hd], cdec[s], h_next, B, Hd)
-            call("cst_dot_attn_fwd", iffn[s][:, :Hd], Hd + 2 * H, memory, iffn[s][:, Hd:], Hd + 2 * H, patt[s], B, Lp, Hd)
+            i_s = if2[:, s * W_:(s + 1) * W_]
+            _cell_fwd(gdec[s], c_in, i_s[:, :Hd], cdec[s], h_next, B, Hd)
+            call("cst_dot_attn_fwd", i_s[:, :Hd], T * W_, memory, i_s[:, Hd:], T * W_, patt[s], B, Lp, Hd)
+            id_s = ifd2[:, s * W_:(s + 1) * W_]
             if drop.p > 0:
-                dropout2d(iffn[s], drop.at(STREAM_G_FFN + s), out=iffn_d[s])
+                dropout2d(i_s, drop.at(STREAM_G_FFN + s), out=id_s)
             r1s = r12[:, s * Hd:(s + 1) * Hd]
-            linear_fwd(iffn_d[s], P["fn_1.weight"], P["fn_1.bias"], act=2, out=r1s)
+            linear_fwd(id_s, P["fn_1.weight"], P["fn_1.bias"], act=2, out=r1s)
             o_s = out2[:, s * V:(s + 1) * V]
             linear_fwd(r1s, P["fn_2.weight"], None, out=o_s)
             if soft:
@@ -173,9 +177,18 @@ class GeneratorFn(torch.autograd.Function):
         G = {k: None for k in PARAM_KEYS}
         dE = torch.zeros(V, E, device=dev, dtype=torch.float32)
         dmem = torch.zeros(B, Lp, 2 * H, device=dev, dtype=torch.float32)
-        dpre1 = _new(dev, T, B, Hd)
+        W_ = Hd + 2 * H
+        if2 = iffn.view(B, T * W_)
+        dpre1 = _new(dev, B, T, Hd)
+        dp12 = dpre1.view(B, T * Hd)
         dgd = _new(dev, T, B, 4 * Hd)
-        diffn = _new(dev, B, Hd + 2 * H)
+        diffn_all = _new(dev, B, T, W_)
+        df2 = diffn_all.view(B, T * W_)
+        if not soft:
+            # all dlogits are known up front (token CE): one large dgrad through fn_2 (+LeakyReLU gate)
+            # and one through fn_1 instead of T small ones
+            dgrad(dout.view(B * T, V), P["fn_2.weight"], out=dpre1.view(B * T, Hd), aux=r1.view(B * T, Hd), act=4)
+            dgrad(dpre1.view(B * T, Hd), P["fn_1.weight"], out=diffn_all.view(B * T, W_))
         dXH = _new(dev, B, E + Hd)
         dxe = _new(dev, B, E)
         dc = _new(dev, B, Hd)
@@ -199,11 +212,17 @@ class GeneratorFn(torch.autograd.Function):
                     embed_scatter_add(dE, g_x, ids_a=ids_fb[s], ids_b=x_c[:, s], ldb=T, coin=coins[s:s + 1])
             if soft:
                 softmax_tau_bwd(out2[:, s * V:(s + 1) * V], dl, inv_tau, dl)
-            r1s = r12[:, s * Hd:(s + 1) * Hd]
-            dgrad(dl, P["fn_2.weight"], out=dpre1[s], aux=r1s, act=4)                     # through LeakyReLU
-            dgrad(dpre1[s], P["fn_1.weight"], out=diffn, drop=drop.at(STREAM_G_FFN + s))    # through dropout(i_ffn)
-            call("cst_dot_attn_bwd", diffn[:, Hd:], Hd + 2 * H, iffn[s][:, :Hd], Hd + 2 * H, memory, patt[s],
-                 diffn[:, :Hd], Hd + 2 * H, 1, dmem, B, Lp, Hd)
+            diffn = df2[:, s * W_:(s + 1) * W_]
+            fd = drop.at(STREAM_G_FFN + s)
+            if soft:
+                r1s = r12[:, s * Hd:(s + 1) * Hd]
+                dp1s = dp12[:, s * Hd:(s + 1) * Hd]
+                dgrad(dl, P["fn_2.weight"], out=dp1s, aux=r1s, act=4)                   # through LeakyReLU
+                dgrad(dp1s, P["fn_1.weight"], out=diffn, drop=fd)                         # through dropout(i_ffn)
+            elif fd.p > 0:
+                dropout2d(diffn, fd, out=diffn)
+            call("cst_dot_attn_bwd", diffn[:, Hd:], T * W_, if2[:, s * W_:s * W_ + Hd], T * W_, memory, patt[s],
+                 diffn[:, :Hd], T * W_, 1, dmem, B, Lp, Hd)
             c_prev = c0 if s == 0 else cdec[s - 1]
             last = s == T - 1
             _cell_bwd(gdec[s], c_prev, cdec[s], diffn[:, :Hd], None if last else dXH[:, E:], None if last else dc,
@@ -220,8 +239,8 @@ class GeneratorFn(torch.autograd.Function):
         dc_cat = dgrad(dpre_t, P["transfer.weight"])
         # batched weight gradients of the decoder
         G["fn_2.weight"] = wgrad(dout.view(B * T, V), r1.view(B * T, Hd))
-        dp1 = dpre1.view(T * B, Hd)
-        G["fn_1.weight"] = wgrad(dp1, iffn_d.view(T * B, Hd + 2 * H))
+        dp1 = dpre1.view(B * T, Hd)
+        G["fn_1.weight"] = wgrad(dp1, iffn_d.view(B * T, W_))
         G["fn_1.bias"] = colsum(dp1)
         dg2 = dgd.view(T * B, 4 * Hd)
         dwcat = wgrad(dg2, XH.view(T * B, E + Hd))

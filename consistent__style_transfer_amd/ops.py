@@ -66,13 +66,25 @@ def _f32(t):
 # =============================================================================================
 # raw wrappers
 # =============================================================================================
+_WS = {}
+WS_FLOATS = 8 * 1024 * 1024          # 32 MiB split-K slab workspace per device
+
+
+def _workspace(dev):
+    ws = _WS.get(dev)
+    if ws is None:
+        ws = _WS[dev] = torch.empty(WS_FLOATS, device=dev, dtype=torch.float32)
+    return ws
+
+
 def gemm(A, a_kmajor, B, b_kmajor, C, M, N, K, bias=None, addend=None, aux=None, act=0, gate_scale=1.0,
-         accumulate=False, alpha=1.0, drop=NO_DROP, tile=0):
+         accumulate=False, alpha=1.0, drop=NO_DROP, tile=0, splitk=0):
     """C[M,N] = epi(alpha * op(A) op(B)); A, B, C, addend, aux are row-major 2-D views."""
+    ws = _workspace(C.device)
     call("cst_gemm", _f32(A), _ld(A), int(a_kmajor), _f32(B), _ld(B), int(b_kmajor), _f32(C), _ld(C), M, N, K,
          bias, addend, _ld(addend) if addend is not None else 0, aux, _ld(aux) if aux is not None else 0,
          act, float(gate_scale), int(accumulate), float(alpha), int(_STATE["f32"]),
-         1, 0, 0, 0, 0, 0, 0, *drop.args(), tile)
+         1, 0, 0, 0, 0, 0, 0, *drop.args(), tile, splitk, ws, WS_FLOATS)
     return C
 
 

@@ -37,7 +37,9 @@ int cst_abi_version(void);
  * (0 none, 1 relu, 2 LeakyReLU(0.1), 3 aux>0 ? v*gate_scale : 0, 4 aux>0 ? v : 0.1 v),
  * dropout over index m*N+n, optional C += v.  precision_f32 = 1 uses v_mfma_f32_16x16x4_f32
  * (exact fp32), 0 uses v_mfma_f32_16x16x32_bf16 with fp32 accumulation.  batch > 1 repeats with
- * the element strides s*.  tile: 0 auto, 64 or 128.
+ * the element strides s*.  tile: 0 auto, 64 or 128.  splitk: 0 auto (few output tiles and a long
+ * K are cut into K-slices whose partial sums go to `workspace` and are summed in slice order by a
+ * second pass that applies the epilogue), 1 never, >1 forced; workspace_floats >= batch*splits*M*N.
  * Replaces: nn.Linear / F.linear / tensor.matmul at rnn.py:35-38,61,79-80,85; mlm.py:24,31,45;
  * match.py:22,28,43; classifier.py:21,27,37; discriminator.py:28,35-37,39,45,48-49; the packed
  * in_proj / out_proj / linear1 / linear2 of nn.TransformerEncoderLayer (mlm.py:20-22,
@@ -50,7 +52,7 @@ int cst_gemm(const float* A, long lda, int a_kmajor, const float* B, long ldb, i
              int accumulate, float alpha, int precision_f32,
              int batch, long sA, long sB, long sC, long sBias, long sAdd, long sAux,
              float drop_p, uint32_t drop_seed, uint32_t drop_stream, const void* drop_seed_dev,
-             int tile, void* stream);
+             int tile, int splitk, float* workspace, long workspace_floats, void* stream);
 
 /* Fused token cross-entropy forward + backward: row_loss[r] = logsumexp(x_r) - x_r[target_r];
  * dlogits = grad_scale * (softmax(x_r) - onehot(target_r)) (may alias logits; null = forward

@@ -27,7 +27,7 @@ def test_header_cites_reference_call_sites():
 def test_argument_errors_are_status_codes_not_exceptions():
     L = _lib.lib()
     rc = L.fn["cst_gemm"](None, 0, 1, None, 0, 1, None, 0, 4, 4, 4, None, None, 0, None, 0, 0, 1.0, 0, 1.0, 0,
-                          1, 0, 0, 0, 0, 0, 0, 0.0, 0, 0, None, 0, None)
+                          1, 0, 0, 0, 0, 0, 0, 0.0, 0, 0, None, 0, 0, None, 0, None)
     assert rc == 1
     assert "null operand" in L.last_error()
     rc = L.fn["cst_mha_fwd"](1, 1, 1, 2, 100, 8, 64, 0.0, 0, 0, None, None)

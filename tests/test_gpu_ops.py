@@ -54,6 +54,26 @@ def test_gemm_layouts(ops, prec, shape, akm, bkm):
     ops.set_precision("bf16")
 
 
+@pytest.mark.parametrize("prec", ["f32", "bf16"])
+@pytest.mark.parametrize("shape,akm,bkm", [((256, 512, 10000), 1, 0), ((300, 24, 65536), 0, 0), ((37, 53, 1900), 1, 1),
+                                           ((256, 256, 1024), 1, 0), ((100, 1200, 4096), 0, 0)])
+def test_gemm_splitk(ops, prec, shape, akm, bkm):
+    """Long-K / few-tile shapes take the split-K path (auto and forced) with a gated, accumulating epilogue."""
+    ops.set_precision(prec)
+    M, N, K = shape
+    A, B = rnd(M, K, seed=1), rnd(K, N, seed=2)
+    aux, c0 = rnd(M, N, seed=3), rnd(M, N, seed=4)
+    ref = c0 + torch.where(aux > 0, A @ B, 0.1 * (A @ B))
+    Ad = dev(A if akm else A.t().contiguous())
+    Bd = dev(B.t().contiguous() if bkm else B)
+    tol = 2e-4 if prec == "f32" else 2e-2
+    for sk in (0, 7):
+        C = dev(c0.clone())
+        ops.gemm(Ad, akm, Bd, bkm, C, M, N, K, aux=dev(aux), act=4, accumulate=True, splitk=sk)
+        close(C, ref, tol, tol * math.sqrt(K), f"{shape} splitk={sk}")
+    ops.set_precision("bf16")
+
+
 @pytest.mark.parametrize("tile", [64, 128])
 def test_gemm_epilogues(ops, tile):
     ops.set_precision("f32")
