@@ -69,13 +69,43 @@ def coins_for(step, L):
     return [r.random() < 0.5 for _ in range(L)]
 
 
+def coins_tensor(step, L, device):
+    return torch.tensor([int(c) for c in coins_for(step, L)], dtype=torch.int32).to(device, non_blocking=True)
+
+
 def run_step(stages_, batches, it, reducer):
+    """Eager step (used with --no-graph, for N > 1 and for the per-kernel timing leg)."""
     pre, wu, opt = stages_
     bp, bw, bo = batches[it % len(batches)]
     L = bw[1].shape[1]
+    dev = bw[1].device
     pre.train_step(bp, seed=3 * it, reducer=reducer)
-    wu.train_step(bw, coins=coins_for(2 * it, L), seed=3 * it + 1, reducer=reducer)
-    opt.train_step(bo, it, coins=coins_for(2 * it + 1, L), seed=3 * it + 2, reducer=reducer)
+    wu.train_step(bw, coins=coins_tensor(2 * it, L, dev), seed=3 * it + 1, reducer=reducer)
+    opt.train_step(bo, it, coins=coins_tensor(2 * it + 1, L, dev), seed=3 * it + 2, reducer=reducer)
+
+
+class GraphedPipeline:
+    """The three stage steps captured as hipGraphs (the optimize stage twice: with and without
+    the every-4th-batch discriminator update)."""
+
+    def __init__(self, stages_, batches):
+        from consistent__style_transfer_amd.graphs import GraphedStep
+        pre, wu, opt = stages_
+        bp, bw, bo = batches[0]
+        L = bw[1].shape[1]
+        dev = bw[1].device
+        c0 = coins_tensor(0, L, dev)
+        self.pre = GraphedStep(lambda *b: pre.train_step(b), list(bp), [pre])
+        self.wu = GraphedStep(lambda nx, x, lab, coins: wu.train_step((nx, x, lab), coins=coins), list(bw) + [c0], [wu])
+        self.opt_d = GraphedStep(lambda x, lab, coins: opt.train_step((x, lab), 0, coins=coins), list(bo) + [c0], [opt])
+        self.opt_nd = GraphedStep(lambda x, lab, coins: opt.train_step((x, lab), 1, coins=coins), list(bo) + [c0], [opt])
+        self.L, self.dev = L, dev
+
+    def step(self, batches, it):
+        bp, bw, bo = batches[it % len(batches)]
+        self.pre(*bp)
+        self.wu(*bw, coins_tensor(2 * it, self.L, self.dev))
+        (self.opt_d if it % 4 == 0 else self.opt_nd)(*bo, coins_tensor(2 * it + 1, self.L, self.dev))
 
 
 def cpu_baseline(w, budget_s=25.0):
@@ -140,6 +170,7 @@ def main():
     ap.add_argument("--precision", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying hipGraphs")
     ap.add_argument("--breakdown", action="store_true", help="print the per-entry-point time table to stderr")
     args = ap.parse_args()
 
@@ -161,12 +192,18 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
+    use_graph = (not args.no_graph) and world == 1
+    if use_graph:
+        pipe = GraphedPipeline(stages_, batches)
+        step = lambda it: pipe.step(batches, it)
+    else:
+        step = lambda it: run_step(stages_, batches, it, reducer)
     for it in range(args.warmup):
-        run_step(stages_, batches, it, reducer)
+        step(it)
     barrier()
     t0 = time.perf_counter()
     for it in range(args.steps):
-        run_step(stages_, batches, args.warmup + it, reducer)
+        step(args.warmup + it)
     barrier()
     dt = max_over_ranks(time.perf_counter() - t0, device)
     ms_per_step = 1000.0 * dt / args.steps
@@ -216,7 +253,8 @@ def main():
             "dtype": args.precision if args.precision == "bf16" else "f32", "data": "synthetic",
             "config": {"workload": args.workload, "per_gpu_batch": w["B"], "global_batch": w["B"] * world,
                        "seq_len": w["L"], "vocab": w["V"], "critic_layers": w["n_layer"], "d_model": w["d_model"],
-                       "parallelism": f"dp{world}", "stages": "pretrain+warmup+optimize(G+D)", "weights": "random-init"},
+                       "parallelism": f"dp{world}", "stages": "pretrain+warmup+optimize(G+D)", "weights": "random-init",
+                       "launch": "hipGraph replay" if use_graph else "eager"},
             "roofline": roofline, "cpu_baseline": cpu,
         }
         print(json.dumps(line), flush=True)

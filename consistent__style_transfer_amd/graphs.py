@@ -1,0 +1,52 @@
+"""HIP-graph capture of whole training steps.
+
+A stage step is ~500-1500 small kernel launches (18 sequential decode steps x 3 decodes, 4-6
+encoder layers forward and backward, optimiser); launched eagerly the host cannot feed the GPU
+(each launch costs 5-10 us of host time for kernels that run 2-20 us).  Every entry point of
+libcst_hip.so is capture-safe (no allocation, no synchronisation), so the whole step -- forward,
+backward, gradient gather, clipping, Adam -- is recorded once into a hipGraph and replayed.
+
+Anything that varies between steps is read from device memory: the batch (static input buffers),
+the scheduled-sampling coins (int32 device vector consumed by cst_embed_gather), the dropout seed
+(a device word added to every call site's seed and bumped by the graph itself) and Adam's step
+counter.
+"""
+import torch
+
+from ._lib import call
+
+
+class GraphedStep:
+    def __init__(self, fn, example_inputs, seed_modules=(), warmup=2):
+        """fn(*static_inputs) -> dict of tensors.  `example_inputs`: tensors fixing shapes/dtypes.
+        `seed_modules`: modules whose dropout seed must advance on every replay."""
+        dev = example_inputs[0].device
+        self.static_in = [t.clone() for t in example_inputs]
+        self.seed_dev = torch.zeros(1, dtype=torch.int32, device=dev)
+        for m in seed_modules:
+            for sub in m.modules():
+                st = getattr(sub, "_seed_state", None)
+                if st is not None:
+                    st.seed_dev = self.seed_dev
+        self.fn = fn
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            for _ in range(warmup):
+                self._body()
+        torch.cuda.current_stream().wait_stream(s)
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.static_out = self._body()
+        torch.cuda.synchronize()
+
+    def _body(self):
+        call("cst_add_i32", self.seed_dev, 7919)          # new dropout masks on every replay
+        return self.fn(*self.static_in)
+
+    def __call__(self, *inputs):
+        for dst, src in zip(self.static_in, inputs):
+            dst.copy_(src, non_blocking=True)
+        self.graph.replay()
+        return self.static_out

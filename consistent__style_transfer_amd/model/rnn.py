@@ -58,7 +58,9 @@ class DenoiseLSTM(nn.Module):
                 coins = [random.random() < 1 / 2 for _ in range(x.size(1))]
             if not isinstance(coins, torch.Tensor):
                 coins = torch.tensor([int(bool(c)) for c in coins], dtype=torch.int32)
-            coins_dev = coins.to(device=inp.device, dtype=torch.int32).contiguous()
+            if coins.device != inp.device or coins.dtype != torch.int32:
+                coins = coins.to(device=inp.device, dtype=torch.int32)
+            coins_dev = coins.contiguous()
         cfg = {"mode": mode, "tau": tau, "max_len": self.max_len, "drop": make_drop(self, p_drop, seed)}
         out, ids = GeneratorFn.apply(inp, label_i, x, label, coins_dev, cfg, *self._params())
         self.last_ids = ids

@@ -182,6 +182,7 @@ class OptimizeStage(nn.Module):
         self.g_group.gather_grads(False)
         if reducer is not None:
             reducer([self.g_group])
+        self.d_group.has_grad = True                      # its (possibly all-zero) accumulated grads join the norm
         clip_groups([self.g_group, self.d_group], self.clip, self._scratch)
         self.g_group.step()
         self.g_group.zero_grad()
@@ -192,7 +193,7 @@ class OptimizeStage(nn.Module):
         self.disc.train(self.training)                                        # main_optimize.py:116
         d = self.d_losses(batch, seed)
         d["loss"].backward()
-        self.d_group.gather_grads(self.d_group.has_grad)                       # accumulates until zero_grad
+        self.d_group.gather_grads(True)                   # += : accumulates until zero_grad (flat_g is 0 after it)
         if reducer is not None and batch_idx % 4 == 0:
             reducer([self.d_group])
         clip_groups([self.g_group, self.d_group], self.clip, self._scratch)
