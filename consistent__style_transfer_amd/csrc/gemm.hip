@@ -12,11 +12,12 @@
 //   B "K-major"  : B[n*ldb + k]      (a torch Linear weight [out,in] used as is: forward)
 //   B "MN-major" : B[k*ldb + n]      (the weight used transposed: dgrad; activations in wgrad)
 // so no operand is ever transposed in HBM.  Tiles are staged global -> registers -> LDS as
-// [row][k] images (k contiguous, padded) whatever the HBM layout; MN-major tiles are transposed
-// in registers (4x4 patches) on the way.  Two arithmetic modes:
+// [row][k] images (k contiguous, XOR-swizzled 16-byte slots) whatever the HBM layout; MN-major
+// tiles are transposed in registers on the way.  Two arithmetic modes:
 //   bf16 : v_mfma_f32_16x16x32_bf16, operands rounded to bf16 while staging, fp32 accumulate
 //   f32  : v_mfma_f32_16x16x4_f32, exact fp32 products (the parity mode)
-// 256 threads = 4 waves in a 2x2 grid; tile BMxBN = 128x128 or 64x64, BK = 32.
+// 256 threads = 4 waves in a 2x2 grid; tile BMxBN = 128x128 or 64x64; a K-tile is 128 bytes per
+// row in LDS (BK = 64 in bf16 mode, 32 in f32 mode), double buffered, one barrier per K-tile.
 #include "cst_common.h"
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
@@ -62,125 +63,90 @@ __device__ __forceinline__ unsigned short f2bf(float f) {
     return __builtin_bit_cast(unsigned short, b);
 }
 
-constexpr int BK = 32;
+// ---- LDS tile image -----------------------------------------------------------------------
+// Every operand tile is stored as [rows][128 bytes]: 64 bf16 (bf16 mode, BK = 64) or 32 fp32
+// (f32 mode, BK = 32) of consecutive k per row, i.e. 8 slots of 16 bytes.  Slot s of row r lives
+// at physical slot s ^ (r & 7): with 128-byte rows every row starts on bank 0, and the XOR makes
+// both the 16-byte staging stores (8 lanes = 8 slots of one row, or 8 consecutive rows of one
+// slot) and the ds_read_b128 fragment reads (16 rows x 4 k-slots per wave) bank-conflict free.
+template <bool F32> struct TileCfg { static constexpr int BK = 64; };
+template <> struct TileCfg<true> { static constexpr int BK = 32; };
+constexpr int ROW_BYTES = 128;
 
-template <bool F32> struct LdsElem { typedef unsigned short type; static constexpr int PAD = 8; };
-template <> struct LdsElem<true> { typedef float type; static constexpr int PAD = 4; };
+__device__ __forceinline__ int lds_off(int row, int slot) { return row * ROW_BYTES + ((slot ^ (row & 7)) << 4); }
 
-// ---- global -> register staging --------------------------------------------------------------
-// K-major operand: tile [ROWS][BK]; each thread owns float4 chunks along k.
-template <int ROWS>
-struct StageK {
-    static constexpr int CHUNKS = ROWS * (BK / 4);            // float4 chunks in the tile
-    static constexpr int PER_T = (CHUNKS + 255) / 256;
-    float4 v[PER_T];
-    __device__ __forceinline__ void load(const float* __restrict__ P, long ld, int row0, int k0, int rows, int K, int vec) {
+template <bool F32>
+__device__ __forceinline__ uint4 pack_slot(const float (&v)[8]) {
+    uint4 u;
+    if constexpr (F32) {        // only v[0..3] are meaningful
+        u.x = __float_as_uint(v[0]); u.y = __float_as_uint(v[1]); u.z = __float_as_uint(v[2]); u.w = __float_as_uint(v[3]);
+    } else {
+        u.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
+        u.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
+        u.z = (uint32_t)f2bf(v[4]) | ((uint32_t)f2bf(v[5]) << 16);
+        u.w = (uint32_t)f2bf(v[6]) | ((uint32_t)f2bf(v[7]) << 16);
+    }
+    return u;
+}
+
+// ---- global -> register -> LDS staging ---------------------------------------------------------
+// One "item" = one 16-byte LDS slot = EPS consecutive k of one row (8 bf16 or 4 fp32).
+// K-major operand : item idx -> (row = idx / 8, slot = idx % 8); the k run is contiguous in HBM
+//                   (one or two float4 loads; 8 lanes cover 128..256 contiguous bytes of a row).
+// MN-major operand: item idx -> (row = idx % ROWS, slot = idx / ROWS); for a fixed k the rows are
+//                   contiguous in HBM, so each of the EPS scalar loads is coalesced across lanes
+//                   (64 lanes x 4 B) and the transpose happens in registers.
+template <int ROWS, bool F32, bool KMAJ>
+struct Stage {
+    static constexpr int EPS = F32 ? 4 : 8;
+    static constexpr int ITEMS = ROWS * 8;
+    static constexpr int PER_T = ITEMS / 256;
+    float v[PER_T][8];
+    __device__ __forceinline__ void load(const float* __restrict__ P, long ld, int row0, int k0, int rows, int kend, int vec) {
 #pragma unroll
         for (int i = 0; i < PER_T; ++i) {
             const int idx = threadIdx.x + 256 * i;
-            const int r = idx / (BK / 4), c = (idx % (BK / 4)) * 4;
-            float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (idx < CHUNKS && row0 + r < rows) {
-                const float* p = P + (long)(row0 + r) * ld + k0 + c;
-                if (vec && k0 + c + 3 < K) {
-                    t = *reinterpret_cast<const float4*>(p);
+            const int r = KMAJ ? idx >> 3 : idx % ROWS;
+            const int slot = KMAJ ? idx & 7 : idx / ROWS;
+            const int k = k0 + slot * EPS;
+            const bool rok = row0 + r < rows;
+            if constexpr (KMAJ) {
+                const float* p = P + (long)(row0 + r) * ld + k;
+                if (rok && vec && k + EPS <= kend) {
+                    const float4 a = *reinterpret_cast<const float4*>(p);
+                    v[i][0] = a.x; v[i][1] = a.y; v[i][2] = a.z; v[i][3] = a.w;
+                    if constexpr (!F32) {
+                        const float4 b = *reinterpret_cast<const float4*>(p + 4);
+                        v[i][4] = b.x; v[i][5] = b.y; v[i][6] = b.z; v[i][7] = b.w;
+                    }
                 } else {
-                    if (k0 + c + 0 < K) t.x = p[0];
-                    if (k0 + c + 1 < K) t.y = p[1];
-                    if (k0 + c + 2 < K) t.z = p[2];
-                    if (k0 + c + 3 < K) t.w = p[3];
+#pragma unroll
+                    for (int e = 0; e < EPS; ++e) v[i][e] = (rok && k + e < kend) ? p[e] : 0.f;
                 }
+            } else {
+                const float* p = P + (long)k * ld + row0 + r;
+#pragma unroll
+                for (int e = 0; e < EPS; ++e) v[i][e] = (rok && k + e < kend) ? p[(long)e * ld] : 0.f;
             }
-            v[i] = t;
         }
     }
-    template <bool F32, int LDS_LD>
-    __device__ __forceinline__ void store(typename LdsElem<F32>::type* S) {
+    __device__ __forceinline__ void store(char* S) const {
 #pragma unroll
         for (int i = 0; i < PER_T; ++i) {
             const int idx = threadIdx.x + 256 * i;
-            if (idx < CHUNKS) {
-                const int r = idx / (BK / 4), c = (idx % (BK / 4)) * 4;
-                if constexpr (F32) {
-                    *reinterpret_cast<float4*>(&S[r * LDS_LD + c]) = v[i];
-                } else {
-                    uint2 pk;
-                    pk.x = (uint32_t)f2bf(v[i].x) | ((uint32_t)f2bf(v[i].y) << 16);
-                    pk.y = (uint32_t)f2bf(v[i].z) | ((uint32_t)f2bf(v[i].w) << 16);
-                    *reinterpret_cast<uint2*>(&S[r * LDS_LD + c]) = pk;
-                }
-            }
+            const int r = KMAJ ? idx >> 3 : idx % ROWS;
+            const int slot = KMAJ ? idx & 7 : idx / ROWS;
+            *reinterpret_cast<uint4*>(S + lds_off(r, slot)) = pack_slot<F32>(v[i]);
         }
     }
 };
-
-// MN-major operand: HBM tile is [BK][ROWS] (rows contiguous); each thread owns 4(k) x 4(row)
-// patches, loaded as 4 float4 along the contiguous dimension and transposed in registers.
-template <int ROWS>
-struct StageMN {
-    static constexpr int PATCHES = (BK / 4) * (ROWS / 4);
-    static constexpr int PER_T = (PATCHES + 255) / 256;
-    float4 v[PER_T][4];
-    __device__ __forceinline__ void load(const float* __restrict__ P, long ld, int row0, int k0, int rows, int K, int vec) {
-#pragma unroll
-        for (int i = 0; i < PER_T; ++i) {
-            const int p = threadIdx.x + 256 * i;
-            const int rg = (p % (ROWS / 4)) * 4, kg = (p / (ROWS / 4)) * 4;
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk) {
-                float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (p < PATCHES && k0 + kg + kk < K) {
-                    const float* q = P + (long)(k0 + kg + kk) * ld + row0 + rg;
-                    if (vec && row0 + rg + 3 < rows) {
-                        t = *reinterpret_cast<const float4*>(q);
-                    } else {
-                        if (row0 + rg + 0 < rows) t.x = q[0];
-                        if (row0 + rg + 1 < rows) t.y = q[1];
-                        if (row0 + rg + 2 < rows) t.z = q[2];
-                        if (row0 + rg + 3 < rows) t.w = q[3];
-                    }
-                }
-                v[i][kk] = t;
-            }
-        }
-    }
-    template <bool F32, int LDS_LD>
-    __device__ __forceinline__ void store(typename LdsElem<F32>::type* S) {
-#pragma unroll
-        for (int i = 0; i < PER_T; ++i) {
-            const int p = threadIdx.x + 256 * i;
-            if (p < PATCHES) {
-                const int rg = (p % (ROWS / 4)) * 4, kg = (p / (ROWS / 4)) * 4;
-                const float a[4][4] = {{v[i][0].x, v[i][1].x, v[i][2].x, v[i][3].x},
-                                       {v[i][0].y, v[i][1].y, v[i][2].y, v[i][3].y},
-                                       {v[i][0].z, v[i][1].z, v[i][2].z, v[i][3].z},
-                                       {v[i][0].w, v[i][1].w, v[i][2].w, v[i][3].w}};
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    if constexpr (F32) {
-                        *reinterpret_cast<float4*>(&S[(rg + j) * LDS_LD + kg]) = make_float4(a[j][0], a[j][1], a[j][2], a[j][3]);
-                    } else {
-                        uint2 pk;
-                        pk.x = (uint32_t)f2bf(a[j][0]) | ((uint32_t)f2bf(a[j][1]) << 16);
-                        pk.y = (uint32_t)f2bf(a[j][2]) | ((uint32_t)f2bf(a[j][3]) << 16);
-                        *reinterpret_cast<uint2*>(&S[(rg + j) * LDS_LD + kg]) = pk;
-                    }
-                }
-            }
-        }
-    }
-};
-
-template <int ROWS, bool KMAJ> struct StageSel { typedef StageK<ROWS> type; };
-template <int ROWS> struct StageSel<ROWS, false> { typedef StageMN<ROWS> type; };
 
 template <int BM, int BN, bool F32, bool A_KMAJ, bool B_KMAJ>
 __global__ __launch_bounds__(256) void cst_gemm_kernel(GemmArgs g) {
-    typedef typename LdsElem<F32>::type elem_t;
-    constexpr int LDS_LD = BK + LdsElem<F32>::PAD;
+    constexpr int BK = TileCfg<F32>::BK;
     constexpr int TM = BM / 32, TN = BN / 32;      // 16x16 tiles per wave in each direction
-    __shared__ __attribute__((aligned(16))) elem_t As[BM * LDS_LD];
-    __shared__ __attribute__((aligned(16))) elem_t Bs[BN * LDS_LD];
+    constexpr int A_BYTES = BM * ROW_BYTES, B_BYTES = BN * ROW_BYTES;
+    __shared__ __attribute__((aligned(16))) char smem[2 * (A_BYTES + B_BYTES)];
 
     const int tilesM = (g.M + BM - 1) / BM;
     const int tm = blockIdx.x % tilesM, tn = blockIdx.x / tilesM;
@@ -199,57 +165,53 @@ __global__ __launch_bounds__(256) void cst_gemm_kernel(GemmArgs g) {
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
-    typename StageSel<BM, A_KMAJ>::type sa;
-    typename StageSel<BN, B_KMAJ>::type sb;
+    Stage<BM, F32, A_KMAJ> sa;
+    Stage<BN, F32, B_KMAJ> sb;
     const int kbeg = blockIdx.y * g.k_per_split;
     const int kend = min(g.K, kbeg + g.k_per_split);
+    const int nk = (kend - kbeg + BK - 1) / BK;
     sa.load(A, g.lda, m0, kbeg, g.M, kend, g.vecA);
     sb.load(B, g.ldb, n0, kbeg, g.N, kend, g.vecB);
+    sa.store(smem);
+    sb.store(smem + A_BYTES);
+    __syncthreads();
 
-    const int nk = (kend - kbeg + BK - 1) / BK;
     for (int kt = 0; kt < nk; ++kt) {
-        sa.template store<F32, LDS_LD>(As);
-        sb.template store<F32, LDS_LD>(Bs);
-        __syncthreads();
-        if (kt + 1 < nk) {
+        const char* As = smem + (kt & 1) * (A_BYTES + B_BYTES);
+        const char* Bs = As + A_BYTES;
+        if (kt + 1 < nk) {                     // next tile: HBM -> registers while this one is multiplied
             sa.load(A, g.lda, m0, kbeg + (kt + 1) * BK, g.M, kend, g.vecA);
             sb.load(B, g.ldb, n0, kbeg + (kt + 1) * BK, g.N, kend, g.vecB);
         }
-        if constexpr (!F32) {
-            bf16x8_t af[TM], bfr[TN];
+        // two k-steps per tile; fragment slot of lane group lq in step kk is kk*4 + lq
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            uint4 af[TM], bfr[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const uint4*>(As + lds_off(wm * (BM / 2) + i * 16 + lr, kk * 4 + lq));
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bfr[j] = *reinterpret_cast<const uint4*>(Bs + lds_off(wn * (BN / 2) + j * 16 + lr, kk * 4 + lq));
 #pragma unroll
             for (int i = 0; i < TM; ++i)
-                af[i] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u16x8_t*>(&As[(wm * (BM / 2) + i * 16 + lr) * LDS_LD + lq * 8]));
 #pragma unroll
-            for (int j = 0; j < TN; ++j)
-                bfr[j] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u16x8_t*>(&Bs[(wn * (BN / 2) + j * 16 + lr) * LDS_LD + lq * 8]));
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
-        } else {
-            // k order inside the tile is permuted identically for A and B: MFMA (kk,e) consumes
-            // k = 16*kk + 4*lq + e from lane group lq -- each k exactly once.
-#pragma unroll
-            for (int kk = 0; kk < BK / 16; ++kk) {
-                float4 af[TM], bfr[TN];
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-                    af[i] = *reinterpret_cast<const float4*>(&As[(wm * (BM / 2) + i * 16 + lr) * LDS_LD + kk * 16 + lq * 4]);
-#pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    bfr[j] = *reinterpret_cast<const float4*>(&Bs[(wn * (BN / 2) + j * 16 + lr) * LDS_LD + kk * 16 + lq * 4]);
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int j = 0; j < TN; ++j) {
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i].x, bfr[j].x, acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i].y, bfr[j].y, acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i].z, bfr[j].z, acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i].w, bfr[j].w, acc[i][j], 0, 0, 0);
+                for (int j = 0; j < TN; ++j) {
+                    if constexpr (!F32) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, af[i]),
+                                                                            __builtin_bit_cast(bf16x8_t, bfr[j]), acc[i][j], 0, 0, 0);
+                    } else {
+                        // k order inside the step is permuted identically for A and B: MFMA e consumes
+                        // k = 16*kk + 4*lq + e from lane group lq -- each k exactly once.
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(af[i].x), __uint_as_float(bfr[j].x), acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(af[i].y), __uint_as_float(bfr[j].y), acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(af[i].z), __uint_as_float(bfr[j].z), acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(af[i].w), __uint_as_float(bfr[j].w), acc[i][j], 0, 0, 0);
                     }
-            }
+                }
+        }
+        if (kt + 1 < nk) {                     // the other buffer was last read before the previous barrier
+            char* An = smem + ((kt + 1) & 1) * (A_BYTES + B_BYTES);
+            sa.store(An);
+            sb.store(An + A_BYTES);
         }
         __syncthreads();
     }
@@ -351,28 +313,37 @@ extern "C" int cst_gemm(const float* A, long lda, int a_kmajor, const float* B, 
     g.vecA = vec_ok(A, lda, sA); g.vecB = vec_ok(B, ldb, sB);
     g.alpha = alpha; g.gate_scale = gate_scale;
     g.drop = cst_make_drop(drop_p, drop_seed, drop_stream, drop_seed_dev);
-    // tile choice: big tiles only when they still fill the 256 CUs
-    long big = (long)cst_div_up(M, 128) * cst_div_up(N, 128) * batch;
-    int use_big = tile == 128 || (tile == 0 && big >= 192);
-    if (tile == 64) use_big = 0;
-    // split-K: few output tiles and a long reduction -> partial slabs + a reduce/epilogue pass
-    long tiles = use_big ? big : (long)cst_div_up(M, 64) * cst_div_up(N, 64) * batch;
-    int splits = 1;
-    if (splitk > 1) splits = splitk;
-    else if (splitk == 0 && workspace && tiles < 128 && K >= 512) {
-        splits = (int)((512 + tiles - 1) / tiles);
-        if (splits > K / 128) splits = K / 128;
+    // tile / split choice.  128x128 tiles when they fill the 256 CUs on their own; with a long K
+    // and a handful of big tiles, big tiles + split-K; otherwise 64x64 tiles, split along K when
+    // even those are few.  Partial slabs are summed in slice order by cst_gemm_splitk_reduce.
+    const long big = (long)cst_div_up(M, 128) * cst_div_up(N, 128) * batch;
+    const long small = (long)cst_div_up(M, 64) * cst_div_up(N, 64) * batch;
+    int use_big, splits = 1;
+    if (tile == 128 || (tile == 0 && big >= 192)) { use_big = 1; }
+    else if (tile == 0 && K >= 2048 && big >= 16 && workspace && splitk == 0) {
+        use_big = 1;
+        splits = (int)((512 + big - 1) / big);
+        if (splits > K / 512) splits = K / 512;
+    } else {
+        use_big = 0;
+        if (splitk == 0 && workspace && small < 128 && K >= 512) {
+            splits = (int)((512 + small - 1) / small);
+            if (splits > K / 128) splits = K / 128;
+        }
     }
+    if (splitk > 1) splits = splitk;
+    if (splitk == 1) splits = 1;
     if (splits > 1) {
-        int kps = cst_div_up(cst_div_up(K, splits), BK) * BK;
+        const int bk = precision_f32 ? 32 : 64;
+        int kps = cst_div_up(cst_div_up(K, splits), bk) * bk;
         splits = cst_div_up(K, kps);
         while (splits > 1 && (long)batch * splits * M * N > workspace_floats) {
-            kps += BK;
+            kps += bk;
             splits = cst_div_up(K, kps);
         }
         g.k_per_split = kps;
     }
-    if (splits <= 1) { splits = 1; g.k_per_split = cst_div_up(K, BK) * BK; }
+    if (splits <= 1) { splits = 1; g.k_per_split = cst_div_up(K, 64) * 64; }
     CST_REQUIRE(splits == 1 || workspace, "cst_gemm: split-K needs a workspace");
     g.splits = splits;
     g.slab = workspace;

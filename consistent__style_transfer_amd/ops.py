@@ -67,7 +67,7 @@ def _f32(t):
 # raw wrappers
 # =============================================================================================
 _WS = {}
-WS_FLOATS = 8 * 1024 * 1024          # 32 MiB split-K slab workspace per device
+WS_FLOATS = 16 * 1024 * 1024         # 64 MiB split-K slab workspace per device
 
 
 def _workspace(dev):
