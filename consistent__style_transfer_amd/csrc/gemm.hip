@@ -97,59 +97,157 @@ __device__ __forceinline__ uint4 pack_slot(const float (&v)[8]) {
 //                   contiguous in HBM, so each of the EPS scalar loads is coalesced across lanes
 //                   (64 lanes x 4 B) and the transpose happens in registers.
 template <int ROWS, bool F32, bool KMAJ>
-struct Stage {
-    static constexpr int EPS = F32 ? 4 : 8;
-    static constexpr int ITEMS = ROWS * 8;
-    static constexpr int PER_T = ITEMS / 256;
-    float v[PER_T][8];
+struct Stage;
+
+// K-major, bf16 image: an item is one float4 (4 consecutive k) -> half a slot (8 bytes).
+// 16 consecutive lanes read one whole 256-byte row of the HBM tile; their 16 ds_write_b64 cover
+// the whole 128-byte LDS row (every bank once).
+template <int ROWS>
+struct Stage<ROWS, false, true> {
+    static constexpr int PER_T = ROWS * 16 / 256;
+    float4 v[PER_T];
     __device__ __forceinline__ void load(const float* __restrict__ P, long ld, int row0, int k0, int rows, int kend, int vec) {
 #pragma unroll
         for (int i = 0; i < PER_T; ++i) {
             const int idx = threadIdx.x + 256 * i;
-            const int r = KMAJ ? idx >> 3 : idx % ROWS;
-            const int slot = KMAJ ? idx & 7 : idx / ROWS;
-            const int k = k0 + slot * EPS;
-            const bool rok = row0 + r < rows;
-            if constexpr (KMAJ) {
+            const int r = idx >> 4, k = k0 + (idx & 15) * 4;
+            float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (row0 + r < rows) {
                 const float* p = P + (long)(row0 + r) * ld + k;
-                if (rok && vec && k + EPS <= kend) {
-                    const float4 a = *reinterpret_cast<const float4*>(p);
-                    v[i][0] = a.x; v[i][1] = a.y; v[i][2] = a.z; v[i][3] = a.w;
-                    if constexpr (!F32) {
-                        const float4 b = *reinterpret_cast<const float4*>(p + 4);
-                        v[i][4] = b.x; v[i][5] = b.y; v[i][6] = b.z; v[i][7] = b.w;
-                    }
-                } else {
-#pragma unroll
-                    for (int e = 0; e < EPS; ++e) v[i][e] = (rok && k + e < kend) ? p[e] : 0.f;
-                }
-            } else {
-                const float* p = P + (long)k * ld + row0 + r;
-#pragma unroll
-                for (int e = 0; e < EPS; ++e) v[i][e] = (rok && k + e < kend) ? p[(long)e * ld] : 0.f;
+                if (k + 0 < kend) t.x = p[0];
+                if (k + 1 < kend) t.y = p[1];
+                if (k + 2 < kend) t.z = p[2];
+                if (k + 3 < kend) t.w = p[3];
             }
+            v[i] = t;
+        }
+    }
+    // full K-tile, 16-byte addressable operand: every load is unconditional (rows past the edge
+    // re-read the last valid row; their products land in output rows that are never stored), so
+    // the compiler issues all of them back to back behind ONE wait -- a guarded load makes hipcc
+    // branch around it and drain vmcnt at every join.
+    __device__ __forceinline__ void load_full(const float* __restrict__ P, long ld, int row0, int k0, int rows) {
+#pragma unroll
+        for (int i = 0; i < PER_T; ++i) {
+            const int idx = threadIdx.x + 256 * i;
+            const int r = min(row0 + (idx >> 4), rows - 1), k = k0 + (idx & 15) * 4;
+            v[i] = *reinterpret_cast<const float4*>(P + (long)r * ld + k);
         }
     }
     __device__ __forceinline__ void store(char* S) const {
 #pragma unroll
         for (int i = 0; i < PER_T; ++i) {
             const int idx = threadIdx.x + 256 * i;
-            const int r = KMAJ ? idx >> 3 : idx % ROWS;
-            const int slot = KMAJ ? idx & 7 : idx / ROWS;
-            *reinterpret_cast<uint4*>(S + lds_off(r, slot)) = pack_slot<F32>(v[i]);
+            const int r = idx >> 4, q = idx & 15;
+            uint2 u;
+            u.x = (uint32_t)f2bf(v[i].x) | ((uint32_t)f2bf(v[i].y) << 16);
+            u.y = (uint32_t)f2bf(v[i].z) | ((uint32_t)f2bf(v[i].w) << 16);
+            *reinterpret_cast<uint2*>(S + lds_off(r, q >> 1) + (q & 1) * 8) = u;
         }
     }
 };
 
-template <int BM, int BN, bool F32, bool A_KMAJ, bool B_KMAJ>
+// K-major, fp32 image: an item is one float4 = one slot; 8 lanes cover a 128-byte row.
+template <int ROWS>
+struct Stage<ROWS, true, true> {
+    static constexpr int PER_T = ROWS * 8 / 256;
+    float4 v[PER_T];
+    __device__ __forceinline__ void load(const float* __restrict__ P, long ld, int row0, int k0, int rows, int kend, int vec) {
+#pragma unroll
+        for (int i = 0; i < PER_T; ++i) {
+            const int idx = threadIdx.x + 256 * i;
+            const int r = idx >> 3, k = k0 + (idx & 7) * 4;
+            float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (row0 + r < rows) {
+                const float* p = P + (long)(row0 + r) * ld + k;
+                if (k + 0 < kend) t.x = p[0];
+                if (k + 1 < kend) t.y = p[1];
+                if (k + 2 < kend) t.z = p[2];
+                if (k + 3 < kend) t.w = p[3];
+            }
+            v[i] = t;
+        }
+    }
+    __device__ __forceinline__ void load_full(const float* __restrict__ P, long ld, int row0, int k0, int rows) {
+#pragma unroll
+        for (int i = 0; i < PER_T; ++i) {
+            const int idx = threadIdx.x + 256 * i;
+            const int r = min(row0 + (idx >> 3), rows - 1), k = k0 + (idx & 7) * 4;
+            v[i] = *reinterpret_cast<const float4*>(P + (long)r * ld + k);
+        }
+    }
+    __device__ __forceinline__ void store(char* S) const {
+#pragma unroll
+        for (int i = 0; i < PER_T; ++i) {
+            const int idx = threadIdx.x + 256 * i;
+            *reinterpret_cast<float4*>(S + lds_off(idx >> 3, idx & 7)) = v[i];
+        }
+    }
+};
+
+// MN-major (either image): an item is one 16-byte slot = EPS consecutive k of one row; for a
+// fixed k the rows are contiguous in HBM, so each of the EPS scalar loads is coalesced across the
+// 64 lanes (256 bytes) and the transpose happens in registers; 8 consecutive lanes (rows) then
+// write 8 distinct physical slots.
+template <int ROWS, bool F32>
+struct Stage<ROWS, F32, false> {
+    static constexpr int EPS = F32 ? 4 : 8;
+    static constexpr int PER_T = ROWS * 8 / 256;
+    float v[PER_T][8];
+    __device__ __forceinline__ void load(const float* __restrict__ P, long ld, int row0, int k0, int rows, int kend, int vec) {
+#pragma unroll
+        for (int i = 0; i < PER_T; ++i) {
+            const int idx = threadIdx.x + 256 * i;
+            const int r = idx % ROWS, k = k0 + (idx / ROWS) * EPS;
+            const bool rok = row0 + r < rows;
+            const float* p = P + (long)k * ld + row0 + r;
+#pragma unroll
+            for (int e = 0; e < EPS; ++e) v[i][e] = (rok && k + e < kend) ? p[(long)e * ld] : 0.f;
+        }
+    }
+    __device__ __forceinline__ void load_full(const float* __restrict__ P, long ld, int row0, int k0, int rows) {
+#pragma unroll
+        for (int i = 0; i < PER_T; ++i) {
+            const int idx = threadIdx.x + 256 * i;
+            const int r = min(row0 + idx % ROWS, rows - 1), k = k0 + (idx / ROWS) * EPS;
+            const float* p = P + (long)k * ld + r;
+#pragma unroll
+            for (int e = 0; e < EPS; ++e) v[i][e] = p[(long)e * ld];
+        }
+    }
+    __device__ __forceinline__ void store(char* S) const {
+#pragma unroll
+        for (int i = 0; i < PER_T; ++i) {
+            const int idx = threadIdx.x + 256 * i;
+            *reinterpret_cast<uint4*>(S + lds_off(idx % ROWS, idx / ROWS)) = pack_slot<F32>(v[i]);
+        }
+    }
+};
+
+// NBUF = 2: double-buffered LDS, one barrier per K-tile (fewer, longer-lived workgroups);
+// NBUF = 1: single buffer, two barriers per K-tile, half the LDS -> more workgroups per CU
+// (thread-level parallelism hides the HBM/L2 latency of the register-staged loads).
+template <int BM, int BN, bool F32, bool A_KMAJ, bool B_KMAJ, int NBUF>
 __global__ __launch_bounds__(256) void cst_gemm_kernel(GemmArgs g) {
     constexpr int BK = TileCfg<F32>::BK;
     constexpr int TM = BM / 32, TN = BN / 32;      // 16x16 tiles per wave in each direction
     constexpr int A_BYTES = BM * ROW_BYTES, B_BYTES = BN * ROW_BYTES;
-    __shared__ __attribute__((aligned(16))) char smem[2 * (A_BYTES + B_BYTES)];
+    __shared__ __attribute__((aligned(16))) char smem[NBUF * (A_BYTES + B_BYTES)];
 
-    const int tilesM = (g.M + BM - 1) / BM;
-    const int tm = blockIdx.x % tilesM, tn = blockIdx.x / tilesM;
+    // block -> tile.  Blocks are dealt round-robin over the 8 XCDs (speed only, never correctness):
+    // give each XCD one contiguous run of tile ids, and order ids so that 4 consecutive ones share
+    // an A row-panel while cycling through 4 B column-panels -- both stay resident in that XCD's L2.
+    const int tilesM = (g.M + BM - 1) / BM, tilesN = (g.N + BN - 1) / BN;
+    int id;
+    {
+        const int nblk = gridDim.x, q = nblk >> 3, r = nblk & 7, xcd = blockIdx.x & 7;
+        id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (blockIdx.x >> 3);
+    }
+    constexpr int GN = 4;
+    const int grp = id / (GN * tilesM);
+    const int gw = min(GN, tilesN - grp * GN);
+    const int local = id - grp * GN * tilesM;
+    const int tm = local / gw, tn = grp * GN + local % gw;
     const int m0 = tm * BM, n0 = tn * BN;
     const long bz = blockIdx.z;
     const float* A = g.A + bz * g.sA;
@@ -170,19 +268,23 @@ __global__ __launch_bounds__(256) void cst_gemm_kernel(GemmArgs g) {
     const int kbeg = blockIdx.y * g.k_per_split;
     const int kend = min(g.K, kbeg + g.k_per_split);
     const int nk = (kend - kbeg + BK - 1) / BK;
-    sa.load(A, g.lda, m0, kbeg, g.M, kend, g.vecA);
-    sb.load(B, g.ldb, n0, kbeg, g.N, kend, g.vecB);
+    // wave-uniform choice per K-tile: the branch-free loader needs a full tile (and 16-byte
+    // addressable rows for K-major operands); only the K tail takes the guarded loader
+    const bool fastA = A_KMAJ ? g.vecA : true, fastB = B_KMAJ ? g.vecB : true;
+    auto load_tiles = [&](int k0) {
+        const bool full = k0 + BK <= kend;
+        if (full && fastA) sa.load_full(A, g.lda, m0, k0, g.M); else sa.load(A, g.lda, m0, k0, g.M, kend, g.vecA);
+        if (full && fastB) sb.load_full(B, g.ldb, n0, k0, g.N); else sb.load(B, g.ldb, n0, k0, g.N, kend, g.vecB);
+    };
+    load_tiles(kbeg);
     sa.store(smem);
     sb.store(smem + A_BYTES);
     __syncthreads();
 
     for (int kt = 0; kt < nk; ++kt) {
-        const char* As = smem + (kt & 1) * (A_BYTES + B_BYTES);
+        const char* As = smem + (NBUF == 2 ? (kt & 1) : 0) * (A_BYTES + B_BYTES);
         const char* Bs = As + A_BYTES;
-        if (kt + 1 < nk) {                     // next tile: HBM -> registers while this one is multiplied
-            sa.load(A, g.lda, m0, kbeg + (kt + 1) * BK, g.M, kend, g.vecA);
-            sb.load(B, g.ldb, n0, kbeg + (kt + 1) * BK, g.N, kend, g.vecB);
-        }
+        if (kt + 1 < nk) load_tiles(kbeg + (kt + 1) * BK);   // next tile: HBM -> registers while this one is multiplied
         // two k-steps per tile; fragment slot of lane group lq in step kk is kk*4 + lq
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
@@ -208,8 +310,9 @@ __global__ __launch_bounds__(256) void cst_gemm_kernel(GemmArgs g) {
                     }
                 }
         }
-        if (kt + 1 < nk) {                     // the other buffer was last read before the previous barrier
-            char* An = smem + ((kt + 1) & 1) * (A_BYTES + B_BYTES);
+        if constexpr (NBUF == 1) __syncthreads();      // everyone is done reading the only buffer
+        if (kt + 1 < nk) {                     // NBUF == 2: the other buffer was last read before the previous barrier
+            char* An = smem + (NBUF == 2 ? ((kt + 1) & 1) : 0) * (A_BYTES + B_BYTES);
             sa.store(An);
             sb.store(An + A_BYTES);
         }
@@ -238,17 +341,48 @@ __global__ __launch_bounds__(256) void cst_gemm_kernel(GemmArgs g) {
     const float* addend = g.addend ? g.addend + bz * g.sAdd : nullptr;
     const float* aux = g.aux ? g.aux + bz * g.sAux : nullptr;
     const uint32_t dseed = g.drop.p > 0.f ? cst_drop_seed(g.drop) : 0u;
+    // Stage this wave's (BM/2)x(BN/2) accumulator block through LDS (the K-loop's last barrier has
+    // retired every tile read) so that each global store instruction writes whole 256-byte row
+    // segments instead of 64-byte pieces of four different rows.
+    constexpr int WM = BM / 2, WN = BN / 2, CLD = WN;     // 2-way ds_write_b32 conflicts are free
+    constexpr int PASSES = 2 / NBUF;                       // single-buffer builds stage half the rows at a time
+    constexpr int PR = WM / PASSES;                        // rows of the wave block per pass
+    static_assert(4 * PR * CLD * 4 <= NBUF * (A_BYTES + B_BYTES), "C staging must fit the tile buffers");
+    float* Cs = reinterpret_cast<float*>(smem) + wave * PR * CLD;
+    constexpr int C4 = WN / 4;                             // float4 chunks per row of the wave block
+    const bool cvec = (g.ldc % 4 == 0) && ((reinterpret_cast<uintptr_t>(C) & 15) == 0) && !g.accumulate;
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
+    for (int ps = 0; ps < PASSES; ++ps) {
+        if (ps > 0) __builtin_amdgcn_wave_barrier();
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int n = n0 + wn * (BN / 2) + j * 16 + lr;
-            if (n >= g.N) continue;
+        for (int i = 0; i < TM / PASSES; ++i)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int m = m0 + wm * (BM / 2) + i * 16 + lq * 4 + r;
-                if (m >= g.M) continue;
-                gemm_epilogue_store(g, C, bias, addend, aux, dseed, bz, m, n, acc[i][j][r]);
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) Cs[(i * 16 + lq * 4 + r) * CLD + j * 16 + lr] = acc[ps * (TM / PASSES) + i][j][r];
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int it = 0; it < PR * C4 / 64; ++it) {
+            const int idx = lane + 64 * it;
+            const int rr = idx / C4, cc = (idx % C4) * 4;
+            const int m = m0 + wm * WM + ps * PR + rr, n = n0 + wn * WN + cc;
+            if (m >= g.M || n >= g.N) continue;
+            const float4 a4 = *reinterpret_cast<const float4*>(&Cs[rr * CLD + cc]);
+            const float av[4] = {a4.x, a4.y, a4.z, a4.w};
+            if (cvec && n + 3 < g.N && !addend && !aux && g.drop.p <= 0.f) {
+                float o[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float v = g.alpha * av[e] + (bias ? bias[n + e] : 0.f);
+                    if (g.act == 1) v = v > 0.f ? v : 0.f;
+                    else if (g.act == 2) v = v > 0.f ? v : 0.1f * v;
+                    o[e] = v;
+                }
+                *reinterpret_cast<float4*>(C + (long)m * g.ldc + n) = make_float4(o[0], o[1], o[2], o[3]);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (n + e < g.N) gemm_epilogue_store(g, C, bias, addend, aux, dseed, bz, m, n + e, av[e]);
             }
         }
     }
@@ -271,12 +405,12 @@ __global__ __launch_bounds__(256) void cst_gemm_splitk_reduce(GemmArgs g) {
     }
 }
 
-template <int BM, int BN>
+template <int BM, int BN, int NBUF>
 static void launch_cfg(const GemmArgs& g, int f32, int akm, int bkm, int batch, hipStream_t st) {
     dim3 grid(cst_div_up(g.M, BM) * cst_div_up(g.N, BN), g.splits, batch), block(256);
 #define CST_GEMM_CASE(F, AK, BKM)                                                              \
     if (f32 == F && akm == AK && bkm == BKM) {                                                 \
-        hipLaunchKernelGGL((cst_gemm_kernel<BM, BN, (bool)F, (bool)AK, (bool)BKM>), grid, block, 0, st, g); \
+        hipLaunchKernelGGL((cst_gemm_kernel<BM, BN, (bool)F, (bool)AK, (bool)BKM, NBUF>), grid, block, 0, st, g); \
         return;                                                                                \
     }
     CST_GEMM_CASE(0, 1, 1) CST_GEMM_CASE(0, 1, 0) CST_GEMM_CASE(0, 0, 1) CST_GEMM_CASE(0, 0, 0)
@@ -319,6 +453,8 @@ extern "C" int cst_gemm(const float* A, long lda, int a_kmajor, const float* B, 
     const long big = (long)cst_div_up(M, 128) * cst_div_up(N, 128) * batch;
     const long small = (long)cst_div_up(M, 64) * cst_div_up(N, 64) * batch;
     int use_big, splits = 1;
+    const int nbuf2 = tile & 1;                 // odd tile codes (65, 129) pick the double-buffered build
+    tile &= ~1;
     if (tile == 128 || (tile == 0 && big >= 192)) { use_big = 1; }
     else if (tile == 0 && K >= 2048 && big >= 16 && workspace && splitk == 0) {
         use_big = 1;
@@ -348,8 +484,11 @@ extern "C" int cst_gemm(const float* A, long lda, int a_kmajor, const float* B, 
     g.splits = splits;
     g.slab = workspace;
     hipStream_t st = (hipStream_t)stream;
-    if (use_big) launch_cfg<128, 128>(g, precision_f32 ? 1 : 0, a_kmajor ? 1 : 0, b_kmajor ? 1 : 0, batch, st);
-    else launch_cfg<64, 64>(g, precision_f32 ? 1 : 0, a_kmajor ? 1 : 0, b_kmajor ? 1 : 0, batch, st);
+    const int pf = precision_f32 ? 1 : 0, ak = a_kmajor ? 1 : 0, bk_ = b_kmajor ? 1 : 0;
+    if (use_big && nbuf2) launch_cfg<128, 128, 2>(g, pf, ak, bk_, batch, st);
+    else if (use_big) launch_cfg<128, 128, 1>(g, pf, ak, bk_, batch, st);
+    else if (nbuf2) launch_cfg<64, 64, 2>(g, pf, ak, bk_, batch, st);
+    else launch_cfg<64, 64, 1>(g, pf, ak, bk_, batch, st);
     CST_LAUNCH_CHECK("cst_gemm");
     if (splits > 1) {
         long mn = (long)M * N;

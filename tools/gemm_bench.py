@@ -1,0 +1,56 @@
+#!/usr/bin/env python3
+"""Micro-benchmark of cst_gemm on the shapes the training step uses (GPU box only).
+Times each shape with HIP events over many back-to-back launches (launch overhead amortised)."""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from consistent__style_transfer_amd import ops
+
+SHAPES = [  # (M, N, K, a_kmajor, b_kmajor, note)
+    (9216, 2048, 512, 1, 1, "FFN1 fwd (Matcher)"), (9216, 512, 2048, 1, 1, "FFN2 fwd"), (9216, 1536, 512, 1, 1, "QKV fwd"),
+    (9216, 512, 2048, 1, 0, "FFN1 dgrad"), (9216, 2048, 512, 1, 0, "FFN2 dgrad"),
+    (2048, 512, 9216, 0, 0, "FFN1 wgrad"), (512, 2048, 9216, 0, 0, "FFN2 wgrad"),
+    (4608, 10000, 512, 1, 1, "vocab fwd"), (4608, 512, 10000, 1, 0, "vocab dgrad"), (10000, 512, 4608, 0, 0, "vocab wgrad"),
+    (256, 2048, 640, 1, 1, "dec gates"), (256, 1024, 256, 1, 1, "enc gates"), (256, 10000, 512, 1, 1, "fn_2 step"),
+    (256, 512, 1024, 1, 1, "fn_1 step"), (256, 640, 2048, 1, 0, "dec dXH"), (256, 256, 1024, 1, 0, "enc dh"),
+    (256, 512, 10000, 1, 0, "fn_2 dgrad step"), (4096, 1200, 1200, 1, 1, "highway"), (69632, 300, 16, 1, 1, "disc conv"),
+]
+
+
+TILES = [0, 64, 65, 128, 129]        # auto, 64 single/double buffered, 128 single/double buffered
+
+
+def main():
+    prec = sys.argv[1] if len(sys.argv) > 1 else "bf16"
+    ops.set_precision(prec)
+    for M, N, K, akm, bkm, note in SHAPES:
+        A = torch.randn((M, K) if akm else (K, M), device="cuda")
+        B = torch.randn((N, K) if bkm else (K, N), device="cuda")
+        C = torch.empty(M, N, device="cuda")
+        res = []
+        for tile in TILES:
+            for _ in range(3):
+                ops.gemm(A, akm, B, bkm, C, M, N, K, tile=tile)
+            torch.cuda.synchronize()
+            n = 20
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                for _ in range(n):
+                    ops.gemm(A, akm, B, bkm, C, M, N, K, tile=tile)
+            g.replay()
+            torch.cuda.synchronize()
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            g.replay()
+            b.record()
+            torch.cuda.synchronize()
+            res.append(a.elapsed_time(b) * 1000 / n)
+        fl = 2.0 * M * N * K
+        by = 4.0 * (M * K + N * K + M * N)
+        best = min(res)
+        print(f"{note:18s} {M:6d}x{N:5d}x{K:5d} a{akm}b{bkm}  " + "  ".join(f"t{t}:{u:7.1f}us" for t, u in zip(TILES, res))
+              + f"   best {fl / best / 1e6:7.1f} TF/s  {by / best / 1e6:5.2f} TB/s(min-traffic)")
+
+
+if __name__ == "__main__":
+    main()
