@@ -395,7 +395,48 @@ def curve_goldens(name, c, steps):
     return out
 
 
+def host_goldens():
+    """Host-side batch construction (src/data_util.py, src/vocab.py) under fixed seeds, on a sample
+    of the Yelp dev sentences that ships as a data fixture (tests/golden/yelp_dev_sample.{0,1})."""
+    import json
+    np.float = float                       # data_util.py:44 uses the alias numpy 2 removed
+    import data_util as ref_du
+    import vocab as ref_vocab
+    out = {}
+    # data sample: first 150 non-empty lines of each dev file (data, not source)
+    paths = []
+    for lab in (0, 1):
+        with open(f"/root/reference/data/yelp/style.dev.{lab}", encoding="utf-8") as f:
+            lines = [l.strip() for l in f if l.strip()][:150]
+        pth = os.path.join(HERE, f"yelp_dev_sample.{lab}")
+        with open(pth, "w", encoding="utf-8") as f:
+            f.write("\n".join(lines) + "\n")
+        paths.append(pth)
+    tk = ref_vocab.BPETokenizer(paths, 600)
+    tk.tokenizer.save_model(HERE, "yelp_sample")          # the reference's save() predates tokenizers 0.22
+    tk2 = ref_vocab.BPETokenizer.load(os.path.join(HERE, "yelp_sample-vocab.json"), os.path.join(HERE, "yelp_sample-merges.txt"))
+    sents = [l.strip() for l in open(paths[0], encoding="utf-8")][:40]
+    enc = [tk2.encode(s)[:18] for s in sents]
+    out["vocab"] = {"len": len(tk2), "encode": enc, "decode": [tk2.decode(e) for e in enc[:10]],
+                    "special": tk2.tokens_to_ids(["<pad>", "<s>", "</s>", "<unk>"])}
+    # data_util under fixed seeds
+    sentences = [list(e) for e in enc[:16]]
+    al, lens, ml = ref_du.align(sentences, 0)
+    out["align"] = {"out": al, "lens": lens, "max_len": ml}
+    np.random.seed(11); random.seed(12)
+    out["transfer_noise"] = [[int(t) for t in s] for s in ref_du.transfer_noise(sentences, p=0.15)]
+    np.random.seed(21); random.seed(22)
+    out["rand_perm"] = [[int(t) for t in s] for s in ref_du.rand_perm(sentences, p=0.15)]
+    np.random.seed(31); random.seed(32)
+    out["transfer_noise_p1"] = [[int(t) for t in s] for s in ref_du.transfer_noise(sentences, p=0.1)]
+    out["sentences"] = sentences
+    with open(os.path.join(HERE, "host.json"), "w") as f:
+        json.dump(out, f)
+    return out
+
+
 def main():
+    host_goldens()
     for name, c in CONFIGS.items():
         mg = module_goldens(name, c)
         # keep fixtures small: big gradient arrays are replaced by their L2 norm and a
