@@ -32,8 +32,8 @@ class GraphedStep:
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):
-            for _ in range(warmup):
-                self._body()
+            for _ in range(max(1, warmup)):       # at least one eager pass (allocator + lazy init); it is a real step
+                self.first_out = self._body()
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()

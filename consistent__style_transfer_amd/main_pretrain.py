@@ -1,0 +1,83 @@
+"""Stage 1 -- critic pre-training (reference: src/main_pretrain.py).
+
+    python -m consistent__style_transfer_amd.main_pretrain --dataset=yelp --ver=0
+
+Jointly trains the TextCNN style classifier (CE), the Matcher (MSE against the content-distance
+label) and the MLM denoiser (token CE) with one Adam(lr 1e-4), gradient clip 5.0; a model whose
+validation loss got worse is frozen from then on (main_pretrain.py:92-114); weights go to
+`<dump_dir>/<dataset>/pretrain/{cls,mat,dn}.pth`.  Existing checkpoints at that path are loaded
+first (the reference's unconditional load from `pretraincls.pth` is a path bug).
+"""
+import os
+
+import torch
+
+from . import ops
+from .arguments import apply_model_constants, fetch_args
+from .loader import StyleDataset, collate_pretrain, load_s2l
+from .stages import PretrainStage
+from .trainer import StepCache, Trainer
+from .vocab import BPETokenizer
+
+STAGE = "pretrain"
+
+
+class PretrainAdapter(PretrainStage):
+    def __init__(self, args, vocab):
+        super().__init__(len(vocab), args.n_class)
+        self.hparams = args
+        self.vocab = vocab
+        for name, m in self.named_models.items():
+            path = f"{args.task_dump_dir}/{name}.pth"
+            if os.path.exists(path):
+                m.load_state_dict(torch.load(path, map_location="cpu"))
+
+    def train_batch(self, trainer, batch, batch_idx):
+        key = tuple(sorted(k for k, v in self.flags.items() if v))
+        out = self._steps.run(key, lambda *b: self.train_step(b, reducer=trainer.reducer), list(batch))
+        return {k: out[k] for k in ("s_loss", "c_loss", "dn_loss")}
+
+    def validation_step(self, trainer, batch):
+        s, c, dn = self.losses(batch)
+        return tuple(0.0 if t is None else float(t.item()) for t in (s, c, dn))
+
+    def validation_end(self, trainer, outputs):
+        means = [trainer.mean_over_ranks(sum(o[i] for o in outputs) / len(outputs)) for i in range(3)]
+        for name, loss in zip(("cls", "mat", "dn"), means):
+            if self.flags[name]:
+                if self.best_eval[name] < loss:
+                    self.flags[name] = False
+                else:
+                    self.best_eval[name] = loss
+                    if trainer.rank == 0:
+                        torch.save(self.named_models[name].state_dict(), f"{self.hparams.task_dump_dir}/{name}.pth")
+        val_loss = sum(self.best_eval.values())
+        if trainer.rank == 0:
+            print(f"CLS: {self.flags['cls']}-{self.best_eval['cls']}\nMAT: {self.flags['mat']}-{self.best_eval['mat']}\n"
+                  f"DN: {self.flags['dn']}-{self.best_eval['dn']}\nval_loss: {val_loss}", flush=True)
+        return val_loss
+
+
+def main(argv=None, label_fn=None):
+    args = fetch_args(argv)
+    apply_model_constants(args)
+    ops.set_precision(args.precision)
+    os.makedirs(f"{args.dump_dir}/{args.dataset}/{STAGE}", exist_ok=True)
+    args.task_dump_dir = f"{args.dump_dir}/{args.dataset}/{STAGE}"
+    args.log_dir = f"{args.log_dir}/{args.dataset}"
+    vocab = BPETokenizer.load(f"{args.dump_dir}/{args.dataset}/{args.dataset}-vocab.json",
+                              f"{args.dump_dir}/{args.dataset}/{args.dataset}-merges.txt")
+    trainer = Trainer(args, patience=1, log_name=STAGE)
+    stage = PretrainAdapter(args, vocab).to(trainer.device)
+    stage.train()
+    stage.setup_optim()
+    stage._steps = StepCache(trainer.use_graph, [stage])
+    data_dir = f"{args.data_dir}/{args.dataset}"
+    train_ds = StyleDataset([f"{data_dir}/style.train.0", f"{data_dir}/style.train.1"], vocab, args.max_len, load_s2l)
+    val_ds = StyleDataset([f"{data_dir}/style.dev.0", f"{data_dir}/style.dev.1"], vocab, args.max_len, load_s2l)
+    trainer.fit(stage, train_ds, val_ds, collate_pretrain(vocab, label_fn=label_fn), args.batch_size)
+    return stage
+
+
+if __name__ == "__main__":
+    main()

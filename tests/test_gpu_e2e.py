@@ -1,0 +1,75 @@
+"""GPU end to end: the three stage scripts behind the reference's CLI on a small corpus (the Yelp
+dev sample fixture): pretrain -> warmup -> optimize (train) -> optimize (test), checkpoints under the
+reference's file names, state_dict keys loadable across stages, .tsf writers, hipGraph and eager."""
+import json
+import os
+import shutil
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _small_constants():
+    from consistent__style_transfer_amd.model import classifier, discriminator, rnn
+    rnn.d_embed, rnn.d_enc, rnn.d_dec = 32, 32, 64
+    classifier.d_embed, classifier.kernel_number = 32, [16, 16, 16]
+    discriminator.embed_dim, discriminator.num_rep, discriminator.dis_num_filters = 32, 4, [12, 12, 12, 12]
+
+
+def _restore_constants():
+    from consistent__style_transfer_amd.model import classifier, discriminator, match, mlm, rnn
+    rnn.d_embed, rnn.d_enc, rnn.d_dec = 128, 256, 512
+    classifier.d_embed, classifier.kernel_number = 128, [128, 128, 128]
+    discriminator.embed_dim, discriminator.num_rep, discriminator.dis_num_filters = 128, 16, [300, 300, 300, 300]
+    mlm.d_model = match.d_model = 512
+    mlm.n_head = match.n_head = 8
+    mlm.n_layer = match.n_layer = 6
+
+
+@pytest.mark.parametrize("graph", [True, False])
+def test_three_stages_cli(tmp_path, graph):
+    from consistent__style_transfer_amd import main_optimize, main_pretrain, main_warmup
+    root = tmp_path
+    data, dump = root / "data" / "yelp", root / "dump" / "yelp"
+    os.makedirs(data)
+    os.makedirs(dump)
+    for lab in (0, 1):
+        src = os.path.join(G, f"yelp_dev_sample.{lab}")
+        for split in ("train", "dev", "test"):
+            shutil.copy(src, data / f"style.{split}.{lab}")
+    shutil.copy(os.path.join(G, "yelp_sample-vocab.json"), dump / "yelp-vocab.json")
+    shutil.copy(os.path.join(G, "yelp_sample-merges.txt"), dump / "yelp-merges.txt")
+    common = ["--dataset", "yelp", "--data_dir", str(root / "data"), "--dump_dir", str(root / "dump"),
+              "--log_dir", str(root / "log"), "--out_dir", str(root / "output"), "--n_layer", "1", "--d_model", "64",
+              "--n_head", "4", "--batch_size", "32", "--max_steps", "6", "--val_batches", "2", "--epochs", "1"]
+    if not graph:
+        common.append("--no_graph")
+    _small_constants()
+    try:
+        pre = main_pretrain.main(common + ["--ver", "0"])
+        for name in ("cls", "mat", "dn"):
+            assert os.path.exists(dump / "pretrain" / f"{name}.pth")
+        assert all(torch.isfinite(p).all() for p in pre.parameters())
+        wu = main_warmup.main(common + ["--ver", "0"])
+        assert os.path.exists(dump / "warmup" / "G.pth")
+        assert wu.best_eval < 10.0
+        opt = main_optimize.main(common + ["--ver", "v0"])
+        saved = os.listdir(dump / "optimize-v0")
+        assert len(saved) == 1 and saved[0].startswith("G_epoch_")
+        assert all(torch.isfinite(p).all() for p in opt.generator.parameters())
+        main_optimize.main(common + ["--ver", "v0", "--mode", "test"])
+        for split in ("train", "test"):
+            for lab in (0, 1):
+                lines = open(root / "output" / "yelp-v0" / f"style.{split}.{lab}.tsf", encoding="utf-8").read().split("\n")
+                assert len(lines) - 1 == 150
+        # scalar stream with the reference's names
+        log = root / "log" / "yelp" / "optimize-v0"
+        ver = sorted(os.listdir(log))[0]
+        rows = [json.loads(l) for l in open(log / ver / "metrics.jsonl")]
+        assert any("val_loss" in r for r in rows)
+        assert os.path.exists(log / ver / "meta_tags.csv")
+    finally:
+        _restore_constants()
