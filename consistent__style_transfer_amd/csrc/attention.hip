@@ -107,10 +107,11 @@ extern "C" int cst_mha_fwd(const float* qkv, float* out, float* lse, int B, int 
     hipStream_t st = (hipStream_t)stream;
     switch (hd) {
         case 8: hipLaunchKernelGGL((mha_fwd_kernel<8>), grid, block, 0, st, qkv, out, lse, S, H, scale, dr); break;
+        case 16: hipLaunchKernelGGL((mha_fwd_kernel<16>), grid, block, 0, st, qkv, out, lse, S, H, scale, dr); break;
         case 32: hipLaunchKernelGGL((mha_fwd_kernel<32>), grid, block, 0, st, qkv, out, lse, S, H, scale, dr); break;
         case 64: hipLaunchKernelGGL((mha_fwd_kernel<64>), grid, block, 0, st, qkv, out, lse, S, H, scale, dr); break;
         case 96: hipLaunchKernelGGL((mha_fwd_kernel<96>), grid, block, 0, st, qkv, out, lse, S, H, scale, dr); break;
-        default: cst_set_error("cst_mha_fwd: head dim %d unsupported (8, 32, 64, 96)", hd); return CST_ERR_ARG;
+        default: cst_set_error("cst_mha_fwd: head dim %d unsupported (8, 16, 32, 64, 96)", hd); return CST_ERR_ARG;
     }
     CST_LAUNCH_CHECK("cst_mha_fwd");
     return CST_OK;
@@ -213,8 +214,8 @@ extern "C" int cst_mha_bwd(const float* qkv, const float* dout, const float* lse
         break;                                                                                                    \
     }
     switch (hd) {
-        MHA_BWD_CASE(8) MHA_BWD_CASE(32) MHA_BWD_CASE(64) MHA_BWD_CASE(96)
-        default: cst_set_error("cst_mha_bwd: head dim %d unsupported (8, 32, 64, 96)", hd); return CST_ERR_ARG;
+        MHA_BWD_CASE(8) MHA_BWD_CASE(16) MHA_BWD_CASE(32) MHA_BWD_CASE(64) MHA_BWD_CASE(96)
+        default: cst_set_error("cst_mha_bwd: head dim %d unsupported (8, 16, 32, 64, 96)", hd); return CST_ERR_ARG;
     }
 #undef MHA_BWD_CASE
     CST_LAUNCH_CHECK("cst_mha_bwd");

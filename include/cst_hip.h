@@ -88,7 +88,7 @@ int cst_colsum(const float* X, long ld, int M, int N, float* out, int accumulate
 int cst_reduce_sum(const float* in, long n, float scale, float* out, int accumulate, void* stream);
 
 /* Unmasked multi-head self-attention core, qkv [B,S,3d] -> out [B,S,d], lse [B,H,S]; S <= 64,
- * head dim in {8,32,64,96}; attention dropout on the probabilities (index ((b*H+h)*S+i)*S+j).
+ * head dim in {8,16,32,64,96}; attention dropout on the probabilities (index ((b*H+h)*S+i)*S+j).
  * nn.MultiheadAttention inside nn.TransformerEncoderLayer (mlm.py:20-22,43; match.py:18-20,39). */
 int cst_mha_fwd(const float* qkv, float* out, float* lse, int B, int S, int H, int hd,
                 float drop_p, uint32_t drop_seed, uint32_t drop_stream, const void* drop_seed_dev, void* stream);
