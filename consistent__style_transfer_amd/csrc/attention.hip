@@ -224,17 +224,29 @@ extern "C" int cst_mha_bwd(const float* qkv, const float* dout, const float* lse
 
 // ---------------------------------------------------------------------------------------------
 // Single-query attention, forward.  q [B, ldq] (D used), mem [B,L,D], out [B, ldo], p [B,L].
+// The batch row's memory tile (L x D fp32, <= 64 x 512 -> 128 KiB) is pulled into LDS with every
+// load in flight at once (one HBM/L2 round trip), then scores, softmax and the weighted sum run
+// from LDS.  Optionally also writes the dropped copy [q | out] * mask of the decoder's i_ffn
+// (rnn.py:78-79) so the step needs no separate dropout launch.
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void dot_attn_fwd_kernel(const float* __restrict__ q, long ldq,
                                                            const float* __restrict__ mem, float* __restrict__ out, long ldo,
-                                                           float* __restrict__ p, int L, int D, float scale) {
-    __shared__ float sc[MHA_SMAX];
+                                                           float* __restrict__ p, int L, int D, float scale,
+                                                           float* __restrict__ dropped, long lddrop, CstDrop drop) {
+    extern __shared__ __attribute__((aligned(16))) float dsm[];
+    float* ms = dsm;                 // [L][D]
+    float* qs = ms + L * D;          // [D]
+    float* sc = qs + D;              // [64]
     const int b = blockIdx.x, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const float* qb = q + (long)b * ldq;
-    const float* mb = mem + (long)b * L * D;
+    const float4* mb4 = reinterpret_cast<const float4*>(mem + (long)b * L * D);
+    const int n4 = L * D / 4;
+    for (int e = threadIdx.x; e < n4; e += 256) reinterpret_cast<float4*>(ms)[e] = mb4[e];
+    for (int c = threadIdx.x; c < D; c += 256) qs[c] = qb[c];
+    __syncthreads();
     for (int j = w; j < L; j += 4) {
         float s = 0.f;
-        for (int c = lane; c < D; c += 64) s += qb[c] * mb[(long)j * D + c];
+        for (int c = lane; c < D; c += 64) s += qs[c] * ms[j * D + c];
         s = wave_sum(s);
         if (lane == 0) sc[j] = s * scale;
     }
@@ -250,19 +262,34 @@ __global__ __launch_bounds__(256) void dot_attn_fwd_kernel(const float* __restri
         p[(long)b * L + threadIdx.x] = pj;
     }
     __syncthreads();
+    const uint32_t dseed = drop.p > 0.f ? cst_drop_seed(drop) : 0u;
     for (int c = threadIdx.x; c < D; c += 256) {
         float o = 0.f;
-        for (int j = 0; j < L; ++j) o += sc[j] * mb[(long)j * D + c];
+        for (int j = 0; j < L; ++j) o += sc[j] * ms[j * D + c];
         out[(long)b * ldo + c] = o;
+        if (dropped) {
+            // dropout index space is the (B, 2D) matrix [q | out]
+            float* dr = dropped + (long)b * lddrop;
+            const float mq = drop.p > 0.f ? cst_drop_mask(drop, dseed, (uint32_t)((long)b * 2 * D + c)) : 1.f;
+            const float mo = drop.p > 0.f ? cst_drop_mask(drop, dseed, (uint32_t)((long)b * 2 * D + D + c)) : 1.f;
+            dr[c] = qs[c] * mq;
+            dr[D + c] = o * mo;
+        }
     }
 }
 
 extern "C" int cst_dot_attn_fwd(const float* q, long ldq, const float* mem, float* out, long ldo, float* p,
-                                int B, int L, int D, void* stream) {
+                                int B, int L, int D, float* dropped, long lddrop,
+                                float drop_p, uint32_t drop_seed, uint32_t drop_stream, const void* drop_seed_dev,
+                                void* stream) {
     CST_REQUIRE(q && mem && out && p, "cst_dot_attn_fwd: null pointer");
-    CST_REQUIRE(B > 0 && L > 0 && L <= MHA_SMAX && D > 0, "cst_dot_attn_fwd: L=%d unsupported (max %d)", L, MHA_SMAX);
-    hipLaunchKernelGGL(dot_attn_fwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, q, ldq, mem, out, ldo, p, L, D,
-                       1.0f / sqrtf((float)D));
+    CST_REQUIRE(B > 0 && L > 0 && L <= MHA_SMAX && D > 0 && D % 4 == 0, "cst_dot_attn_fwd: L=%d (max %d) or D=%d unsupported", L, MHA_SMAX, D);
+    const size_t lds = sizeof(float) * ((size_t)L * D + D + 64);
+    CST_REQUIRE(lds <= 160 * 1024, "cst_dot_attn_fwd: memory tile of %zu bytes exceeds the 160 KiB LDS", lds);
+    CstDrop dr = cst_make_drop(drop_p, drop_seed, drop_stream, drop_seed_dev);
+    if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)dot_attn_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(dot_attn_fwd_kernel, dim3(B), dim3(256), lds, (hipStream_t)stream, q, ldq, mem, out, ldo, p, L, D,
+                       1.0f / sqrtf((float)D), dropped, lddrop, dr);
     CST_LAUNCH_CHECK("cst_dot_attn_fwd");
     return CST_OK;
 }
@@ -273,19 +300,26 @@ __global__ __launch_bounds__(256) void dot_attn_bwd_kernel(const float* __restri
                                                            const float* __restrict__ mem, const float* __restrict__ p,
                                                            float* __restrict__ dq, long lddq, int dq_accumulate,
                                                            float* __restrict__ dmem, int L, int D, float scale) {
-    __shared__ float ds[MHA_SMAX];
-    __shared__ float ps[MHA_SMAX];
+    extern __shared__ __attribute__((aligned(16))) float dsm[];
+    float* ms = dsm;                 // [L][D]
+    float* gs = ms + L * D;          // [D] dout row
+    float* ds = gs + D;              // [64]
+    float* ps = ds + 64;             // [64]
     const int b = blockIdx.x, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const float* gb = dout + (long)b * lddo;
     const float* qb = q + (long)b * ldq;
-    const float* mb = mem + (long)b * L * D;
+    const float4* mb4 = reinterpret_cast<const float4*>(mem + (long)b * L * D);
+    const int n4 = L * D / 4;
+    for (int e = threadIdx.x; e < n4; e += 256) reinterpret_cast<float4*>(ms)[e] = mb4[e];
+    for (int c = threadIdx.x; c < D; c += 256) gs[c] = gb[c];
+    if (threadIdx.x < L) ps[threadIdx.x] = p[(long)b * L + threadIdx.x];
+    __syncthreads();
     for (int j = w; j < L; j += 4) {
         float s = 0.f;
-        for (int c = lane; c < D; c += 64) s += gb[c] * mb[(long)j * D + c];
+        for (int c = lane; c < D; c += 64) s += gs[c] * ms[j * D + c];
         s = wave_sum(s);
         if (lane == 0) ds[j] = s;          // dp_j
     }
-    if (threadIdx.x < L) ps[threadIdx.x] = p[(long)b * L + threadIdx.x];
     __syncthreads();
     float delta = 0.f;
     for (int j = 0; j < L; ++j) delta += ds[j] * ps[j];
@@ -294,10 +328,10 @@ __global__ __launch_bounds__(256) void dot_attn_bwd_kernel(const float* __restri
     __syncthreads();
     float* dmb = dmem + (long)b * L * D;
     for (int c = threadIdx.x; c < D; c += 256) {
-        const float g = gb[c], qc = qb[c];
+        const float g = gs[c], qc = qb[c];
         float a = 0.f;
         for (int j = 0; j < L; ++j) {
-            a += ds[j] * mb[(long)j * D + c];
+            a += ds[j] * ms[j * D + c];
             dmb[(long)j * D + c] += ps[j] * g + ds[j] * qc;
         }
         float* o = dq + (long)b * lddq + c;
@@ -308,8 +342,11 @@ __global__ __launch_bounds__(256) void dot_attn_bwd_kernel(const float* __restri
 extern "C" int cst_dot_attn_bwd(const float* dout, long lddo, const float* q, long ldq, const float* mem, const float* p,
                                 float* dq, long lddq, int dq_accumulate, float* dmem, int B, int L, int D, void* stream) {
     CST_REQUIRE(dout && q && mem && p && dq && dmem, "cst_dot_attn_bwd: null pointer");
-    CST_REQUIRE(B > 0 && L > 0 && L <= MHA_SMAX && D > 0, "cst_dot_attn_bwd: L=%d unsupported (max %d)", L, MHA_SMAX);
-    hipLaunchKernelGGL(dot_attn_bwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, dout, lddo, q, ldq, mem, p,
+    CST_REQUIRE(B > 0 && L > 0 && L <= MHA_SMAX && D > 0 && D % 4 == 0, "cst_dot_attn_bwd: L=%d (max %d) or D=%d unsupported", L, MHA_SMAX, D);
+    const size_t lds = sizeof(float) * ((size_t)L * D + D + 128);
+    CST_REQUIRE(lds <= 160 * 1024, "cst_dot_attn_bwd: memory tile of %zu bytes exceeds the 160 KiB LDS", lds);
+    if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)dot_attn_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(dot_attn_bwd_kernel, dim3(B), dim3(256), lds, (hipStream_t)stream, dout, lddo, q, ldq, mem, p,
                        dq, lddq, dq_accumulate, dmem, L, D, 1.0f / sqrtf((float)D));
     CST_LAUNCH_CHECK("cst_dot_attn_bwd");
     return CST_OK;

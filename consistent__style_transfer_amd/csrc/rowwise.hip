@@ -448,8 +448,16 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ X
     const int c = blockIdx.x * 64 + lane;
     const long r0 = (long)blockIdx.y * rows_per_split;
     float s = 0.f;
-    if (c < N)
-        for (long r = r0 + w; r < r0 + rows_per_split && r < M; r += 4) s += X[r * ld + c];
+    if (c < N) {
+        const long rend = min((long)M, r0 + rows_per_split);
+        long r = r0 + w;
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;       // four loads in flight per lane
+        for (; r + 12 < rend; r += 16) {
+            s0 += X[r * ld + c]; s1 += X[(r + 4) * ld + c]; s2 += X[(r + 8) * ld + c]; s3 += X[(r + 12) * ld + c];
+        }
+        for (; r < rend; r += 4) s0 += X[r * ld + c];
+        s = (s0 + s1) + (s2 + s3);
+    }
     sh[w][lane] = s;
     __syncthreads();
     if (w == 0 && c < N) {
@@ -464,7 +472,7 @@ extern "C" int cst_colsum(const float* X, long ld, int M, int N, float* out, int
     hipStream_t st = (hipStream_t)stream;
     const int cg = cst_div_up(N, 64);
     int splits = 1;
-    if (M >= 512) { splits = 1024 / cg; if (splits < 1) splits = 1; if (splits > M / 64) splits = M / 64; if (splits < 1) splits = 1; }
+    if (M >= 256) { splits = 2048 / cg; if (splits < 1) splits = 1; if (splits > M / 32) splits = M / 32; if (splits < 1) splits = 1; }
     const int rps = cst_div_up(M, splits);
     const int use_atomic = splits > 1;
     if (use_atomic && !accumulate) {
@@ -476,7 +484,7 @@ extern "C" int cst_colsum(const float* X, long ld, int M, int N, float* out, int
 }
 
 extern "C" long cst_layernorm_bwd_workspace_floats(int T, int d) {
-    const int nblk = T < 1024 ? cst_div_up(T, 4) : 256;
+    const int nblk = T < 4096 ? cst_div_up(T, 4) : 1024;
     return 2L * nblk * d;
 }
 
@@ -485,7 +493,7 @@ extern "C" int cst_layernorm_bwd(const float* dy, const float* z, const float* m
                                  float* workspace, long workspace_floats, int T, int d, void* stream) {
     CST_REQUIRE(dy && z && mean && rstd && gamma && dz && workspace, "cst_layernorm_bwd: null pointer");
     CST_REQUIRE(T > 0 && d > 0 && d <= 64 * LN_MAXE, "cst_layernorm_bwd: d=%d unsupported", d);
-    const int nblk = T < 1024 ? cst_div_up(T, 4) : 256;
+    const int nblk = T < 4096 ? cst_div_up(T, 4) : 1024;      // one row per wave per pass: latency hidden by occupancy
     CST_REQUIRE(workspace_floats >= 2L * nblk * d, "cst_layernorm_bwd: workspace too small (%ld < %ld)", workspace_floats, 2L * nblk * d);
     const int rpb = cst_div_up(T, nblk);
     hipStream_t st = (hipStream_t)stream;

@@ -133,10 +133,10 @@ class GeneratorFn(torch.autograd.Function):
             h_next = XH[s + 1][:, E:] if s + 1 < T else None
             i_s = if2[:, s * W_:(s + 1) * W_]
             _cell_fwd(gdec[s], c_in, i_s[:, :Hd], cdec[s], h_next, B, Hd)
-            call("cst_dot_attn_fwd", i_s[:, :Hd], T * W_, memory, i_s[:, Hd:], T * W_, patt[s], B, Lp, Hd)
             id_s = ifd2[:, s * W_:(s + 1) * W_]
-            if drop.p > 0:
-                dropout2d(i_s, drop.at(STREAM_G_FFN + s), out=id_s)
+            fd = drop.at(STREAM_G_FFN + s)
+            call("cst_dot_attn_fwd", i_s[:, :Hd], T * W_, memory, i_s[:, Hd:], T * W_, patt[s], B, Lp, Hd,
+                 id_s if drop.p > 0 else None, T * W_, *fd.args())           # also writes dropout(i_ffn)
             r1s = r12[:, s * Hd:(s + 1) * Hd]
             linear_fwd(id_s, P["fn_1.weight"], P["fn_1.bias"], act=2, out=r1s)
             o_s = out2[:, s * V:(s + 1) * V]
@@ -197,19 +197,19 @@ class GeneratorFn(torch.autograd.Function):
             if s + 1 < T:
                 # gradient of the embedding that fed step s+1 (dropout STREAM_G_XT+s was applied to it)
                 xd = drop.at(STREAM_G_XT + s)
-                if xd.p > 0:
-                    dropout2d(dXH[:, :E], xd, out=dxe)
-                    g_x = dxe
-                else:
-                    g_x = dXH[:, :E]
                 if soft:
+                    if xd.p > 0:
+                        dropout2d(dXH[:, :E], xd, out=dxe)
+                        g_x = dxe
+                    else:
+                        g_x = dXH[:, :E]
                     # straight-through: d p_s += dx @ E^T ; dE += onehot(argmax)^T dx   (rnn.py:84-85)
                     gemm(g_x, True, E_tok, True, dl, B, V, E, accumulate=True)
                     embed_scatter_add(dE, g_x, ids_a=ids_fb[s])
                 elif x_c is None:
-                    embed_scatter_add(dE, g_x, ids_a=ids_fb[s])
+                    embed_scatter_add(dE, dXH[:, :E], ids_a=ids_fb[s], drop=xd)       # dropout mask applied in the scatter
                 else:
-                    embed_scatter_add(dE, g_x, ids_a=ids_fb[s], ids_b=x_c[:, s], ldb=T, coin=coins[s:s + 1])
+                    embed_scatter_add(dE, dXH[:, :E], ids_a=ids_fb[s], ids_b=x_c[:, s], ldb=T, coin=coins[s:s + 1], drop=xd)
             if soft:
                 softmax_tau_bwd(out2[:, s * V:(s + 1) * V], dl, inv_tau, dl)
             diffn = df2[:, s * W_:(s + 1) * W_]

@@ -95,9 +95,12 @@ int cst_mha_fwd(const float* qkv, float* out, float* lse, int B, int S, int H, i
 int cst_mha_bwd(const float* qkv, const float* dout, const float* lse, float* dqkv, int B, int S, int H, int hd,
                 float drop_p, uint32_t drop_seed, uint32_t drop_stream, const void* drop_seed_dev, void* stream);
 
-/* Single-query dot attention (rnn.py:46-50,76): out = softmax(q mem^T / sqrt(D)) mem; p [B,L] kept. */
+/* Single-query dot attention (rnn.py:46-50,76): out = softmax(q mem^T / sqrt(D)) mem; p [B,L] kept.
+ * `dropped` (optional, [B, lddrop]): also writes dropout([q | out]) -- the decoder's i_ffn of
+ * rnn.py:78-79, dropout index b*2D + c -- saving a separate dropout launch per decode step. */
 int cst_dot_attn_fwd(const float* q, long ldq, const float* mem, float* out, long ldo, float* p,
-                     int B, int L, int D, void* stream);
+                     int B, int L, int D, float* dropped, long lddrop,
+                     float drop_p, uint32_t drop_seed, uint32_t drop_stream, const void* drop_seed_dev, void* stream);
 /* dq (+)= ..., dmem += ... (dmem accumulates across decode steps; zero it first). */
 int cst_dot_attn_bwd(const float* dout, long lddo, const float* q, long ldq, const float* mem, const float* p,
                      float* dq, long lddq, int dq_accumulate, float* dmem, int B, int L, int D, void* stream);
