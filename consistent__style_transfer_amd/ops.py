@@ -71,9 +71,12 @@ WS_FLOATS = 16 * 1024 * 1024         # 64 MiB split-K slab workspace per device
 
 
 def _workspace(dev):
-    ws = _WS.get(dev)
+    """One split-K slab buffer per (device, stream): GEMMs of concurrent stream branches must not share it."""
+    key = (dev, torch.cuda.current_stream(dev).cuda_stream)
+    ws = _WS.get(key)
     if ws is None:
-        ws = _WS[dev] = torch.empty(WS_FLOATS, device=dev, dtype=torch.float32)
+        with torch.cuda.stream(torch.cuda.default_stream(dev)):       # allocate outside any side stream / capture pool
+            ws = _WS[key] = torch.empty(WS_FLOATS, device=dev, dtype=torch.float32)
     return ws
 
 

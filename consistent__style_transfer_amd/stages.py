@@ -22,6 +22,32 @@ from .model import MLM, DenoiseLSTM, Matcher, RelGAN_D, TextCNN
 from .optim import FlatGroup, clip_groups
 
 
+class Fork:
+    """Run independent branches of a step on forked HIP streams and join them.  Branch 0 stays on
+    the current stream.  Autograd replays each branch's backward on the stream its forward ran on,
+    so the backward pass forks and joins the same way; inside a hipGraph capture the branches
+    become parallel sub-graphs.  Serial when disabled (CST_NO_FORK=1) or off the GPU."""
+
+    def __init__(self, n):
+        import os
+        self.enabled = torch.cuda.is_available() and os.environ.get("CST_NO_FORK", "0") != "1"
+        self.streams = [torch.cuda.Stream() for _ in range(n - 1)] if self.enabled else []
+
+    def run(self, fns):
+        if not self.enabled:
+            return [f() for f in fns]
+        main = torch.cuda.current_stream()
+        outs = [None] * len(fns)
+        for s, (i, f) in zip(self.streams, list(enumerate(fns))[1:]):
+            s.wait_stream(main)
+            with torch.cuda.stream(s):
+                outs[i] = f()
+        outs[0] = fns[0]()
+        for s in self.streams[:len(fns) - 1]:
+            main.wait_stream(s)
+        return outs
+
+
 def _set_requires_grad(params, flag):
     for p in params:
         p.requires_grad_(flag)
@@ -55,14 +81,22 @@ class PretrainStage(nn.Module):
     def losses(self, batch, seed=None):
         """(s_loss, c_loss, dn_loss) -- main_pretrain.py:66-77; a frozen model contributes None."""
         x, nx_1, nx_2, nx, label, c_label = batch
-        s = c = dn = None
-        if self.flags["cls"]:
-            s = ops.token_ce(self.classifier(x, seed=seed), label)
-        if self.flags["mat"]:
-            c = ops.mse_loss(self.matcher(nx_1, nx_2, seed=seed), c_label)
-        if self.flags["dn"]:
+
+        def f_dn():
+            if not self.flags["dn"]:
+                return None
             lg = self.denoiser(nx, seed=seed)
-            dn = ops.token_ce(lg.view(-1, lg.size(-1)), x.reshape(-1), unit_grad=True)
+            return ops.token_ce(lg.view(-1, lg.size(-1)), x.reshape(-1), unit_grad=True)
+
+        def f_mat():
+            return ops.mse_loss(self.matcher(nx_1, nx_2, seed=seed), c_label) if self.flags["mat"] else None
+
+        def f_cls():
+            return ops.token_ce(self.classifier(x, seed=seed), label) if self.flags["cls"] else None
+
+        if not hasattr(self, "_fork"):
+            self._fork = Fork(3)
+        dn, c, s = self._fork.run([f_dn, f_mat, f_cls])          # three independent critics, three streams
         return s, c, dn
 
     def train_step(self, batch, seed=None, reducer=None):
@@ -144,20 +178,32 @@ class OptimizeStage(nn.Module):
     def g_losses(self, batch, coins=None, seed=None):
         x, labels = batch
         sample_p = self.forward(x, labels, 1 - labels, self.tau, seed=seed)
-        s_logits = self.classifier(sample_p, seed=seed)
-        c_logits = self.matcher(sample_p, x, seed=seed)
-        was_training = self.disc.training
-        self.disc.eval()                                                      # main_optimize.py:102
-        adv_logits = self.disc(sample_p)
-        self.disc.train(was_training)
         with torch.no_grad():
             tokens = self.generator.last_ids.t().contiguous()                 # == sample_p.argmax(-1)
-        bk_logits = self.generator(tokens, 1 - labels, x, labels, coins=coins,
-                                   seed=None if seed is None else seed + 1)
-        s_loss = ops.token_ce(s_logits, 1 - labels, weight=1.0)
-        c_loss = ops.mse_loss(c_logits, None, self.gap)
-        g_loss = ops.bce_logits_loss(adv_logits, 1.0)
-        bk_loss = ops.token_ce(bk_logits.view(-1, bk_logits.size(-1)), x.reshape(-1), weight=self.w_bt, unit_grad=True)
+        inv_labels = 1 - labels
+        was_training = self.disc.training
+        self.disc.eval()                                                      # main_optimize.py:102
+
+        # four independent consumers of sample_p: the back-translation decode (latency-bound small
+        # kernels) overlaps with the critics' large GEMMs
+        def f_bk():
+            lg = self.generator(tokens, inv_labels, x, labels, coins=coins, seed=None if seed is None else seed + 1)
+            return ops.token_ce(lg.view(-1, lg.size(-1)), x.reshape(-1), weight=self.w_bt, unit_grad=True)
+
+        def f_mat():
+            cl = self.matcher(sample_p, x, seed=seed)
+            return cl, ops.mse_loss(cl, None, self.gap)
+
+        def f_cls():
+            return ops.token_ce(self.classifier(sample_p, seed=seed), inv_labels, weight=1.0)
+
+        def f_adv():
+            return ops.bce_logits_loss(self.disc(sample_p), 1.0)
+
+        if not hasattr(self, "_fork"):
+            self._fork = Fork(4)
+        bk_loss, (c_logits, c_loss), s_loss, g_loss = self._fork.run([f_bk, f_mat, f_cls, f_adv])
+        self.disc.train(was_training)
         loss = bk_loss + self.wc * c_loss + self.w_adv * g_loss + self.ws * s_loss
         return {"loss": loss, "G": g_loss, "STI": s_loss, "CP_logits": c_logits, "BK": bk_loss / self.w_bt if self.w_bt else bk_loss,
                 "sample_ids": tokens}
