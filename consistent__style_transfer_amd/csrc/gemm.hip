@@ -96,20 +96,20 @@ __device__ __forceinline__ uint4 pack_slot(const float (&v)[8]) {
 // MN-major operand: item idx -> (row = idx % ROWS, slot = idx / ROWS); for a fixed k the rows are
 //                   contiguous in HBM, so each of the EPS scalar loads is coalesced across lanes
 //                   (64 lanes x 4 B) and the transpose happens in registers.
-template <int ROWS, bool F32, bool KMAJ>
+template <int ROWS, bool F32, bool KMAJ, int NT>
 struct Stage;
 
 // K-major, bf16 image: an item is one float4 (4 consecutive k) -> half a slot (8 bytes).
 // 16 consecutive lanes read one whole 256-byte row of the HBM tile; their 16 ds_write_b64 cover
 // the whole 128-byte LDS row (every bank once).
-template <int ROWS>
-struct Stage<ROWS, false, true> {
-    static constexpr int PER_T = ROWS * 16 / 256;
+template <int ROWS, int NT>
+struct Stage<ROWS, false, true, NT> {
+    static constexpr int PER_T = ROWS * 16 / NT;
     float4 v[PER_T];
     __device__ __forceinline__ void load(const float* __restrict__ P, long ld, int row0, int k0, int rows, int kend, int vec) {
 #pragma unroll
         for (int i = 0; i < PER_T; ++i) {
-            const int idx = threadIdx.x + 256 * i;
+            const int idx = threadIdx.x + NT * i;
             const int r = idx >> 4, k = k0 + (idx & 15) * 4;
             float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
             if (row0 + r < rows) {
@@ -129,7 +129,7 @@ struct Stage<ROWS, false, true> {
     __device__ __forceinline__ void load_full(const float* __restrict__ P, long ld, int row0, int k0, int rows) {
 #pragma unroll
         for (int i = 0; i < PER_T; ++i) {
-            const int idx = threadIdx.x + 256 * i;
+            const int idx = threadIdx.x + NT * i;
             const int r = min(row0 + (idx >> 4), rows - 1), k = k0 + (idx & 15) * 4;
             v[i] = *reinterpret_cast<const float4*>(P + (long)r * ld + k);
         }
@@ -137,7 +137,7 @@ struct Stage<ROWS, false, true> {
     __device__ __forceinline__ void store(char* S) const {
 #pragma unroll
         for (int i = 0; i < PER_T; ++i) {
-            const int idx = threadIdx.x + 256 * i;
+            const int idx = threadIdx.x + NT * i;
             const int r = idx >> 4, q = idx & 15;
             uint2 u;
             u.x = (uint32_t)f2bf(v[i].x) | ((uint32_t)f2bf(v[i].y) << 16);
@@ -148,14 +148,14 @@ struct Stage<ROWS, false, true> {
 };
 
 // K-major, fp32 image: an item is one float4 = one slot; 8 lanes cover a 128-byte row.
-template <int ROWS>
-struct Stage<ROWS, true, true> {
-    static constexpr int PER_T = ROWS * 8 / 256;
+template <int ROWS, int NT>
+struct Stage<ROWS, true, true, NT> {
+    static constexpr int PER_T = ROWS * 8 / NT;
     float4 v[PER_T];
     __device__ __forceinline__ void load(const float* __restrict__ P, long ld, int row0, int k0, int rows, int kend, int vec) {
 #pragma unroll
         for (int i = 0; i < PER_T; ++i) {
-            const int idx = threadIdx.x + 256 * i;
+            const int idx = threadIdx.x + NT * i;
             const int r = idx >> 3, k = k0 + (idx & 7) * 4;
             float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
             if (row0 + r < rows) {
@@ -171,7 +171,7 @@ struct Stage<ROWS, true, true> {
     __device__ __forceinline__ void load_full(const float* __restrict__ P, long ld, int row0, int k0, int rows) {
 #pragma unroll
         for (int i = 0; i < PER_T; ++i) {
-            const int idx = threadIdx.x + 256 * i;
+            const int idx = threadIdx.x + NT * i;
             const int r = min(row0 + (idx >> 3), rows - 1), k = k0 + (idx & 7) * 4;
             v[i] = *reinterpret_cast<const float4*>(P + (long)r * ld + k);
         }
@@ -179,7 +179,7 @@ struct Stage<ROWS, true, true> {
     __device__ __forceinline__ void store(char* S) const {
 #pragma unroll
         for (int i = 0; i < PER_T; ++i) {
-            const int idx = threadIdx.x + 256 * i;
+            const int idx = threadIdx.x + NT * i;
             *reinterpret_cast<float4*>(S + lds_off(idx >> 3, idx & 7)) = v[i];
         }
     }
@@ -189,15 +189,15 @@ struct Stage<ROWS, true, true> {
 // fixed k the rows are contiguous in HBM, so each of the EPS scalar loads is coalesced across the
 // 64 lanes (256 bytes) and the transpose happens in registers; 8 consecutive lanes (rows) then
 // write 8 distinct physical slots.
-template <int ROWS, bool F32>
-struct Stage<ROWS, F32, false> {
+template <int ROWS, bool F32, int NT>
+struct Stage<ROWS, F32, false, NT> {
     static constexpr int EPS = F32 ? 4 : 8;
-    static constexpr int PER_T = ROWS * 8 / 256;
+    static constexpr int PER_T = ROWS * 8 / NT;
     float v[PER_T][8];
     __device__ __forceinline__ void load(const float* __restrict__ P, long ld, int row0, int k0, int rows, int kend, int vec) {
 #pragma unroll
         for (int i = 0; i < PER_T; ++i) {
-            const int idx = threadIdx.x + 256 * i;
+            const int idx = threadIdx.x + NT * i;
             const int r = idx % ROWS, k = k0 + (idx / ROWS) * EPS;
             const bool rok = row0 + r < rows;
             const float* p = P + (long)k * ld + row0 + r;
@@ -208,7 +208,7 @@ struct Stage<ROWS, F32, false> {
     __device__ __forceinline__ void load_full(const float* __restrict__ P, long ld, int row0, int k0, int rows) {
 #pragma unroll
         for (int i = 0; i < PER_T; ++i) {
-            const int idx = threadIdx.x + 256 * i;
+            const int idx = threadIdx.x + NT * i;
             const int r = min(row0 + idx % ROWS, rows - 1), k = k0 + (idx / ROWS) * EPS;
             const float* p = P + (long)k * ld + r;
 #pragma unroll
@@ -218,19 +218,22 @@ struct Stage<ROWS, F32, false> {
     __device__ __forceinline__ void store(char* S) const {
 #pragma unroll
         for (int i = 0; i < PER_T; ++i) {
-            const int idx = threadIdx.x + 256 * i;
+            const int idx = threadIdx.x + NT * i;
             *reinterpret_cast<uint4*>(S + lds_off(idx % ROWS, idx / ROWS)) = pack_slot<F32>(v[i]);
         }
     }
 };
 
-// NBUF = 2: double-buffered LDS, one barrier per K-tile (fewer, longer-lived workgroups);
-// NBUF = 1: single buffer, two barriers per K-tile, half the LDS -> more workgroups per CU
-// (thread-level parallelism hides the HBM/L2 latency of the register-staged loads).
-template <int BM, int BN, bool F32, bool A_KMAJ, bool B_KMAJ, int NBUF>
-__global__ __launch_bounds__(256) void cst_gemm_kernel(GemmArgs g) {
+// One LDS buffer, two barriers per K-tile: the HBM/L2 latency of the register-staged loads is
+// hidden by thread-level parallelism (several workgroups per CU), which measured faster than
+// double buffering at equal tile size.  NW = 4 waves (2x2) or 8 waves (2x4) per workgroup: with 8
+// waves each thread stages half as much (fewer VGPRs -> more resident waves -> more loads in flight).
+template <int BM, int BN, bool F32, bool A_KMAJ, bool B_KMAJ, int NW>
+__global__ __launch_bounds__(NW * 64) void cst_gemm_kernel(GemmArgs g) {
     constexpr int BK = TileCfg<F32>::BK;
-    constexpr int TM = BM / 32, TN = BN / 32;      // 16x16 tiles per wave in each direction
+    constexpr int NT = NW * 64, NBUF = 1;
+    constexpr int WGN = NW / 2;                    // waves along N (2 or 4); always 2 along M
+    constexpr int TM = BM / 32, TN = BN / (16 * WGN);   // 16x16 tiles per wave in each direction
     constexpr int A_BYTES = BM * ROW_BYTES, B_BYTES = BN * ROW_BYTES;
     __shared__ __attribute__((aligned(16))) char smem[NBUF * (A_BYTES + B_BYTES)];
 
@@ -254,7 +257,7 @@ __global__ __launch_bounds__(256) void cst_gemm_kernel(GemmArgs g) {
     const float* B = g.B + bz * g.sB;
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WGN, wn = wave % WGN;
     const int lr = lane & 15, lq = lane >> 4;
 
     f32x4_t acc[TM][TN];
@@ -263,8 +266,8 @@ __global__ __launch_bounds__(256) void cst_gemm_kernel(GemmArgs g) {
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
-    Stage<BM, F32, A_KMAJ> sa;
-    Stage<BN, F32, B_KMAJ> sb;
+    Stage<BM, F32, A_KMAJ, NT> sa;
+    Stage<BN, F32, B_KMAJ, NT> sb;
     const int kbeg = blockIdx.y * g.k_per_split;
     const int kend = min(g.K, kbeg + g.k_per_split);
     const int nk = (kend - kbeg + BK - 1) / BK;
@@ -282,7 +285,7 @@ __global__ __launch_bounds__(256) void cst_gemm_kernel(GemmArgs g) {
     __syncthreads();
 
     for (int kt = 0; kt < nk; ++kt) {
-        const char* As = smem + (NBUF == 2 ? (kt & 1) : 0) * (A_BYTES + B_BYTES);
+        const char* As = smem;
         const char* Bs = As + A_BYTES;
         if (kt + 1 < nk) load_tiles(kbeg + (kt + 1) * BK);   // next tile: HBM -> registers while this one is multiplied
         // two k-steps per tile; fragment slot of lane group lq in step kk is kk*4 + lq
@@ -292,7 +295,7 @@ __global__ __launch_bounds__(256) void cst_gemm_kernel(GemmArgs g) {
 #pragma unroll
             for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const uint4*>(As + lds_off(wm * (BM / 2) + i * 16 + lr, kk * 4 + lq));
 #pragma unroll
-            for (int j = 0; j < TN; ++j) bfr[j] = *reinterpret_cast<const uint4*>(Bs + lds_off(wn * (BN / 2) + j * 16 + lr, kk * 4 + lq));
+            for (int j = 0; j < TN; ++j) bfr[j] = *reinterpret_cast<const uint4*>(Bs + lds_off(wn * (BN / WGN) + j * 16 + lr, kk * 4 + lq));
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -310,11 +313,10 @@ __global__ __launch_bounds__(256) void cst_gemm_kernel(GemmArgs g) {
                     }
                 }
         }
-        if constexpr (NBUF == 1) __syncthreads();      // everyone is done reading the only buffer
-        if (kt + 1 < nk) {                     // NBUF == 2: the other buffer was last read before the previous barrier
-            char* An = smem + (NBUF == 2 ? ((kt + 1) & 1) : 0) * (A_BYTES + B_BYTES);
-            sa.store(An);
-            sb.store(An + A_BYTES);
+        __syncthreads();                       // everyone is done reading the buffer
+        if (kt + 1 < nk) {
+            sa.store(smem);
+            sb.store(smem + A_BYTES);
         }
         __syncthreads();
     }
@@ -326,7 +328,7 @@ __global__ __launch_bounds__(256) void cst_gemm_kernel(GemmArgs g) {
         for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
-                const int n = n0 + wn * (BN / 2) + j * 16 + lr;
+                const int n = n0 + wn * (BN / WGN) + j * 16 + lr;
                 if (n >= g.N) continue;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
@@ -344,11 +346,12 @@ __global__ __launch_bounds__(256) void cst_gemm_kernel(GemmArgs g) {
     // Stage this wave's (BM/2)x(BN/2) accumulator block through LDS (the K-loop's last barrier has
     // retired every tile read) so that each global store instruction writes whole 256-byte row
     // segments instead of 64-byte pieces of four different rows.
-    constexpr int WM = BM / 2, WN = BN / 2, CLD = WN;     // 2-way ds_write_b32 conflicts are free
-    constexpr int PASSES = 2 / NBUF;                       // single-buffer builds stage half the rows at a time
+    constexpr int WM = BM / 2, WN = BN / WGN, CLD = WN;   // 2-way ds_write_b32 conflicts are free
+    constexpr int PASSES = 2;                              // stage half the rows of the wave block at a time
     constexpr int PR = WM / PASSES;                        // rows of the wave block per pass
-    static_assert(4 * PR * CLD * 4 <= NBUF * (A_BYTES + B_BYTES), "C staging must fit the tile buffers");
+    static_assert(NW * PR * CLD * 4 <= NBUF * (A_BYTES + B_BYTES), "C staging must fit the tile buffers");
     float* Cs = reinterpret_cast<float*>(smem) + wave * PR * CLD;
+    static_assert((PR * (WN / 4)) % 64 == 0, "C staging rows must divide over the wave");
     constexpr int C4 = WN / 4;                             // float4 chunks per row of the wave block
     const bool cvec = (g.ldc % 4 == 0) && ((reinterpret_cast<uintptr_t>(C) & 15) == 0) && !g.accumulate;
 #pragma unroll
@@ -405,12 +408,12 @@ __global__ __launch_bounds__(256) void cst_gemm_splitk_reduce(GemmArgs g) {
     }
 }
 
-template <int BM, int BN, int NBUF>
+template <int BM, int BN, int NW>
 static void launch_cfg(const GemmArgs& g, int f32, int akm, int bkm, int batch, hipStream_t st) {
-    dim3 grid(cst_div_up(g.M, BM) * cst_div_up(g.N, BN), g.splits, batch), block(256);
+    dim3 grid(cst_div_up(g.M, BM) * cst_div_up(g.N, BN), g.splits, batch), block(NW * 64);
 #define CST_GEMM_CASE(F, AK, BKM)                                                              \
     if (f32 == F && akm == AK && bkm == BKM) {                                                 \
-        hipLaunchKernelGGL((cst_gemm_kernel<BM, BN, (bool)F, (bool)AK, (bool)BKM, NBUF>), grid, block, 0, st, g); \
+        hipLaunchKernelGGL((cst_gemm_kernel<BM, BN, (bool)F, (bool)AK, (bool)BKM, NW>), grid, block, 0, st, g); \
         return;                                                                                \
     }
     CST_GEMM_CASE(0, 1, 1) CST_GEMM_CASE(0, 1, 0) CST_GEMM_CASE(0, 0, 1) CST_GEMM_CASE(0, 0, 0)
@@ -453,7 +456,8 @@ extern "C" int cst_gemm(const float* A, long lda, int a_kmajor, const float* B, 
     const long big = (long)cst_div_up(M, 128) * cst_div_up(N, 128) * batch;
     const long small = (long)cst_div_up(M, 64) * cst_div_up(N, 64) * batch;
     int use_big, splits = 1;
-    const int nbuf2 = tile & 1;                 // odd tile codes (65, 129) pick the double-buffered build
+    const int w8 = tile & 1;                    // odd tile code 129 forces the 8-wave build, 128 the 4-wave one
+    const int forced = tile != 0;
     tile &= ~1;
     if (tile == 128 || (tile == 0 && big >= 192)) { use_big = 1; }
     else if (tile == 0 && K >= 2048 && big >= 16 && workspace && splitk == 0) {
@@ -485,10 +489,11 @@ extern "C" int cst_gemm(const float* A, long lda, int a_kmajor, const float* B, 
     g.slab = workspace;
     hipStream_t st = (hipStream_t)stream;
     const int pf = precision_f32 ? 1 : 0, ak = a_kmajor ? 1 : 0, bk_ = b_kmajor ? 1 : 0;
-    if (use_big && nbuf2) launch_cfg<128, 128, 2>(g, pf, ak, bk_, batch, st);
-    else if (use_big) launch_cfg<128, 128, 1>(g, pf, ak, bk_, batch, st);
-    else if (nbuf2) launch_cfg<64, 64, 2>(g, pf, ak, bk_, batch, st);
-    else launch_cfg<64, 64, 1>(g, pf, ak, bk_, batch, st);
+    // measured (tools/gemm_bench.py): two K-major operands run best with 4 waves per workgroup, any
+    // MN-major operand (dgrad / wgrad: many scalar staging loads) with 8
+    if (use_big && (forced ? w8 : !(ak && bk_))) launch_cfg<128, 128, 8>(g, pf, ak, bk_, batch, st);
+    else if (use_big) launch_cfg<128, 128, 4>(g, pf, ak, bk_, batch, st);
+    else launch_cfg<64, 64, 4>(g, pf, ak, bk_, batch, st);
     CST_LAUNCH_CHECK("cst_gemm");
     if (splits > 1) {
         long mn = (long)M * N;

@@ -70,13 +70,21 @@ _WS = {}
 WS_FLOATS = 16 * 1024 * 1024         # 64 MiB split-K slab workspace per device
 
 
+_LANE = [0]          # which concurrent branch of a step is issuing work (stages.Fork sets it)
+
+
+def set_lane(i):
+    _LANE[0] = i
+
+
 def _workspace(dev):
-    """One split-K slab buffer per (device, stream): GEMMs of concurrent stream branches must not share it."""
-    key = (dev, torch.cuda.current_stream(dev).cuda_stream)
+    """One split-K slab buffer per (device, branch lane): GEMMs of concurrent stream branches must
+    not share it.  Keyed by lane (not by stream id) so the buffers created in the eager warm-up pass
+    are the ones a later hipGraph capture sees -- nothing is allocated while capturing."""
+    key = (dev, _LANE[0])
     ws = _WS.get(key)
     if ws is None:
-        with torch.cuda.stream(torch.cuda.default_stream(dev)):       # allocate outside any side stream / capture pool
-            ws = _WS[key] = torch.empty(WS_FLOATS, device=dev, dtype=torch.float32)
+        ws = _WS[key] = torch.empty(WS_FLOATS, device=dev, dtype=torch.float32)
     return ws
 
 

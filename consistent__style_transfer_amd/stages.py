@@ -26,11 +26,14 @@ class Fork:
     """Run independent branches of a step on forked HIP streams and join them.  Branch 0 stays on
     the current stream.  Autograd replays each branch's backward on the stream its forward ran on,
     so the backward pass forks and joins the same way; inside a hipGraph capture the branches
-    become parallel sub-graphs.  Serial when disabled (CST_NO_FORK=1) or off the GPU."""
+    become parallel sub-graphs.  OFF by default: measured on MI355X (round 1) the branches do not
+    overlap -- eager and hipGraph replay both take the sum of the kernel durations (38.2 ms/step
+    either way, 40.6 ms with forked streams in eager mode) -- so the step stays serial unless
+    CST_FORK=1."""
 
     def __init__(self, n):
         import os
-        self.enabled = torch.cuda.is_available() and os.environ.get("CST_NO_FORK", "0") != "1"
+        self.enabled = torch.cuda.is_available() and os.environ.get("CST_FORK", "0") == "1"
         self.streams = [torch.cuda.Stream() for _ in range(n - 1)] if self.enabled else []
 
     def run(self, fns):
@@ -40,8 +43,10 @@ class Fork:
         outs = [None] * len(fns)
         for s, (i, f) in zip(self.streams, list(enumerate(fns))[1:]):
             s.wait_stream(main)
+            ops.set_lane(i)
             with torch.cuda.stream(s):
                 outs[i] = f()
+        ops.set_lane(0)
         outs[0] = fns[0]()
         for s in self.streams[:len(fns) - 1]:
             main.wait_stream(s)

@@ -17,7 +17,7 @@ SHAPES = [  # (M, N, K, a_kmajor, b_kmajor, note)
 ]
 
 
-TILES = [0, 64, 65, 128, 129]        # auto, 64 single/double buffered, 128 single/double buffered
+TILES = [0, 64, 128, 129]        # auto, 64x64, 128x128 with 4 waves, 128x128 with 8 waves
 
 
 def main():
