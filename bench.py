@@ -210,29 +210,38 @@ def main():
     value = w["B"] * world * args.steps / dt
 
     roofline = None
-    table = None
     if rank == 0 and not args.no_roofline:
-        timer = _lib.KernelTimer(by_shape=args.breakdown)
-        _lib.set_timer(timer)
+        # dominant kernel = cst_gemm_kernel (55-60 % of the step's kernel time, profiles/): its launches
+        # are timed live with start/stop HIP events bound to each dispatch on the launch stream
+        # (hipExtLaunchKernelGGL), over extra untimed-for-throughput steps of the same workload.
         nprof = min(3, args.steps)
+        torch.cuda.synchronize()
+        _lib.gemm_profile(True)
         for it in range(nprof):
-            run_step(stages_, batches, args.warmup + args.steps + it, None if world > 1 else reducer)
-        _lib.set_timer(None)
-        table = timer.summary()
-        g = {"calls": 0, "ms": 0.0, "work": 0.0}
-        for k, v in table.items():
-            if k.startswith("cst_gemm"):
-                for f in g:
-                    g[f] += v[f]
-        if g and g["ms"] > 0:
-            ach = g["work"] / (g["ms"] * 1e-3) / 1e12
-            roofline = {"bound": "mfma", "kernel": "cst_gemm_kernel (all layouts; bf16 16x16x32 MFMA)",
+            run_step(stages_, batches, args.warmup + args.steps + it, None)
+        torch.cuda.synchronize()
+        _lib.gemm_profile(False)
+        ms, flops, min_bytes, n = _lib.gemm_profile_read()
+        if n and ms > 0:
+            ach = flops / (ms * 1e-3) / 1e12
+            traffic = None
+            pmc_path = os.path.join(REPO, "profiles", "round1_pmc_traffic.json")
+            if os.path.exists(pmc_path):            # HBM bytes per launch from the rocprofv3 --pmc passes of this command
+                k = json.load(open(pmc_path))["kernels"].get("cst_gemm_kernel")
+                if k:
+                    traffic = k["fetch_bytes_per_launch"] + k["write_bytes_per_launch"]
+            roofline = {"bound": "mfma", "kernel": "cst_gemm_kernel (bf16 v_mfma_f32_16x16x32, all operand layouts)",
                         "achieved": ach, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / MFMA_PEAK_TFLOPS,
-                        "traffic": None, "launches_per_step": g["calls"] / nprof,
-                        "avg_launch_us": 1000.0 * g["ms"] / g["calls"],
-                        "flops_per_launch": g["work"] / g["calls"],
-                        "share_of_kernel_time": g["ms"] / sum(v["ms"] for v in table.values())}
+                        "traffic": traffic, "launches_per_step": n / nprof, "avg_launch_us": 1000.0 * ms / n,
+                        "flops_per_launch": flops / n, "min_operand_bytes_per_launch": min_bytes / n,
+                        "kernel_ms_per_step": ms / nprof}
         if args.breakdown:
+            timer = _lib.KernelTimer(by_shape=True)
+            _lib.set_timer(timer)
+            for it in range(nprof):
+                run_step(stages_, batches, args.warmup + args.steps + nprof + it, None)
+            _lib.set_timer(None)
+            table = timer.summary()
             tot = sum(v["ms"] for v in table.values())
             for k, v in sorted(table.items(), key=lambda kv: -kv[1]["ms"]):
                 tf = f"  {v['work'] / (v['ms'] * 1e-3) / 1e12:7.1f} TF/s" if v["work"] else ""

@@ -16,7 +16,7 @@ HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "cst_hip.h")
 
 _CT = {
     "int": ctypes.c_int, "long": ctypes.c_long, "float": ctypes.c_float,
-    "uint32_t": ctypes.c_uint32,
+    "uint32_t": ctypes.c_uint32, "double": ctypes.c_double,
 }
 
 
@@ -141,3 +141,17 @@ def call(name, *args):
 def call_plain(name, *args):
     """Entry points without a stream / status (workspace queries)."""
     return lib().fn[name](*[_ptr(a) for a in args])
+
+
+def gemm_profile(enable):
+    lib().fn["cst_gemm_profile_enable"](1 if enable else 0)
+
+
+def gemm_profile_read():
+    """-> (total kernel ms, total FLOP, total minimal operand bytes, launches) since enable."""
+    ms, fl, by = ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
+    n = ctypes.c_long()
+    rc = lib().fn["cst_gemm_profile_read"](ctypes.byref(ms), ctypes.byref(fl), ctypes.byref(by), ctypes.byref(n))
+    if rc != 0:
+        raise RuntimeError(lib().last_error())
+    return ms.value, fl.value, by.value, n.value

@@ -408,12 +408,49 @@ __global__ __launch_bounds__(256) void cst_gemm_splitk_reduce(GemmArgs g) {
     }
 }
 
+// ---- optional kernel-precise timing (bench.py's roofline leg) ------------------------------------
+// When enabled, every cst_gemm_kernel launch goes through hipExtLaunchKernelGGL with a start and a
+// stop event bound to that kernel (begin / end of the dispatch itself, like a profiler's kernel
+// trace), so the measured duration excludes host launch gaps.
+#include <hip/hip_ext.h>
+#include <vector>
+struct GemmProf { hipEvent_t a, b; double flops; double bytes; };
+static bool g_prof_on = false;
+static std::vector<GemmProf> g_prof;
+
+extern "C" int cst_gemm_profile_enable(int on) {
+    if (on && !g_prof_on) g_prof.clear();
+    g_prof_on = on != 0;
+    return CST_OK;
+}
+
+// sums over the recorded launches; destroys the events
+extern "C" int cst_gemm_profile_read(double* total_ms, double* total_flops, double* total_min_bytes, long* launches) {
+    double ms = 0, fl = 0, by = 0;
+    for (auto& p : g_prof) {
+        if (hipEventSynchronize(p.b) != hipSuccess) { cst_set_error("cst_gemm_profile_read: event sync failed"); return CST_ERR_LAUNCH; }
+        float t = 0.f;
+        (void)hipEventElapsedTime(&t, p.a, p.b);
+        ms += t; fl += p.flops; by += p.bytes;
+        (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b);
+    }
+    *total_ms = ms; *total_flops = fl; *total_min_bytes = by; *launches = (long)g_prof.size();
+    g_prof.clear();
+    return CST_OK;
+}
+
 template <int BM, int BN, int NW>
 static void launch_cfg(const GemmArgs& g, int f32, int akm, int bkm, int batch, hipStream_t st) {
     dim3 grid(cst_div_up(g.M, BM) * cst_div_up(g.N, BN), g.splits, batch), block(NW * 64);
+    hipEvent_t ea = nullptr, eb = nullptr;
+    if (g_prof_on) {
+        (void)hipEventCreate(&ea); (void)hipEventCreate(&eb);
+        g_prof.push_back({ea, eb, 2.0 * g.M * g.N * g.K * batch, 4.0 * ((double)g.M * g.K + (double)g.N * g.K + (double)g.M * g.N) * batch});
+    }
 #define CST_GEMM_CASE(F, AK, BKM)                                                              \
     if (f32 == F && akm == AK && bkm == BKM) {                                                 \
-        hipLaunchKernelGGL((cst_gemm_kernel<BM, BN, (bool)F, (bool)AK, (bool)BKM, NW>), grid, block, 0, st, g); \
+        if (g_prof_on) hipExtLaunchKernelGGL((cst_gemm_kernel<BM, BN, (bool)F, (bool)AK, (bool)BKM, NW>), grid, block, 0, st, ea, eb, 0, g); \
+        else hipLaunchKernelGGL((cst_gemm_kernel<BM, BN, (bool)F, (bool)AK, (bool)BKM, NW>), grid, block, 0, st, g); \
         return;                                                                                \
     }
     CST_GEMM_CASE(0, 1, 1) CST_GEMM_CASE(0, 1, 0) CST_GEMM_CASE(0, 0, 1) CST_GEMM_CASE(0, 0, 0)

@@ -54,6 +54,12 @@ int cst_gemm(const float* A, long lda, int a_kmajor, const float* B, long ldb, i
              float drop_p, uint32_t drop_seed, uint32_t drop_stream, const void* drop_seed_dev,
              int tile, int splitk, float* workspace, long workspace_floats, void* stream);
 
+/* Kernel-precise timing of cst_gemm_kernel for roofline reporting: while enabled every launch carries
+ * a start and a stop HIP event bound to the dispatch (hipExtLaunchKernelGGL); the read call returns
+ * the summed kernel time, FLOPs (2MNK) and minimal operand bytes 4(MK+NK+MN).  Not capture-safe. */
+int cst_gemm_profile_enable(int on);
+int cst_gemm_profile_read(double* total_ms_host, double* total_flops_host, double* total_min_bytes_host, long* launches_host);
+
 /* Fused token cross-entropy forward + backward: row_loss[r] = logsumexp(x_r) - x_r[target_r];
  * dlogits = grad_scale * (softmax(x_r) - onehot(target_r)) (may alias logits; null = forward
  * only).  Rows with a target outside [0,V) contribute 0.  Replaces nn.CrossEntropyLoss at
