@@ -179,7 +179,7 @@ def main():
     rank, local, world = init_distributed()
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world} (launch N>1 with torch.distributed.run)"
     assert torch.cuda.is_available(), "bench.py needs a GPU: the product path has no CPU fallback"
-    device = torch.device("cuda", local)
+    device = torch.device("cuda", local % torch.cuda.device_count())
     torch.cuda.set_device(device)
     ops.set_precision(args.precision)
     w = WORKLOADS[args.workload]
@@ -188,6 +188,7 @@ def main():
     reducer = GradReducer(world) if world > 1 else None
 
     def barrier():
+        torch.cuda.synchronize()
         if world > 1:
             torch.distributed.barrier()
         torch.cuda.synchronize()

@@ -1,0 +1,404 @@
+// bf16-operand "NT" GEMM with direct-to-LDS staging for gfx950, and the cast kernels that feed it.
+//
+//   C[M,N] = epilogue( alpha * A[M,K] . B[N,K]^T ),  A and B bf16 in HBM with K contiguous and
+//   zero-padded to a multiple of 64 (the cast kernels below write that padding).
+//
+// Why a second GEMM: with fp32 operands in HBM (gemm.hip) every tile goes HBM -> VGPR -> convert ->
+// LDS, which costs registers (few waves resident), VALU converts and 2x the L2/HBM bytes, and the
+// loads of tile t+1 cannot stay in flight across the barrier without a second register set.  Here
+// operands are already bf16 and K-major on both sides (transposed copies are made once by
+// cst_cast_bf16 / cst_transpose_bf16, so forward, dgrad and wgrad are all NT products), so tiles go
+// HBM -> LDS with global_load_lds_dwordx4 (no VGPR destination) into a 3-stage ring:
+//   iteration t:  s_waitcnt vmcnt(loads of the one newer tile) ; s_barrier ; issue tile t+2 ;
+//                 ds_read_b128 fragments of tile t ; 32 x v_mfma_f32_16x16x32_bf16
+// i.e. one raw barrier per K-tile and two tiles of loads in flight behind the MFMAs (counted vmcnt,
+// never a drain inside the loop; all LDS lives in ONE array so hipcc adds no vmcnt(0) of its own).
+// LDS image = [rows][128 B] with the 16-byte slot XOR-swizzle of gemm.hip; because a
+// global_load_lds wave-instruction writes 1 KiB linearly (lane l -> base + 16 l), the swizzle is
+// applied to the per-lane SOURCE address (same 128-byte line, so coalescing is unchanged).
+//
+// Reference call sites served: the packed in_proj / out_proj / linear1 / linear2 products of
+// nn.TransformerEncoderLayer (mlm.py:20-22, match.py:18-20), forward, dgrad and wgrad.
+#include "cst_common.h"
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef __attribute__((address_space(1))) const void* gbl_ptr_t;
+typedef unsigned short bf16_t;
+
+__device__ __forceinline__ bf16_t f2bf16(float f) {
+    __bf16 b = (__bf16)f;
+    return __builtin_bit_cast(unsigned short, b);
+}
+__device__ __forceinline__ float bf162f(bf16_t h) { return __uint_as_float((uint32_t)h << 16); }
+
+// =============================================================================================
+// cast / transpose
+// =============================================================================================
+// out[r][c]   = bf16(x[r][c] * dropmask(r*C + c))   for c < C, 0 for C <= c < ldo   (r < R)
+// out_t[c][r] = same value                          for r < R, 0 for R <= r < ldot  (c < C)
+// One 64x64 tile per block, transposed through LDS.  IN_BF16: x is already bf16 (pure transpose).
+template <bool IN_BF16>
+__global__ __launch_bounds__(256) void cast_bf16_kernel(const void* __restrict__ xin, long ldx, int R, int C,
+                                                        bf16_t* __restrict__ out, long ldo, int Cp,
+                                                        bf16_t* __restrict__ out_t, long ldot, int Rp, CstDrop drop) {
+    __shared__ bf16_t tile[64][66];
+    const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+    const uint32_t dseed = drop.p > 0.f ? cst_drop_seed(drop) : 0u;
+    // 256 threads: 4 rows per pass, 64 columns
+    for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+        const int rr = i >> 6, cc = i & 63;
+        const int r = r0 + rr, c = c0 + cc;
+        float v = 0.f;
+        if (r < R && c < C) {
+            if constexpr (IN_BF16) v = bf162f(reinterpret_cast<const bf16_t*>(xin)[(long)r * ldx + c]);
+            else v = reinterpret_cast<const float*>(xin)[(long)r * ldx + c];
+            if (drop.p > 0.f) v *= cst_drop_mask(drop, dseed, (uint32_t)((long)r * C + c));
+        }
+        const bf16_t h = f2bf16(v);
+        tile[rr][cc] = h;
+        if (out && r < R && c < Cp) out[(long)r * ldo + c] = h;
+    }
+    if (!out_t) return;
+    __syncthreads();
+    for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+        const int cc = i >> 6, rr = i & 63;          // consecutive threads walk r (contiguous in out_t)
+        const int r = r0 + rr, c = c0 + cc;
+        if (c < C && r < Rp) out_t[(long)c * ldot + r] = tile[rr][cc];
+    }
+}
+
+extern "C" int cst_cast_bf16(const void* x, int x_is_bf16, long ldx, int R, int C,
+                             void* out, long ldo, void* out_t, long ldot,
+                             float drop_p, uint32_t drop_seed, uint32_t drop_stream, const void* drop_seed_dev, void* stream) {
+    CST_REQUIRE(x && (out || out_t) && R > 0 && C > 0 && ldx >= C, "cst_cast_bf16: bad arguments");
+    CST_REQUIRE(!out || ldo >= C, "cst_cast_bf16: ldo < C");
+    CST_REQUIRE(!out_t || ldot >= R, "cst_cast_bf16: ldot < R");
+    // padded extents: every column of `out` up to ldo and every column of `out_t` up to ldot is written
+    const int Cp = out ? (int)ldo : C, Rp = out_t ? (int)ldot : R;
+    CstDrop dr = cst_make_drop(drop_p, drop_seed, drop_stream, drop_seed_dev);
+    dim3 grid(cst_div_up(Cp > C ? Cp : C, 64), cst_div_up(Rp > R ? Rp : R, 64)), block(256);
+    hipStream_t st = (hipStream_t)stream;
+    if (x_is_bf16) hipLaunchKernelGGL((cast_bf16_kernel<true>), grid, block, 0, st, x, ldx, R, C, (bf16_t*)out, ldo, Cp, (bf16_t*)out_t, ldot, Rp, dr);
+    else hipLaunchKernelGGL((cast_bf16_kernel<false>), grid, block, 0, st, x, ldx, R, C, (bf16_t*)out, ldo, Cp, (bf16_t*)out_t, ldot, Rp, dr);
+    CST_LAUNCH_CHECK("cst_cast_bf16");
+    return CST_OK;
+}
+
+// column sums of a bf16 matrix into fp32 (bias gradients of bf16-only activations gradients)
+__global__ __launch_bounds__(256) void colsum_bf16_kernel(const bf16_t* __restrict__ X, long ld, int M, int N,
+                                                          float* __restrict__ out, int rows_per_split) {
+    __shared__ float sh[4][64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane;
+    const long r0 = (long)blockIdx.y * rows_per_split;
+    float s = 0.f;
+    if (c < N) {
+        const long rend = min((long)M, r0 + rows_per_split);
+        float s0 = 0.f, s1 = 0.f;
+        long r = r0 + w;
+        for (; r + 4 < rend; r += 8) { s0 += bf162f(X[r * ld + c]); s1 += bf162f(X[(r + 4) * ld + c]); }
+        for (; r < rend; r += 4) s0 += bf162f(X[r * ld + c]);
+        s = s0 + s1;
+    }
+    sh[w][lane] = s;
+    __syncthreads();
+    if (w == 0 && c < N) atomicAdd(out + c, (sh[0][lane] + sh[1][lane]) + (sh[2][lane] + sh[3][lane]));
+}
+
+extern "C" int cst_colsum_bf16(const void* X, long ld, int M, int N, float* out, void* stream) {
+    CST_REQUIRE(X && out && M > 0 && N > 0 && ld >= N, "cst_colsum_bf16: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    const int cg = cst_div_up(N, 64);
+    int splits = 2048 / cg; if (splits < 1) splits = 1; if (splits > M / 32) splits = M / 32; if (splits < 1) splits = 1;
+    if (hipMemsetAsync(out, 0, sizeof(float) * N, st) != hipSuccess) { cst_set_error("cst_colsum_bf16: memset failed"); return CST_ERR_LAUNCH; }
+    hipLaunchKernelGGL(colsum_bf16_kernel, dim3(cg, splits), dim3(256), 0, st, (const bf16_t*)X, ld, M, N, out, cst_div_up(M, splits));
+    CST_LAUNCH_CHECK("cst_colsum_bf16");
+    return CST_OK;
+}
+
+// =============================================================================================
+// GEMM
+// =============================================================================================
+struct BGemmArgs {
+    const bf16_t* A; const bf16_t* B;
+    float* C; bf16_t* Cb;           // either or both
+    const float* bias; const float* addend; const bf16_t* aux;
+    long lda, ldb, ldc, ldcb, ldadd, ldaux;
+    int M, N, K;                    // K multiple of 64
+    int act;                        // 0 none, 1 relu, 2 leaky(0.1), 3 aux>0 ? v*gate_scale : 0, 4 aux>0 ? v : 0.1 v
+    float alpha, gate_scale;
+    CstDrop drop;
+    int splits, k_per_split;        // k_per_split multiple of 64
+    float* slab;
+};
+
+constexpr int BBK = 64;             // bf16 elements of K per tile = 128 bytes per row
+constexpr int BROW = 128;
+
+__device__ __forceinline__ int blds_off(int row, int slot) { return row * BROW + ((slot ^ (row & 7)) << 4); }
+
+// Fragment reads are inline asm on purpose: hipcc treats an in-flight global_load_lds as a pending
+// LDS write and drains vmcnt(0) in front of any ds_read it can see, which would collapse the
+// 3-stage ring to one tile in flight.  These reads are invisible to that pass; their completion is
+// waited for by the explicit lgkmcnt(0) + sched_barrier below (cdna_hip_programming.md 5.7, form iii).
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
+__device__ __forceinline__ u32x4_t lds_read128(unsigned addr) {
+    u32x4_t v;
+    asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr) : "memory");
+    return v;
+}
+
+__device__ __forceinline__ void bgemm_store(const BGemmArgs& g, uint32_t dseed, int m, int n, float acc) {
+    float v = g.alpha * acc + (g.bias ? g.bias[n] : 0.f);
+    if (g.addend) v += g.addend[(long)m * g.ldadd + n];
+    if (g.act == 1) v = v > 0.f ? v : 0.f;
+    else if (g.act == 2) v = v > 0.f ? v : 0.1f * v;
+    else if (g.act == 3) v = bf162f(g.aux[(long)m * g.ldaux + n]) > 0.f ? v * g.gate_scale : 0.f;
+    else if (g.act == 4) v = bf162f(g.aux[(long)m * g.ldaux + n]) > 0.f ? v : 0.1f * v;
+    if (g.drop.p > 0.f) v *= cst_drop_mask(g.drop, dseed, (uint32_t)((long)m * g.N + n));
+    if (g.C) g.C[(long)m * g.ldc + n] = v;
+    if (g.Cb) g.Cb[(long)m * g.ldcb + n] = f2bf16(v);
+}
+
+template <int BM, int BN, int NSTAGE>
+__global__ __launch_bounds__(256) void cst_gemm_bf16_kernel(BGemmArgs g) {
+    constexpr int A_BYTES = BM * BROW, B_BYTES = BN * BROW, ST_BYTES = A_BYTES + B_BYTES;
+    constexpr int A_CH = BM / 8 / 4, B_CH = BN / 8 / 4;        // 1-KiB chunks (8 rows) per wave per tile
+    constexpr int LOADS = A_CH + B_CH;                          // global_load_lds instructions per wave per tile
+    constexpr int TM = BM / 32, TN = BN / 32;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tilesM = (g.M + BM - 1) / BM, tilesN = (g.N + BN - 1) / BN;
+    int id;
+    {
+        const int nblk = gridDim.x, q = nblk >> 3, r = nblk & 7, xcd = blockIdx.x & 7;
+        id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (blockIdx.x >> 3);
+    }
+    constexpr int GN = 4;
+    const int grp = id / (GN * tilesM);
+    const int gw = min(GN, tilesN - grp * GN);
+    const int local = id - grp * GN * tilesM;
+    const int tm = local / gw, tn = grp * GN + local % gw;
+    const int m0 = tm * BM, n0 = tn * BN;
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);     // provably wave-uniform (LDS DMA base)
+    const int wm = wave >> 1, wn = wave & 1;
+    const int lr = lane & 15, lq = lane >> 4;
+
+    // per-lane source rows / slots of this wave's chunks (constant over k): chunk c covers tile rows
+    // 8c..8c+7; lane l lands at (row 8c + l/8, physical slot l%8) and therefore fetches logical slot
+    // (l%8) ^ (row & 7).  Rows past the matrix edge re-read the last valid row (never stored).
+    const int lrow = lane >> 3, lps = lane & 7;
+    const bf16_t* asrc[A_CH];
+    const bf16_t* bsrc[B_CH];
+#pragma unroll
+    for (int c = 0; c < A_CH; ++c) {
+        const int r = (wave * A_CH + c) * 8 + lrow;
+        asrc[c] = g.A + (long)min(m0 + r, g.M - 1) * g.lda + ((lps ^ (r & 7)) << 3);
+    }
+#pragma unroll
+    for (int c = 0; c < B_CH; ++c) {
+        const int r = (wave * B_CH + c) * 8 + lrow;
+        bsrc[c] = g.B + (long)min(n0 + r, g.N - 1) * g.ldb + ((lps ^ (r & 7)) << 3);
+    }
+    const int kbeg = blockIdx.y * g.k_per_split;
+    const int kend = min(g.K, kbeg + g.k_per_split);
+    const int nk = (kend - kbeg) / BBK;
+
+    auto issue = [&](int t) {
+        char* st = smem + (t % NSTAGE) * ST_BYTES;
+        const int k = kbeg + t * BBK;
+#pragma unroll
+        for (int c = 0; c < A_CH; ++c)
+            __builtin_amdgcn_global_load_lds((gbl_ptr_t)(asrc[c] + k), (lds_ptr_t)(st + (wave * A_CH + c) * 1024), 16, 0, 0);
+#pragma unroll
+        for (int c = 0; c < B_CH; ++c)
+            __builtin_amdgcn_global_load_lds((gbl_ptr_t)(bsrc[c] + k), (lds_ptr_t)(st + A_BYTES + (wave * B_CH + c) * 1024), 16, 0, 0);
+    };
+
+    f32x4_t acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+    const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+    issue(0);
+    if (NSTAGE > 2 && nk > 1) issue(1);
+    for (int t = 0; t < nk; ++t) {
+        // tile t has landed once all but the (one) newer tile's loads of THIS wave are done, and every
+        // wave has said so at the barrier; the barrier also retires all reads of tile t-1, whose ring
+        // slot tile t+2 may now overwrite.
+        if (NSTAGE > 2 && t + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (t + NSTAGE - 1 < nk) issue(t + NSTAGE - 1);
+        const unsigned As = lds_base + (t % NSTAGE) * ST_BYTES;
+        const unsigned Bs = As + A_BYTES;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            u32x4_t af[TM], bfr[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) af[i] = lds_read128(As + blds_off(wm * (BM / 2) + i * 16 + lr, kk * 4 + lq));
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bfr[j] = lds_read128(Bs + blds_off(wn * (BN / 2) + j * 16 + lr, kk * 4 + lq));
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, af[i]),
+                                                                        __builtin_bit_cast(bf16x8_t, bfr[j]), acc[i][j], 0, 0, 0);
+        }
+    }
+    __syncthreads();                                  // all tile reads done before smem is reused for C
+
+    if (g.splits > 1) {
+        float* slab = g.slab + ((long)blockIdx.y * g.M) * g.N;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int n = n0 + wn * (BN / 2) + j * 16 + lr;
+                if (n >= g.N) continue;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int m = m0 + wm * (BM / 2) + i * 16 + lq * 4 + r;
+                    if (m < g.M) slab[(long)m * g.N + n] = acc[i][j][r];
+                }
+            }
+        return;
+    }
+
+    // epilogue through LDS: 256-byte fp32 / 128-byte bf16 row segments per store instruction
+    const uint32_t dseed = g.drop.p > 0.f ? cst_drop_seed(g.drop) : 0u;
+    constexpr int WM = BM / 2, WN = BN / 2, CLD = WN;
+    static_assert(4 * WM * CLD * 4 <= NSTAGE * ST_BYTES, "C staging must fit the ring");
+    float* Cs = reinterpret_cast<float*>(smem) + wave * WM * CLD;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Cs[(i * 16 + lq * 4 + r) * CLD + j * 16 + lr] = acc[i][j][r];
+    __builtin_amdgcn_wave_barrier();
+    constexpr int C4 = WN / 4;
+    const bool simple = !g.addend && g.act < 3 && g.drop.p <= 0.f;
+    const bool vecC = g.C && (g.ldc % 4 == 0) && ((reinterpret_cast<uintptr_t>(g.C) & 15) == 0);
+    const bool vecB = g.Cb && (g.ldcb % 4 == 0) && ((reinterpret_cast<uintptr_t>(g.Cb) & 7) == 0);
+#pragma unroll
+    for (int it = 0; it < WM * C4 / 64; ++it) {
+        const int idx = lane + 64 * it;
+        const int rr = idx / C4, cc = (idx % C4) * 4;
+        const int m = m0 + wm * WM + rr, n = n0 + wn * WN + cc;
+        if (m >= g.M || n >= g.N) continue;
+        const float4 a4 = *reinterpret_cast<const float4*>(&Cs[rr * CLD + cc]);
+        const float av[4] = {a4.x, a4.y, a4.z, a4.w};
+        if (simple && n + 3 < g.N && (!g.C || vecC) && (!g.Cb || vecB)) {
+            float o[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float v = g.alpha * av[e] + (g.bias ? g.bias[n + e] : 0.f);
+                if (g.act == 1) v = v > 0.f ? v : 0.f;
+                else if (g.act == 2) v = v > 0.f ? v : 0.1f * v;
+                o[e] = v;
+            }
+            if (g.C) *reinterpret_cast<float4*>(g.C + (long)m * g.ldc + n) = make_float4(o[0], o[1], o[2], o[3]);
+            if (g.Cb) {
+                uint2 u;
+                u.x = (uint32_t)f2bf16(o[0]) | ((uint32_t)f2bf16(o[1]) << 16);
+                u.y = (uint32_t)f2bf16(o[2]) | ((uint32_t)f2bf16(o[3]) << 16);
+                *reinterpret_cast<uint2*>(g.Cb + (long)m * g.ldcb + n) = u;
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (n + e < g.N) bgemm_store(g, dseed, m, n + e, av[e]);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void cst_gemm_bf16_reduce(BGemmArgs g) {
+    const uint32_t dseed = g.drop.p > 0.f ? cst_drop_seed(g.drop) : 0u;
+    const long MN = (long)g.M * g.N;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < MN; e += (long)gridDim.x * 256) {
+        float acc = 0.f;
+        for (int s = 0; s < g.splits; ++s) acc += g.slab[s * MN + e];
+        bgemm_store(g, dseed, (int)(e / g.N), (int)(e % g.N), acc);
+    }
+}
+
+template <int BM, int BN, int NSTAGE>
+static int bgemm_launch(const BGemmArgs& g, hipStream_t st) {
+    const size_t lds = (size_t)NSTAGE * (BM + BN) * BROW;
+    static bool attr_done = false;
+    if (!attr_done && lds > 64 * 1024) {
+        (void)hipFuncSetAttribute((const void*)cst_gemm_bf16_kernel<BM, BN, NSTAGE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_done = true;
+    }
+    dim3 grid(cst_div_up(g.M, BM) * cst_div_up(g.N, BN), g.splits), block(256);
+    hipLaunchKernelGGL((cst_gemm_bf16_kernel<BM, BN, NSTAGE>), grid, block, lds, st, g);
+    return 0;
+}
+
+extern "C" int cst_gemm_bf16(const void* A, long lda, const void* B, long ldb,
+                             float* C, long ldc, void* Cb, long ldcb, int M, int N, int K,
+                             const float* bias, const float* addend, long ldadd, const void* aux, long ldaux,
+                             int act, float gate_scale, float alpha,
+                             float drop_p, uint32_t drop_seed, uint32_t drop_stream, const void* drop_seed_dev,
+                             int tile, int splitk, float* workspace, long workspace_floats, void* stream) {
+    CST_REQUIRE(A && B && (C || Cb), "cst_gemm_bf16: null operand");
+    CST_REQUIRE(M > 0 && N > 0 && K > 0 && K % 64 == 0, "cst_gemm_bf16: K=%d must be a positive multiple of 64 (zero-padded operands)", K);
+    CST_REQUIRE(lda >= K && ldb >= K && lda % 8 == 0 && ldb % 8 == 0, "cst_gemm_bf16: lda/ldb must be >= K and multiples of 8");
+    CST_REQUIRE((((uintptr_t)A | (uintptr_t)B) & 15) == 0, "cst_gemm_bf16: operands must be 16-byte aligned");
+    CST_REQUIRE(!C || ldc >= N, "cst_gemm_bf16: ldc < N");
+    CST_REQUIRE(!Cb || ldcb >= N, "cst_gemm_bf16: ldcb < N");
+    CST_REQUIRE(act >= 0 && act <= 4 && (act < 3 || aux), "cst_gemm_bf16: bad activation / missing aux");
+    BGemmArgs g;
+    g.A = (const bf16_t*)A; g.B = (const bf16_t*)B; g.C = C; g.Cb = (bf16_t*)Cb;
+    g.bias = bias; g.addend = addend; g.aux = (const bf16_t*)aux;
+    g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.ldcb = ldcb; g.ldadd = ldadd; g.ldaux = ldaux;
+    g.M = M; g.N = N; g.K = K; g.act = act; g.alpha = alpha; g.gate_scale = gate_scale;
+    g.drop = cst_make_drop(drop_p, drop_seed, drop_stream, drop_seed_dev);
+    // tile / ring / split choice (tools/gemm_bench.py bf16nt): the 2-stage ring with two workgroups per
+    // CU beats the 3-stage one at these sizes; 64x128 tiles when they alone give >= 256 workgroups,
+    // 128x128 + split-K for long-K products with few output tiles (wgrad), 64x128 (+split) otherwise.
+    int three = tile & 1;                        // odd tile codes force the 3-stage ring
+    tile &= ~1;
+    const long big = (long)cst_div_up(M, 128) * cst_div_up(N, 128);
+    const long mid = (long)cst_div_up(M, 64) * cst_div_up(N, 128);
+    int use_big, splits = 1;
+    if (tile == 128) use_big = 1;
+    else if (tile == 64) use_big = 0;
+    else use_big = (mid < 256 && K >= 2048);
+    const long tiles = use_big ? big : mid;
+    if (splitk > 1) splits = splitk;
+    else if (splitk == 0 && workspace && tiles < 192 && K >= 512) {
+        splits = (int)((384 + tiles - 1) / tiles);
+        if (splits > K / 256) splits = K / 256;
+    }
+    if (splits > 1) {
+        int kps = cst_div_up(cst_div_up(K, splits), 64) * 64;
+        splits = cst_div_up(K, kps);
+        while (splits > 1 && (long)splits * M * N > workspace_floats) { kps += 64; splits = cst_div_up(K, kps); }
+        g.k_per_split = kps;
+    }
+    if (splits <= 1) { splits = 1; g.k_per_split = K; }
+    CST_REQUIRE(splits == 1 || workspace, "cst_gemm_bf16: split-K needs a workspace");
+    g.splits = splits; g.slab = workspace;
+    hipStream_t st = (hipStream_t)stream;
+    if (use_big) { if (three) bgemm_launch<128, 128, 3>(g, st); else bgemm_launch<128, 128, 2>(g, st); }
+    else { if (three) bgemm_launch<64, 128, 3>(g, st); else bgemm_launch<64, 128, 2>(g, st); }
+    CST_LAUNCH_CHECK("cst_gemm_bf16");
+    if (splits > 1) {
+        long mn = (long)M * N;
+        int rb = (int)((mn + 255) / 256); if (rb > 2048) rb = 2048;
+        hipLaunchKernelGGL(cst_gemm_bf16_reduce, dim3(rb), dim3(256), 0, st, g);
+        CST_LAUNCH_CHECK("cst_gemm_bf16_reduce");
+    }
+    return CST_OK;
+}

@@ -72,7 +72,8 @@ class EncoderStack(nn.Module):
         self.n_head = n_head
 
     def run(self, x2d, B, S, drop):
-        from ..ops import EncoderLayerFn
+        from ..ops import EncoderLayerBf16Fn, EncoderLayerFn, get_precision
+        fn = EncoderLayerFn if get_precision() == "f32" else EncoderLayerBf16Fn
         for i, l in enumerate(self.layers):
-            x2d = EncoderLayerFn.apply(x2d, *l.flat(), B, S, self.n_head, drop, i)
+            x2d = fn.apply(x2d, *l.flat(), B, S, self.n_head, drop, i)
         return x2d

@@ -23,9 +23,10 @@ def init_distributed(backend=None):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
-        if backend == "nccl":
-            torch.cuda.set_device(local)
+            backend = os.environ.get("CST_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
+        if torch.cuda.is_available():
+            # one process per GPU; ranks may only share a device in single-GPU rehearsals (gloo)
+            torch.cuda.set_device(local % torch.cuda.device_count())
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, local, world
 
@@ -56,25 +57,32 @@ class GradReducer:
     def __call__(self, groups):
         if self.world == 1:
             return
-        works = []
+        if self.avg:
+            works = []
+            for g in groups:
+                flat = g.flat_g
+                for s in range(0, flat.numel(), self.bucket):
+                    works.append(dist.all_reduce(flat[s:s + self.bucket], op=dist.ReduceOp.AVG, async_op=True))
+            for w in works:
+                w.wait()
+            return
+        # gloo (CPU tests, single-GPU rehearsals): no AVG and no device tensors -> stage through the host
         for g in groups:
             flat = g.flat_g
-            for s in range(0, flat.numel(), self.bucket):
-                chunk = flat[s:s + self.bucket]
-                if self.avg:
-                    works.append(dist.all_reduce(chunk, op=dist.ReduceOp.AVG, async_op=True))
-                else:
-                    works.append(dist.all_reduce(chunk, op=dist.ReduceOp.SUM, async_op=True))
-        for w in works:
-            w.wait()
-        if not self.avg:
-            for g in groups:
-                g.flat_g.div_(self.world)          # gloo (CPU tests) has no AVG; RCCL path never comes here
+            host = flat.detach().cpu() if flat.is_cuda else flat
+            works = [dist.all_reduce(host[s:s + self.bucket], op=dist.ReduceOp.SUM, async_op=True)
+                     for s in range(0, host.numel(), self.bucket)]
+            for w in works:
+                w.wait()
+            host.div_(self.world)
+            if flat.is_cuda:
+                flat.copy_(host)
 
 
 def max_over_ranks(value, device):
     if not dist.is_initialized():
         return value
-    t = torch.tensor([value], dtype=torch.float64, device=device)
+    on_dev = dist.get_backend() == "nccl"
+    t = torch.tensor([value], dtype=torch.float64, device=device if on_dev else "cpu")
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())

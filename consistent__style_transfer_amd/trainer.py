@@ -80,7 +80,8 @@ class Trainer:
     def __init__(self, args, patience, log_name, sanity_batches=5):
         self.args = args
         self.rank, self.local, self.world = init_distributed()
-        self.device = torch.device("cuda", self.local if self.world > 1 else int(str(args.device).split(",")[0] or 0))
+        self.device = torch.device("cuda", self.local % torch.cuda.device_count() if self.world > 1
+                                   else int(str(args.device).split(",")[0] or 0))
         torch.cuda.set_device(self.device)
         self.early = EarlyStopping(patience)
         self.logger = ScalarLogger(args.log_dir, log_name, args, getattr(args, "restore_version", None), enabled=self.rank == 0)
@@ -103,7 +104,8 @@ class Trainer:
     def mean_over_ranks(self, value):
         if self.world == 1:
             return value
-        t = torch.tensor([value], dtype=torch.float64, device=self.device)
+        on_dev = torch.distributed.get_backend() == "nccl"
+        t = torch.tensor([value], dtype=torch.float64, device=self.device if on_dev else "cpu")
         torch.distributed.all_reduce(t)
         return float(t.item()) / self.world
 

@@ -60,6 +60,26 @@ int cst_gemm(const float* A, long lda, int a_kmajor, const float* B, long ldb, i
 int cst_gemm_profile_enable(int on);
 int cst_gemm_profile_read(double* total_ms_host, double* total_flops_host, double* total_min_bytes_host, long* launches_host);
 
+/* bf16-operand NT GEMM with direct-to-LDS (global_load_lds) staging in a 3-stage ring:
+ * C[M,N] (fp32) and/or Cb[M,N] (bf16) = epilogue(alpha * A[M,K] . B[N,K]^T); A, B bf16 (uint16 storage),
+ * K contiguous and a multiple of 64 (zero padding is written by cst_cast_bf16), lda/ldb multiples of
+ * 8, 16-byte aligned.  Epilogue as cst_gemm (aux is bf16).  The encoder layers' QKV / out-proj / FFN
+ * products (mlm.py:20-22, match.py:18-20) run on it in bf16 mode: forward as is, dgrad with the
+ * transposed weight copy, wgrad with the transposed activation copies -- all NT. */
+int cst_gemm_bf16(const void* A, long lda, const void* B, long ldb,
+                  float* C, long ldc, void* Cb, long ldcb, int M, int N, int K,
+                  const float* bias, const float* addend, long ldadd, const void* aux, long ldaux,
+                  int act, float gate_scale, float alpha,
+                  float drop_p, uint32_t drop_seed, uint32_t drop_stream, const void* drop_seed_dev,
+                  int tile, int splitk, float* workspace, long workspace_floats, void* stream);
+/* out[r, 0..ldo) = bf16(x[r,:] * dropmask) zero-padded, out_t[c, 0..ldot) = the transpose zero-padded
+ * (either may be null); x is fp32, or bf16 when x_is_bf16 (pure transpose). */
+int cst_cast_bf16(const void* x, int x_is_bf16, long ldx, int R, int C,
+                  void* out, long ldo, void* out_t, long ldot,
+                  float drop_p, uint32_t drop_seed, uint32_t drop_stream, const void* drop_seed_dev, void* stream);
+/* out[c] = sum_r X[r,c] for a bf16 matrix (fp32 sums). */
+int cst_colsum_bf16(const void* X, long ld, int M, int N, float* out, void* stream);
+
 /* Fused token cross-entropy forward + backward: row_loss[r] = logsumexp(x_r) - x_r[target_r];
  * dlogits = grad_scale * (softmax(x_r) - onehot(target_r)) (may alias logits; null = forward
  * only).  Rows with a target outside [0,V) contribute 0.  Replaces nn.CrossEntropyLoss at

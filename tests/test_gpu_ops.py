@@ -74,6 +74,60 @@ def test_gemm_splitk(ops, prec, shape, akm, bkm):
     ops.set_precision("bf16")
 
 
+def _bf16_round(t):
+    return t.to(torch.bfloat16).float()
+
+
+@pytest.mark.parametrize("R,C", [(5, 7), (64, 64), (100, 130), (4608, 512), (37, 2048)])
+def test_cast_bf16(ops, R, C):
+    x = rnd(R, C, seed=1)
+    rm, tr = ops.cast_bf16(dev(x))
+    ref = _bf16_round(x)
+    got = rm.view(torch.bfloat16).float().cpu()
+    assert got.shape == (R, (C + 63) // 64 * 64)
+    assert torch.equal(got[:, :C], ref) and float(got[:, C:].abs().sum()) == 0.0
+    gt = tr.view(torch.bfloat16).float().cpu()
+    assert gt.shape == (C, (R + 63) // 64 * 64)
+    assert torch.equal(gt[:, :R], ref.t()) and float(gt[:, R:].abs().sum()) == 0.0
+    # dropout in the cast == oracle mask; bf16 -> bf16 transpose
+    d = ops.Drop(0.25, 3, 1003)
+    rm2, _ = ops.cast_bf16(dev(x), want_t=False, drop=d)
+    mask = torch.from_numpy(orng.dropout_mask(3, 1003, (R, C), 0.25))
+    assert torch.equal(rm2.view(torch.bfloat16).float().cpu()[:, :C], _bf16_round(x * mask))
+    _, t2 = ops.cast_bf16(rm[:, :C], want_rm=False)
+    assert torch.equal(t2.view(torch.bfloat16).float().cpu()[:, :R], ref.t())
+    close(ops.colsum_bf16(rm, C), ref.sum(0), 1e-3, 1e-2)
+
+
+@pytest.mark.parametrize("shape", [(37, 53, 19), (256, 512, 128), (700, 390, 100), (9216, 2048, 512), (4608, 512, 2048),
+                                   (2048, 512, 9216), (256, 2048, 640), (256, 512, 1024), (130, 10000, 64), (64, 64, 10000)])
+@pytest.mark.parametrize("tile", [0, 64, 128])
+def test_gemm_bf16(ops, shape, tile):
+    M, N, K = shape
+    A, B = rnd(M, K, seed=1), rnd(N, K, seed=2)
+    Ab, _ = ops.cast_bf16(dev(A), want_t=False)
+    Bb, _ = ops.cast_bf16(dev(B), want_t=False)
+    ref = _bf16_round(A) @ _bf16_round(B).t()
+    C = torch.full((M, N), float("nan"), device="cuda")
+    ops.gemm_bf16(Ab, Bb, M, N, C=C, tile=tile)
+    close(C, ref, 2e-3, 2e-3 * math.sqrt(K), f"{shape}")
+    # epilogue: bias + addend + gate by a bf16 aux + bf16 output
+    bias, add, aux = rnd(N, seed=3), rnd(M, N, seed=4), rnd(M, N, seed=5)
+    auxb, _ = ops.cast_bf16(dev(aux), want_t=False)
+    Cb = torch.zeros(M, (N + 63) // 64 * 64, device="cuda", dtype=torch.int16)
+    C2 = torch.empty(M, N, device="cuda")
+    ops.gemm_bf16(Ab, Bb, M, N, C=C2, Cb=Cb, bias=dev(bias), addend=dev(add), aux=auxb, act=3, gate_scale=1.25, tile=tile)
+    ref2 = torch.where(_bf16_round(aux) > 0, (ref + bias + add) * 1.25, torch.zeros_like(ref))
+    close(C2, ref2, 2e-3, 2e-3 * math.sqrt(K))
+    close(Cb.view(torch.bfloat16).float()[:, :N], ref2, 1e-2, 1e-2 * math.sqrt(K))
+    # relu + dropout epilogue, bf16-only output
+    d = ops.Drop(0.3, 11, 1002)
+    Cb3 = torch.zeros(M, (N + 63) // 64 * 64, device="cuda", dtype=torch.int16)
+    ops.gemm_bf16(Ab, Bb, M, N, Cb=Cb3, bias=dev(bias), act=1, drop=d, tile=tile)
+    mask = torch.from_numpy(orng.dropout_mask(11, 1002, (M, N), 0.3))
+    close(Cb3.view(torch.bfloat16).float()[:, :N], torch.relu(ref + bias) * mask, 1e-2, 1e-2 * math.sqrt(K))
+
+
 @pytest.mark.parametrize("tile", [64, 128])
 def test_gemm_epilogues(ops, tile):
     ops.set_precision("f32")

@@ -52,5 +52,39 @@ def main():
               + f"   best {fl / best / 1e6:7.1f} TF/s  {by / best / 1e6:5.2f} TB/s(min-traffic)")
 
 
+def main_bf16():
+    print("---- bf16-operand NT GEMM (global_load_lds ring); tile codes: 0 auto, 64/128 3-stage, 65/129 2-stage")
+    for M, N, K, akm, bkm, note in SHAPES:
+        A, B = torch.randn(M, K, device="cuda"), torch.randn(N, K, device="cuda")
+        Ab, _ = ops.cast_bf16(A, want_t=False)
+        Bb, _ = ops.cast_bf16(B, want_t=False)
+        C = torch.empty(M, N, device="cuda")
+        res = []
+        tiles = [0, 64, 65, 128, 129]
+        for tile in tiles:
+            for _ in range(3):
+                ops.gemm_bf16(Ab, Bb, M, N, C=C, tile=tile)
+            torch.cuda.synchronize()
+            n = 20
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                for _ in range(n):
+                    ops.gemm_bf16(Ab, Bb, M, N, C=C, tile=tile)
+            g.replay()
+            torch.cuda.synchronize()
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            g.replay()
+            b.record()
+            torch.cuda.synchronize()
+            res.append(a.elapsed_time(b) * 1000 / n)
+        fl = 2.0 * M * N * K
+        best = min(res)
+        print(f"{note:18s} {M:6d}x{N:5d}x{K:5d}  " + "  ".join(f"t{t}:{u:7.1f}us" for t, u in zip(tiles, res)) + f"   best {fl / best / 1e6:7.1f} TF/s")
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "bf16nt":
+        main_bf16()
+        sys.exit(0)
     main()
