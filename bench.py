@@ -222,20 +222,29 @@ def main():
             run_step(stages_, batches, args.warmup + args.steps + it, None)
         torch.cuda.synchronize()
         _lib.gemm_profile(False)
-        ms, flops, min_bytes, n = _lib.gemm_profile_read()
-        if n and ms > 0:
+        prof = _lib.gemm_profile_read()
+        pmc_path = os.path.join(REPO, "profiles", "round1_pmc_traffic.json")
+        pmc = json.load(open(pmc_path))["kernels"] if os.path.exists(pmc_path) else {}
+        kernels = {}
+        for name, (ms, flops, min_bytes, n) in prof.items():
+            if not n or ms <= 0:
+                continue
             ach = flops / (ms * 1e-3) / 1e12
-            traffic = None
-            pmc_path = os.path.join(REPO, "profiles", "round1_pmc_traffic.json")
-            if os.path.exists(pmc_path):            # HBM bytes per launch from the rocprofv3 --pmc passes of this command
-                k = json.load(open(pmc_path))["kernels"].get("cst_gemm_kernel")
-                if k:
-                    traffic = k["fetch_bytes_per_launch"] + k["write_bytes_per_launch"]
-            roofline = {"bound": "mfma", "kernel": "cst_gemm_kernel (bf16 v_mfma_f32_16x16x32, all operand layouts)",
-                        "achieved": ach, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / MFMA_PEAK_TFLOPS,
-                        "traffic": traffic, "launches_per_step": n / nprof, "avg_launch_us": 1000.0 * ms / n,
-                        "flops_per_launch": flops / n, "min_operand_bytes_per_launch": min_bytes / n,
-                        "kernel_ms_per_step": ms / nprof}
+            k = pmc.get(name)
+            kernels[name] = {"achieved": ach, "frac": ach / MFMA_PEAK_TFLOPS, "launches_per_step": n / nprof,
+                             "avg_launch_us": 1000.0 * ms / n, "flops_per_launch": flops / n,
+                             "min_operand_bytes_per_launch": min_bytes / n, "kernel_ms_per_step": ms / nprof,
+                             "traffic": (k["fetch_bytes_per_launch"] + k["write_bytes_per_launch"]) if k else None}
+        if kernels:
+            # the dominant kernel = the one with the most device time per step
+            dom = max(kernels, key=lambda k: kernels[k]["kernel_ms_per_step"])
+            d = kernels[dom]
+            roofline = {"bound": "mfma", "kernel": dom, "achieved": d["achieved"], "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                        "frac": d["frac"], "traffic": d["traffic"], "launches_per_step": d["launches_per_step"],
+                        "avg_launch_us": d["avg_launch_us"], "flops_per_launch": d["flops_per_launch"],
+                        "min_operand_bytes_per_launch": d["min_operand_bytes_per_launch"],
+                        "kernel_ms_per_step": d["kernel_ms_per_step"],
+                        "other_mfma_kernels": {k: v for k, v in kernels.items() if k != dom}}
         if args.breakdown:
             timer = _lib.KernelTimer(by_shape=True)
             _lib.set_timer(timer)

@@ -148,10 +148,13 @@ def gemm_profile(enable):
 
 
 def gemm_profile_read():
-    """-> (total kernel ms, total FLOP, total minimal operand bytes, launches) since enable."""
-    ms, fl, by = ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
-    n = ctypes.c_long()
-    rc = lib().fn["cst_gemm_profile_read"](ctypes.byref(ms), ctypes.byref(fl), ctypes.byref(by), ctypes.byref(n))
-    if rc != 0:
-        raise RuntimeError(lib().last_error())
-    return ms.value, fl.value, by.value, n.value
+    """-> {kernel: (total kernel ms, total FLOP, total minimal operand bytes, launches)} since enable."""
+    out = {}
+    for which, name in ((0, "cst_gemm_kernel"), (1, "cst_gemm_bf16_kernel")):
+        ms, fl, by = ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
+        n = ctypes.c_long()
+        rc = lib().fn["cst_gemm_profile_read"](which, ctypes.byref(ms), ctypes.byref(fl), ctypes.byref(by), ctypes.byref(n))
+        if rc != 0:
+            raise RuntimeError(lib().last_error())
+        out[name] = (ms.value, fl.value, by.value, n.value)
+    return out

@@ -414,9 +414,11 @@ __global__ __launch_bounds__(256) void cst_gemm_splitk_reduce(GemmArgs g) {
 // trace), so the measured duration excludes host launch gaps.
 #include <hip/hip_ext.h>
 #include <vector>
-struct GemmProf { hipEvent_t a, b; double flops; double bytes; };
+struct GemmProf { hipEvent_t a, b; double flops; double bytes; int which; };    // which: 0 cst_gemm_kernel, 1 cst_gemm_bf16_kernel
 static bool g_prof_on = false;
 static std::vector<GemmProf> g_prof;
+bool cst_prof_on() { return g_prof_on; }
+void cst_prof_push(hipEvent_t a, hipEvent_t b, double flops, double bytes, int which) { g_prof.push_back({a, b, flops, bytes, which}); }
 
 extern "C" int cst_gemm_profile_enable(int on) {
     if (on && !g_prof_on) g_prof.clear();
@@ -424,18 +426,23 @@ extern "C" int cst_gemm_profile_enable(int on) {
     return CST_OK;
 }
 
-// sums over the recorded launches; destroys the events
-extern "C" int cst_gemm_profile_read(double* total_ms, double* total_flops, double* total_min_bytes, long* launches) {
+// sums over the recorded launches of kernel `which` (0 = cst_gemm_kernel, 1 = cst_gemm_bf16_kernel);
+// reading with which = 1 also destroys all events and clears the record list
+extern "C" int cst_gemm_profile_read(int which, double* total_ms, double* total_flops, double* total_min_bytes, long* launches) {
     double ms = 0, fl = 0, by = 0;
+    long n = 0;
     for (auto& p : g_prof) {
+        if (p.which != which) continue;
         if (hipEventSynchronize(p.b) != hipSuccess) { cst_set_error("cst_gemm_profile_read: event sync failed"); return CST_ERR_LAUNCH; }
         float t = 0.f;
         (void)hipEventElapsedTime(&t, p.a, p.b);
-        ms += t; fl += p.flops; by += p.bytes;
-        (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b);
+        ms += t; fl += p.flops; by += p.bytes; ++n;
     }
-    *total_ms = ms; *total_flops = fl; *total_min_bytes = by; *launches = (long)g_prof.size();
-    g_prof.clear();
+    *total_ms = ms; *total_flops = fl; *total_min_bytes = by; *launches = n;
+    if (which == 1) {
+        for (auto& p : g_prof) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
+        g_prof.clear();
+    }
     return CST_OK;
 }
 
@@ -445,7 +452,7 @@ static void launch_cfg(const GemmArgs& g, int f32, int akm, int bkm, int batch, 
     hipEvent_t ea = nullptr, eb = nullptr;
     if (g_prof_on) {
         (void)hipEventCreate(&ea); (void)hipEventCreate(&eb);
-        g_prof.push_back({ea, eb, 2.0 * g.M * g.N * g.K * batch, 4.0 * ((double)g.M * g.K + (double)g.N * g.K + (double)g.M * g.N) * batch});
+        g_prof.push_back({ea, eb, 2.0 * g.M * g.N * g.K * batch, 4.0 * ((double)g.M * g.K + (double)g.N * g.K + (double)g.M * g.N) * batch, 0});
     }
 #define CST_GEMM_CASE(F, AK, BKM)                                                              \
     if (f32 == F && akm == AK && bkm == BKM) {                                                 \

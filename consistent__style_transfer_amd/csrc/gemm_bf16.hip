@@ -332,6 +332,11 @@ __global__ __launch_bounds__(256) void cst_gemm_bf16_reduce(BGemmArgs g) {
     }
 }
 
+// kernel-precise timing shared with gemm.hip (cst_gemm_profile_enable / _read)
+#include <hip/hip_ext.h>
+extern bool cst_prof_on();
+extern void cst_prof_push(hipEvent_t a, hipEvent_t b, double flops, double bytes, int which);
+
 template <int BM, int BN, int NSTAGE>
 static int bgemm_launch(const BGemmArgs& g, hipStream_t st) {
     const size_t lds = (size_t)NSTAGE * (BM + BN) * BROW;
@@ -341,7 +346,14 @@ static int bgemm_launch(const BGemmArgs& g, hipStream_t st) {
         attr_done = true;
     }
     dim3 grid(cst_div_up(g.M, BM) * cst_div_up(g.N, BN), g.splits), block(256);
-    hipLaunchKernelGGL((cst_gemm_bf16_kernel<BM, BN, NSTAGE>), grid, block, lds, st, g);
+    if (cst_prof_on()) {
+        hipEvent_t ea, eb;
+        (void)hipEventCreate(&ea); (void)hipEventCreate(&eb);
+        cst_prof_push(ea, eb, 2.0 * g.M * g.N * g.K, 2.0 * ((double)g.M * g.K + (double)g.N * g.K) + (g.C ? 4.0 : 0.0) * g.M * g.N + (g.Cb ? 2.0 : 0.0) * g.M * g.N, 1);
+        hipExtLaunchKernelGGL((cst_gemm_bf16_kernel<BM, BN, NSTAGE>), grid, block, lds, st, ea, eb, 0, g);
+    } else {
+        hipLaunchKernelGGL((cst_gemm_bf16_kernel<BM, BN, NSTAGE>), grid, block, lds, st, g);
+    }
     return 0;
 }
 

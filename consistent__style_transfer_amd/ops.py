@@ -115,6 +115,24 @@ def cast_bf16(x, want_rm=True, want_t=True, drop=NO_DROP):
     return rm, tr
 
 
+_WCACHE = {}
+
+
+def weight_bf16(W):
+    """bf16 row-major + transposed copies of a weight, cached until the weight changes: the key is
+    the torch in-place version (load_state_dict, .copy_) and the version of the optim.FlatGroup that
+    owns it (bumped by every Adam step, whose kernel writes through a raw pointer)."""
+    grp = getattr(W, "_cst_group", None)
+    ver = (W._version, grp.version if grp is not None else 0, W.data_ptr())
+    hit = _WCACHE.get(id(W))
+    if hit is not None and hit[0] == ver:
+        return hit[1], hit[2]
+    rm, tr = cast_bf16(W.detach())
+    if not torch.cuda.is_current_stream_capturing():
+        _WCACHE[id(W)] = (ver, rm, tr)               # never cache tensors that live in a graph's private pool
+    return rm, tr
+
+
 def gemm_bf16(Ab, Bb, M, N, C=None, Cb=None, bias=None, addend=None, aux=None, act=0, gate_scale=1.0, alpha=1.0,
               drop=NO_DROP, tile=0, splitk=0):
     """C / Cb [M,N] = epi(alpha * Ab[M,Kp] Bb[N,Kp]^T); Ab, Bb zero-padded bf16 from cast_bf16."""
@@ -374,22 +392,22 @@ class EncoderLayerBf16Fn(torch.autograd.Function):
         wg = in_w.requires_grad                       # frozen critics: no transposed activation copies needed
         new = lambda *s: torch.empty(*s, device=dev, dtype=torch.float32)
         xb, xt = cast_bf16(x, want_t=wg)
-        inw_b, inw_t = cast_bf16(in_w)
+        inw_b, inw_t = weight_bf16(in_w)
         qkv = gemm_bf16(xb, inw_b, T, 3 * d, C=new(T, 3 * d), bias=in_b)
         att, lse = new(T, d), new(B * H * S)
         call("cst_mha_fwd", qkv, att, lse, B, S, H, d // H, *drop.at(sb + 0).args())
         attb, attt = cast_bf16(att, want_t=wg)
-        outw_b, outw_t = cast_bf16(out_w)
+        outw_b, outw_t = weight_bf16(out_w)
         z1 = gemm_bf16(attb, outw_b, T, d, C=new(T, d), bias=out_b)
         y1, m1, r1 = new(T, d), new(T), new(T)
         _ln_fwd(z1, x, n1_w, n1_b, drop.at(sb + 1), z1, y1, m1, r1)
         y1b, y1t = cast_bf16(y1, want_t=wg)
-        l1_b16, l1_t = cast_bf16(l1_w)
+        l1_b16, l1_t = weight_bf16(l1_w)
         Fp = _up64(F)
         hb = (torch.zeros if Fp != F else torch.empty)(T, Fp, device=dev, dtype=torch.int16)
         gemm_bf16(y1b, l1_b16, T, F, Cb=hb, bias=l1_b, act=1, drop=drop.at(sb + 2))
         ht = cast_bf16(hb[:, :F], want_rm=False)[1] if wg else None
-        l2_b16, l2_t = cast_bf16(l2_w)
+        l2_b16, l2_t = weight_bf16(l2_w)
         z2 = gemm_bf16(hb, l2_b16, T, d, C=new(T, d), bias=l2_b)
         y2, m2, r2 = new(T, d), new(T), new(T)
         _ln_fwd(z2, y1, n2_w, n2_b, drop.at(sb + 3), z2, y2, m2, r2)

@@ -39,6 +39,9 @@ class FlatGroup:
         self.v = torch.zeros(tot, device=dev, dtype=torch.float32)
         self.step_dev = torch.zeros(1, device=dev, dtype=torch.int32)
         self.has_grad = False                             # flat_g holds gradients not yet consumed by a step
+        self.version = 0                                  # bumped by every step(): invalidates cached bf16 weight copies
+        for p in self.params:
+            p._cst_group = self
         ct, cs = [], []
         for t, n in enumerate(sizes):
             for s in range(0, n, MT_CHUNK):
@@ -79,6 +82,7 @@ class FlatGroup:
         call("cst_clip_scale", self.flat_g, self.total, sumsq, float(max_norm))
 
     def step(self):
+        self.version += 1
         call("cst_add_i32", self.step_dev, 1)
         call("cst_adam_step", self.flat_p, self.flat_g, self.m, self.v, self.total, float(self.lr),
              float(self.betas[0]), float(self.betas[1]), float(self.eps), self.step_dev)

@@ -54,11 +54,12 @@ int cst_gemm(const float* A, long lda, int a_kmajor, const float* B, long ldb, i
              float drop_p, uint32_t drop_seed, uint32_t drop_stream, const void* drop_seed_dev,
              int tile, int splitk, float* workspace, long workspace_floats, void* stream);
 
-/* Kernel-precise timing of cst_gemm_kernel for roofline reporting: while enabled every launch carries
- * a start and a stop HIP event bound to the dispatch (hipExtLaunchKernelGGL); the read call returns
- * the summed kernel time, FLOPs (2MNK) and minimal operand bytes 4(MK+NK+MN).  Not capture-safe. */
+/* Kernel-precise timing of the two GEMM kernels for roofline reporting: while enabled every launch
+ * carries a start and a stop HIP event bound to the dispatch (hipExtLaunchKernelGGL); the read call
+ * returns the summed kernel time, FLOPs (2MNK) and minimal operand bytes of kernel `which`
+ * (0 = cst_gemm_kernel, 1 = cst_gemm_bf16_kernel; read 0 first, reading 1 clears).  Not capture-safe. */
 int cst_gemm_profile_enable(int on);
-int cst_gemm_profile_read(double* total_ms_host, double* total_flops_host, double* total_min_bytes_host, long* launches_host);
+int cst_gemm_profile_read(int which, double* total_ms_host, double* total_flops_host, double* total_min_bytes_host, long* launches_host);
 
 /* bf16-operand NT GEMM with direct-to-LDS (global_load_lds) staging in a 3-stage ring:
  * C[M,N] (fp32) and/or Cb[M,N] (bf16) = epilogue(alpha * A[M,K] . B[N,K]^T); A, B bf16 (uint16 storage),
