@@ -28,6 +28,8 @@ WORKLOADS = {
     "yelp_6l_d512_b256": dict(n_layer=6, d_model=512, n_head=8, B=256, L=18, V=10000),
     # BASELINE.json configs[3] per-GPU shard: 6-layer d=768, 256 sentences per GPU
     "yelp_6l_d768_b256": dict(n_layer=6, d_model=768, n_head=8, B=256, L=18, V=10000),
+    # BASELINE.json configs[2]: book corpus, 6-layer d=512, batch 512, max_len 30 (Matcher S = 60)
+    "book_6l_d512_b512": dict(n_layer=6, d_model=512, n_head=8, B=512, L=30, V=10000),
     # BASELINE.json configs[0]-shaped small case
     "yelp_2l_d256_b32": dict(n_layer=2, d_model=256, n_head=8, B=32, L=16, V=10000),
 }

@@ -128,13 +128,15 @@ __global__ __launch_bounds__(256) void mha_bwd_kernel(const float* __restrict__ 
                                                       int S, int H, float scale, CstDrop drop) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int HD4 = HD / 4;
-    const int SP = S + 1;
+    constexpr int RMAX = MHA_SMAX / 4;   // rows per wave (row i belongs to wave i % 4)
+    const int SP = (S + 3) / 4 * 4 + 4;  // row stride of the S x S images: multiple of 4 (b128 reads), keys >= S hold 0
     float* Qs = smem;                    // [S][HD]
     float* Ks = Qs + S * HD;             // [S][HD]
     float* Vs = Ks + S * HD;             // [S][HD]
     float* Os = Vs + S * HD;             // [S][HD]  (dO)
-    float* Pm = Os + S * HD;             // [S][S+1] dropped probabilities
-    float* Dm = Pm + S * SP;             // [S][S+1] dS
+    float* Dm = Os + S * HD;             // [S][SP]  dS[i][j]
+    float* DmT = Dm + S * SP;            // [S][SP]  dS[j][i]
+    float* PmT = DmT + S * SP;           // [S][SP]  Pd[j][i] (dropped probabilities, transposed)
     const int b = blockIdx.x / H, h = blockIdx.x % H;
     const int d = H * HD;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -147,6 +149,7 @@ __global__ __launch_bounds__(256) void mha_bwd_kernel(const float* __restrict__ 
         Vs[e] = base[(long)i * 3 * d + 2 * d + c];
         Os[e] = dob[(long)i * d + c];
     }
+    for (int e = threadIdx.x; e < 3 * S * SP; e += 256) Dm[e] = 0.f;      // zero incl. the padding keys
     __syncthreads();
     // pass 1: lane = key j; key and value rows in registers
     float kreg[HD], vreg[HD];
@@ -173,24 +176,46 @@ __global__ __launch_bounds__(256) void mha_bwd_kernel(const float* __restrict__ 
         const float dp = (lane < S) ? dpd * mask : 0.f;
         const float delta = wave_sum(dp * p);
         if (lane < S) {
-            Pm[i * SP + lane] = p * mask;
-            Dm[i * SP + lane] = p * (dp - delta) * scale;
+            const float dsv = p * (dp - delta) * scale;
+            Dm[i * SP + lane] = dsv;
+            DmT[lane * SP + i] = dsv;
+            PmT[lane * SP + i] = p * mask;
         }
     }
     __syncthreads();
-    // pass 2: lane = head-dim column c
+    // pass 2: lane = head-dim column c; each wave keeps its rows i = w, w+4, ... as accumulators and
+    // walks the keys 4 at a time: one broadcast b128 of the S x S image per row + 4 operand reads
+    // per 4 keys feed 4*rows FMAs.
     float* dq = dqkv + (long)b * S * 3 * d + h * HD;
+    const int S4 = (S + 3) / 4;
     for (int c = lane; c < HD; c += 64) {
-        for (int i = w; i < S; i += 4) {
-            float aq = 0.f, ak = 0.f, av = 0.f;
-            for (int j = 0; j < S; ++j) {
-                aq += Dm[i * SP + j] * Ks[j * HD + c];       // dQ[i][c]
-                ak += Dm[j * SP + i] * Qs[j * HD + c];       // dK[i][c] = sum_j dS[j][i] Q[j][c]
-                av += Pm[j * SP + i] * Os[j * HD + c];       // dV[i][c] = sum_j Pd[j][i] dO[j][c]
+#pragma unroll
+        for (int which = 0; which < 3; ++which) {
+            const float* img = which == 0 ? Dm : (which == 1 ? DmT : PmT);     // dQ = dS K ; dK = dS^T Q ; dV = Pd^T dO
+            const float* opr = which == 0 ? Ks : (which == 1 ? Qs : Os);
+            float acc[RMAX];
+#pragma unroll
+            for (int r = 0; r < RMAX; ++r) acc[r] = 0.f;
+            for (int j4 = 0; j4 < S4; ++j4) {
+                const int j = j4 * 4;
+                const float o0 = opr[j * HD + c];
+                const float o1 = (j + 1 < S) ? opr[(j + 1) * HD + c] : 0.f;
+                const float o2 = (j + 2 < S) ? opr[(j + 2) * HD + c] : 0.f;
+                const float o3 = (j + 3 < S) ? opr[(j + 3) * HD + c] : 0.f;
+#pragma unroll
+                for (int r = 0; r < RMAX; ++r) {
+                    const int i = w + 4 * r;
+                    if (i < S) {
+                        const float4 m4 = *reinterpret_cast<const float4*>(&img[i * SP + j]);
+                        acc[r] += m4.x * o0 + m4.y * o1 + m4.z * o2 + m4.w * o3;
+                    }
+                }
             }
-            dq[(long)i * 3 * d + c] = aq;
-            dq[(long)i * 3 * d + d + c] = ak;
-            dq[(long)i * 3 * d + 2 * d + c] = av;
+#pragma unroll
+            for (int r = 0; r < RMAX; ++r) {
+                const int i = w + 4 * r;
+                if (i < S) dq[(long)i * 3 * d + which * d + c] = acc[r];
+            }
         }
     }
 }
@@ -203,7 +228,7 @@ extern "C" int cst_mha_bwd(const float* qkv, const float* dout, const float* lse
     CST_REQUIRE(B > 0 && S > 0 && S <= MHA_SMAX && H > 0, "cst_mha_bwd: S=%d unsupported (max %d)", S, MHA_SMAX);
     CstDrop dr = cst_make_drop(drop_p, drop_seed, drop_stream, drop_seed_dev);
     const float scale = 1.0f / sqrtf((float)hd);
-    const size_t lds = sizeof(float) * ((size_t)4 * S * hd + (size_t)2 * S * (S + 1));
+    const size_t lds = sizeof(float) * ((size_t)4 * S * hd + (size_t)3 * S * ((S + 3) / 4 * 4 + 4));
     CST_REQUIRE(lds <= 160 * 1024, "cst_mha_bwd: LDS need %zu exceeds 160 KiB", lds);
     dim3 grid(B * H), block(256);
     hipStream_t st = (hipStream_t)stream;

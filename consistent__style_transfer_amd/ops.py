@@ -621,6 +621,9 @@ class ConvBankFn(torch.autograd.Function):
         saved, off = [], 0
         for w, b in zip(ws, bs):
             F_, k = w.shape[0], w.shape[2]
+            if mode == 1 and L < k:
+                raise RuntimeError(f"RelGAN_D convolution needs L >= k (sequence length {L} < filter size {k}; "
+                                   "discriminator.py:21-24 has no padding)")
             T = L + k - 1 if mode == 0 else L - k + 1
             KE = k * (E if mode == 0 else E // R)
             col = torch.empty(G * T, KE, device=dev, dtype=torch.float32)
