@@ -254,7 +254,7 @@ extern "C" int cst_mha_bwd(const float* qkv, const float* dout, const float* lse
 // from LDS.  Optionally also writes the dropped copy [q | out] * mask of the decoder's i_ffn
 // (rnn.py:78-79) so the step needs no separate dropout launch.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void dot_attn_fwd_kernel(const float* __restrict__ q, long ldq,
+__global__ __launch_bounds__(1024) void dot_attn_fwd_kernel(const float* __restrict__ q, long ldq,
                                                            const float* __restrict__ mem, float* __restrict__ out, long ldo,
                                                            float* __restrict__ p, int L, int D, float scale,
                                                            float* __restrict__ dropped, long lddrop, CstDrop drop) {
@@ -266,10 +266,10 @@ __global__ __launch_bounds__(256) void dot_attn_fwd_kernel(const float* __restri
     const float* qb = q + (long)b * ldq;
     const float4* mb4 = reinterpret_cast<const float4*>(mem + (long)b * L * D);
     const int n4 = L * D / 4;
-    for (int e = threadIdx.x; e < n4; e += 256) reinterpret_cast<float4*>(ms)[e] = mb4[e];
-    for (int c = threadIdx.x; c < D; c += 256) qs[c] = qb[c];
+    for (int e = threadIdx.x; e < n4; e += blockDim.x) reinterpret_cast<float4*>(ms)[e] = mb4[e];
+    for (int c = threadIdx.x; c < D; c += blockDim.x) qs[c] = qb[c];
     __syncthreads();
-    for (int j = w; j < L; j += 4) {
+    for (int j = w; j < L; j += (int)(blockDim.x >> 6)) {
         float s = 0.f;
         for (int c = lane; c < D; c += 64) s += qs[c] * ms[j * D + c];
         s = wave_sum(s);
@@ -288,7 +288,7 @@ __global__ __launch_bounds__(256) void dot_attn_fwd_kernel(const float* __restri
     }
     __syncthreads();
     const uint32_t dseed = drop.p > 0.f ? cst_drop_seed(drop) : 0u;
-    for (int c = threadIdx.x; c < D; c += 256) {
+    for (int c = threadIdx.x; c < D; c += blockDim.x) {
         float o = 0.f;
         for (int j = 0; j < L; ++j) o += sc[j] * ms[j * D + c];
         out[(long)b * ldo + c] = o;
@@ -313,14 +313,14 @@ extern "C" int cst_dot_attn_fwd(const float* q, long ldq, const float* mem, floa
     CST_REQUIRE(lds <= 160 * 1024, "cst_dot_attn_fwd: memory tile of %zu bytes exceeds the 160 KiB LDS", lds);
     CstDrop dr = cst_make_drop(drop_p, drop_seed, drop_stream, drop_seed_dev);
     if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)dot_attn_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(dot_attn_fwd_kernel, dim3(B), dim3(256), lds, (hipStream_t)stream, q, ldq, mem, out, ldo, p, L, D,
+    hipLaunchKernelGGL(dot_attn_fwd_kernel, dim3(B), dim3(B <= 1024 ? 1024 : 256), lds, (hipStream_t)stream, q, ldq, mem, out, ldo, p, L, D,
                        1.0f / sqrtf((float)D), dropped, lddrop, dr);
     CST_LAUNCH_CHECK("cst_dot_attn_fwd");
     return CST_OK;
 }
 
 // backward: dq (+)= sum_j ds_j mem_j ; dmem[j] += p_j dout + ds_j q   (dmem accumulates over steps)
-__global__ __launch_bounds__(256) void dot_attn_bwd_kernel(const float* __restrict__ dout, long lddo,
+__global__ __launch_bounds__(1024) void dot_attn_bwd_kernel(const float* __restrict__ dout, long lddo,
                                                            const float* __restrict__ q, long ldq,
                                                            const float* __restrict__ mem, const float* __restrict__ p,
                                                            float* __restrict__ dq, long lddq, int dq_accumulate,
@@ -335,11 +335,11 @@ __global__ __launch_bounds__(256) void dot_attn_bwd_kernel(const float* __restri
     const float* qb = q + (long)b * ldq;
     const float4* mb4 = reinterpret_cast<const float4*>(mem + (long)b * L * D);
     const int n4 = L * D / 4;
-    for (int e = threadIdx.x; e < n4; e += 256) reinterpret_cast<float4*>(ms)[e] = mb4[e];
-    for (int c = threadIdx.x; c < D; c += 256) gs[c] = gb[c];
+    for (int e = threadIdx.x; e < n4; e += blockDim.x) reinterpret_cast<float4*>(ms)[e] = mb4[e];
+    for (int c = threadIdx.x; c < D; c += blockDim.x) gs[c] = gb[c];
     if (threadIdx.x < L) ps[threadIdx.x] = p[(long)b * L + threadIdx.x];
     __syncthreads();
-    for (int j = w; j < L; j += 4) {
+    for (int j = w; j < L; j += (int)(blockDim.x >> 6)) {
         float s = 0.f;
         for (int c = lane; c < D; c += 64) s += gs[c] * ms[j * D + c];
         s = wave_sum(s);
@@ -352,7 +352,7 @@ __global__ __launch_bounds__(256) void dot_attn_bwd_kernel(const float* __restri
     if (threadIdx.x < L) ds[threadIdx.x] = ps[threadIdx.x] * (ds[threadIdx.x] - delta) * scale;
     __syncthreads();
     float* dmb = dmem + (long)b * L * D;
-    for (int c = threadIdx.x; c < D; c += 256) {
+    for (int c = threadIdx.x; c < D; c += blockDim.x) {
         const float g = gs[c], qc = qb[c];
         float a = 0.f;
         for (int j = 0; j < L; ++j) {
@@ -371,7 +371,7 @@ extern "C" int cst_dot_attn_bwd(const float* dout, long lddo, const float* q, lo
     const size_t lds = sizeof(float) * ((size_t)L * D + D + 128);
     CST_REQUIRE(lds <= 160 * 1024, "cst_dot_attn_bwd: memory tile of %zu bytes exceeds the 160 KiB LDS", lds);
     if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)dot_attn_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(dot_attn_bwd_kernel, dim3(B), dim3(256), lds, (hipStream_t)stream, dout, lddo, q, ldq, mem, p,
+    hipLaunchKernelGGL(dot_attn_bwd_kernel, dim3(B), dim3(B <= 1024 ? 1024 : 256), lds, (hipStream_t)stream, dout, lddo, q, ldq, mem, p,
                        dq, lddq, dq_accumulate, dmem, L, D, 1.0f / sqrtf((float)D));
     CST_LAUNCH_CHECK("cst_dot_attn_bwd");
     return CST_OK;

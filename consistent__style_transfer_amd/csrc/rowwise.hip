@@ -15,20 +15,20 @@
 // ---------------------------------------------------------------------------------------------
 // row loader: NV4 float4 per thread when the row is 16-byte addressable, else scalar strided.
 // ---------------------------------------------------------------------------------------------
-template <int NV4>
+template <int NV4, int NTH = ROW_THREADS>
 struct RowRegs {
     float4 v[NV4];
     __device__ __forceinline__ void load(const float* __restrict__ row, int V, float fill) {
 #pragma unroll
         for (int i = 0; i < NV4; ++i) {
-            const int c = (threadIdx.x + ROW_THREADS * i) * 4;
+            const int c = (threadIdx.x + NTH * i) * 4;
             v[i] = (c < V) ? *reinterpret_cast<const float4*>(row + c) : make_float4(fill, fill, fill, fill);
         }
     }
     __device__ __forceinline__ void store(float* __restrict__ row, int V) const {
 #pragma unroll
         for (int i = 0; i < NV4; ++i) {
-            const int c = (threadIdx.x + ROW_THREADS * i) * 4;
+            const int c = (threadIdx.x + NTH * i) * 4;
             if (c < V) *reinterpret_cast<float4*>(row + c) = v[i];
         }
     }
@@ -167,14 +167,14 @@ __device__ __forceinline__ void upd(float v, int i, float& bv, int& bi) {
 // ---------------------------------------------------------------------------------------------
 // temperature softmax + argmax(p)
 // ---------------------------------------------------------------------------------------------
-template <int NV4>
-__global__ __launch_bounds__(ROW_THREADS) void softmax_tau_vec_kernel(const float* __restrict__ logits, long ld, float inv_tau,
-                                                                      float* __restrict__ p, long ldp,
-                                                                      int64_t* __restrict__ amax, int V) {
+template <int NV4, int NTH = ROW_THREADS>
+__global__ __launch_bounds__(NTH) void softmax_tau_vec_kernel(const float* __restrict__ logits, long ld, float inv_tau,
+                                                              float* __restrict__ p, long ldp,
+                                                              int64_t* __restrict__ amax, int V) {
     __shared__ float red[16];
     __shared__ int redi[16];
     const long r = blockIdx.x;
-    RowRegs<NV4> x;
+    RowRegs<NV4, NTH> x;
     x.load(logits + r * ld, V, -INFINITY);
     float m = -INFINITY;
 #pragma unroll
@@ -195,7 +195,7 @@ __global__ __launch_bounds__(ROW_THREADS) void softmax_tau_vec_kernel(const floa
     float bv = -INFINITY; int bi = 0x7fffffff;
 #pragma unroll
     for (int i = 0; i < NV4; ++i) {
-        const int c = (threadIdx.x + ROW_THREADS * i) * 4;
+        const int c = (threadIdx.x + NTH * i) * 4;
         x.v[i].x /= s; x.v[i].y /= s; x.v[i].z /= s; x.v[i].w /= s;
         if (c < V) { upd(x.v[i].x, c, bv, bi); upd(x.v[i].y, c + 1, bv, bi); upd(x.v[i].z, c + 2, bv, bi); upd(x.v[i].w, c + 3, bv, bi); }
     }
@@ -236,7 +236,10 @@ extern "C" int cst_softmax_tau(const float* logits, long ld, float inv_tau, floa
     CST_REQUIRE(logits && p, "cst_softmax_tau: null pointer");
     CST_REQUIRE(R > 0 && V > 0 && ld >= V && ldp >= V, "cst_softmax_tau: bad shape");
     hipStream_t st = (hipStream_t)stream;
-    if (row_vec_ok(logits, ld, V) && row_vec_ok(p, ldp, V)) {
+    if (row_vec_ok(logits, ld, V) && row_vec_ok(p, ldp, V) && R <= 1024 && V > 4096 && V <= 12288) {
+        // few rows (one decode step): 1024-thread workgroups keep 4x the loads in flight per CU
+        hipLaunchKernelGGL((softmax_tau_vec_kernel<3, 1024>), dim3(R), dim3(1024), 0, st, logits, ld, inv_tau, p, ldp, argmax_out, V);
+    } else if (row_vec_ok(logits, ld, V) && row_vec_ok(p, ldp, V)) {
         ROW_DISPATCH(V, softmax_tau_vec_kernel, dim3(R), dim3(ROW_THREADS), 0, st, logits, ld, inv_tau, p, ldp, argmax_out, V);
     } else {
         hipLaunchKernelGGL(softmax_tau_generic_kernel, dim3(R), dim3(ROW_THREADS), 0, st, logits, ld, inv_tau, p, ldp, argmax_out, V);
@@ -246,13 +249,13 @@ extern "C" int cst_softmax_tau(const float* logits, long ld, float inv_tau, floa
 }
 
 // backward: dx = inv_tau * p * (dp - sum(dp * p));  dx may alias dp
-template <int NV4>
-__global__ __launch_bounds__(ROW_THREADS) void softmax_tau_bwd_vec_kernel(const float* __restrict__ p, long ldp,
-                                                                          const float* dp, long lddp, float inv_tau,
-                                                                          float* dx, long lddx, int V) {
+template <int NV4, int NTH = ROW_THREADS>
+__global__ __launch_bounds__(NTH) void softmax_tau_bwd_vec_kernel(const float* __restrict__ p, long ldp,
+                                                                  const float* dp, long lddp, float inv_tau,
+                                                                  float* dx, long lddx, int V) {
     __shared__ float red[16];
     const long r = blockIdx.x;
-    RowRegs<NV4> q, g;
+    RowRegs<NV4, NTH> q, g;
     q.load(p + r * ldp, V, 0.f);
     g.load(dp + r * lddp, V, 0.f);
     float s = 0.f;
@@ -284,7 +287,9 @@ extern "C" int cst_softmax_tau_bwd(const float* p, long ldp, const float* dp, lo
     CST_REQUIRE(p && dp && dx, "cst_softmax_tau_bwd: null pointer");
     CST_REQUIRE(R > 0 && V > 0 && ldp >= V && lddp >= V && lddx >= V, "cst_softmax_tau_bwd: bad shape");
     hipStream_t st = (hipStream_t)stream;
-    if (row_vec_ok(p, ldp, V) && row_vec_ok(dp, lddp, V) && row_vec_ok(dx, lddx, V) && V <= ROW_THREADS * 4 * 16) {
+    if (row_vec_ok(p, ldp, V) && row_vec_ok(dp, lddp, V) && row_vec_ok(dx, lddx, V) && R <= 1024 && V > 4096 && V <= 12288) {
+        hipLaunchKernelGGL((softmax_tau_bwd_vec_kernel<3, 1024>), dim3(R), dim3(1024), 0, st, p, ldp, dp, lddp, inv_tau, dx, lddx, V);
+    } else if (row_vec_ok(p, ldp, V) && row_vec_ok(dp, lddp, V) && row_vec_ok(dx, lddx, V) && V <= ROW_THREADS * 4 * 16) {
         const int nv4 = cst_div_up(V, ROW_THREADS * 4);
         if (nv4 <= 1) hipLaunchKernelGGL((softmax_tau_bwd_vec_kernel<1>), dim3(R), dim3(ROW_THREADS), 0, st, p, ldp, dp, lddp, inv_tau, dx, lddx, V);
         else if (nv4 <= 4) hipLaunchKernelGGL((softmax_tau_bwd_vec_kernel<4>), dim3(R), dim3(ROW_THREADS), 0, st, p, ldp, dp, lddp, inv_tau, dx, lddx, V);
@@ -300,20 +305,21 @@ extern "C" int cst_softmax_tau_bwd(const float* p, long ldp, const float* dp, lo
 // ---------------------------------------------------------------------------------------------
 // row argmax (first index among equal maxima), int64 out
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(ROW_THREADS) void argmax_kernel(const float* __restrict__ x, long ld, int V, int vec,
-                                                             int64_t* __restrict__ out) {
+__global__ __launch_bounds__(1024) void argmax_kernel(const float* __restrict__ x, long ld, int V, int vec,
+                                                      int64_t* __restrict__ out) {
     __shared__ float red[16];
     __shared__ int redi[16];
     const long r = blockIdx.x;
     const float* row = x + r * ld;
+    const int nth = blockDim.x;
     float bv = -INFINITY; int bi = 0x7fffffff;
     if (vec) {
-        for (int c = threadIdx.x * 4; c < V; c += ROW_THREADS * 4) {
+        for (int c = threadIdx.x * 4; c < V; c += nth * 4) {
             const float4 t = *reinterpret_cast<const float4*>(row + c);
             upd(t.x, c, bv, bi); upd(t.y, c + 1, bv, bi); upd(t.z, c + 2, bv, bi); upd(t.w, c + 3, bv, bi);
         }
     } else {
-        for (int c = threadIdx.x; c < V; c += ROW_THREADS) upd(row[c], c, bv, bi);
+        for (int c = threadIdx.x; c < V; c += nth) upd(row[c], c, bv, bi);
     }
     block_argmax(bv, bi, red, redi);
     if (threadIdx.x == 0) out[r] = bi == 0x7fffffff ? 0 : bi;
@@ -322,7 +328,8 @@ __global__ __launch_bounds__(ROW_THREADS) void argmax_kernel(const float* __rest
 extern "C" int cst_argmax_rows(const float* x, long ld, int R, int V, int64_t* out, void* stream) {
     CST_REQUIRE(x && out && R > 0 && V > 0 && ld >= V, "cst_argmax_rows: bad arguments");
     const int vec = (((uintptr_t)x & 15) == 0) && (ld % 4 == 0) && (V % 4 == 0);
-    hipLaunchKernelGGL(argmax_kernel, dim3(R), dim3(ROW_THREADS), 0, (hipStream_t)stream, x, ld, V, vec, out);
+    const int nth = (R <= 1024 && V >= 4096) ? 1024 : ROW_THREADS;
+    hipLaunchKernelGGL(argmax_kernel, dim3(R), dim3(nth), 0, (hipStream_t)stream, x, ld, V, vec, out);
     CST_LAUNCH_CHECK("cst_argmax_rows");
     return CST_OK;
 }

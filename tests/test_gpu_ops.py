@@ -218,7 +218,7 @@ def test_softmax_tau(ops, R, V, tau):
     (torch.softmax(xr / tau, -1) * dp).sum().backward()
     dx = torch.empty(R, V, device="cuda")
     ops.softmax_tau_bwd(p, dev(dp), 1.0 / tau, dx)
-    close(dx, xr.grad, 5e-4, 1e-7)
+    close(dx, xr.grad, 5e-4, 1e-5)      # p*(dp - sum(dp p)) cancels; the sum order depends on the workgroup width
 
 
 def test_argmax_ties_first_index(ops):
