@@ -24,3 +24,5 @@ def pre_batch(c, it):
 
 
 HP = dict(w_s=0.1, w_c=0.5, w_adv=1.0, w_bt=1.0, tau=0.1, gap=0.0)
+
+CURVE_LR = {"tiny": 1e-3, "ref": 1e-5}      # as tests/golden/make_golden.py

@@ -279,13 +279,18 @@ def step_goldens(name, c):
     return out
 
 
+CURVE_LR = {"tiny": 1e-3, "ref": 1e-5}      # tiny: raised so the optimiser dynamics show; ref: the reference's own lr
+
+
 def curve_goldens(name, c, steps):
     """Multi-step loss curves of the three stages in deterministic mode (dropout 0, recorded
     coins, seeded batches), with the Trainer semantics restated from pytorch_lightning 0.6/0.7 as
     the build's contract: per optimizer, only its parameters require
     grad; backward; clip_grad_norm_ over every parameter that holds a gradient; G steps every
     batch, D steps and zeroes only when batch_idx % 4 == 0 (main_optimize.py:78-88).
-    lr is raised to 1e-3 for optimize/pretrain so that 20 steps visibly move the losses."""
+    lr: CURVE_LR -- raised to 1e-3 on the tiny config so that 20 steps visibly move the losses (and
+    exercise Adam / clipping); the reference-size config keeps the reference's 1e-5, because with
+    1e-3 rounding-level gradient differences are amplified chaotically within ~4 steps."""
     out = {}
     V, B, L = c["V"], c["B"], c["L"]
     ce, mse, bce = nn.CrossEntropyLoss(), nn.MSELoss(), nn.BCEWithLogitsLoss()
@@ -311,8 +316,9 @@ def curve_goldens(name, c, steps):
     # ---- optimize ------------------------------------------------------------------------
     G, C, Mt, Dn, D = build(c)
     allm = (G, C, Mt, Dn, D)
-    og = torch.optim.Adam(G.parameters(), lr=1e-3)
-    od = torch.optim.Adam(D.parameters(), lr=1e-3)
+    lr = CURVE_LR[name]
+    og = torch.optim.Adam(G.parameters(), lr=lr)
+    od = torch.optim.Adam(D.parameters(), lr=lr)
     rows = []
     for it in range(steps):
         x, labels = batch_of(it)
@@ -355,7 +361,7 @@ def curve_goldens(name, c, steps):
     G, C, Mt, Dn, D = build(c)
     for p in G.parameters():
         p.requires_grad_(True)
-    ow = torch.optim.Adam(G.parameters(), lr=1e-3)
+    ow = torch.optim.Adam(G.parameters(), lr=lr)
     rows = []
     for it in range(steps):
         x, labels = batch_of(it)
@@ -376,7 +382,7 @@ def curve_goldens(name, c, steps):
     ps = list(C.parameters()) + list(Mt.parameters()) + list(Dn.parameters())
     for p in ps:
         p.requires_grad_(True)
-    op = torch.optim.Adam(ps, lr=1e-3)
+    op = torch.optim.Adam(ps, lr=lr)
     rows = []
     for it in range(steps):
         x, labels = batch_of(it)

@@ -10,7 +10,7 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
-from curve_inputs import HP, opt_batch, pre_batch, warm_batch  # noqa: E402
+from curve_inputs import CURVE_LR, HP, opt_batch, pre_batch, warm_batch  # noqa: E402
 from helpers import CONFIGS, SEEDS, load_golden  # noqa: E402
 from oracle.detinit import det_state_dict  # noqa: E402
 from test_gpu_modules import set_constants  # noqa: E402
@@ -119,7 +119,7 @@ def test_optimize_loss_curve_ref_config():
     ops.set_precision("f32")
     name = "ref"
     c, G = CONFIGS[name], load_golden("curves", name)
-    st = make_opt(name, lr=1e-3)
+    st = make_opt(name, lr=CURVE_LR[name])
     rows = []
     for it in range(G["optimize.curve"].shape[0]):
         lg = st.train_step(cu(opt_batch(c, it)), it, coins=G["optimize.coins"][it])
