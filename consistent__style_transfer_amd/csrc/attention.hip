@@ -257,7 +257,8 @@ extern "C" int cst_mha_bwd(const float* qkv, const float* dout, const float* lse
 __global__ __launch_bounds__(1024) void dot_attn_fwd_kernel(const float* __restrict__ q, long ldq,
                                                            const float* __restrict__ mem, float* __restrict__ out, long ldo,
                                                            float* __restrict__ p, int L, int D, float scale,
-                                                           float* __restrict__ dropped, long lddrop, CstDrop drop) {
+                                                           float* __restrict__ dropped, long lddrop,
+                                                           unsigned short* __restrict__ dropped_b, long lddropb, CstDrop drop) {
     extern __shared__ __attribute__((aligned(16))) float dsm[];
     float* ms = dsm;                 // [L][D]
     float* qs = ms + L * D;          // [D]
@@ -292,19 +293,27 @@ __global__ __launch_bounds__(1024) void dot_attn_fwd_kernel(const float* __restr
         float o = 0.f;
         for (int j = 0; j < L; ++j) o += sc[j] * ms[j * D + c];
         out[(long)b * ldo + c] = o;
-        if (dropped) {
+        if (dropped || dropped_b) {
             // dropout index space is the (B, 2D) matrix [q | out]
-            float* dr = dropped + (long)b * lddrop;
             const float mq = drop.p > 0.f ? cst_drop_mask(drop, dseed, (uint32_t)((long)b * 2 * D + c)) : 1.f;
             const float mo = drop.p > 0.f ? cst_drop_mask(drop, dseed, (uint32_t)((long)b * 2 * D + D + c)) : 1.f;
-            dr[c] = qs[c] * mq;
-            dr[D + c] = o * mo;
+            if (dropped) {
+                float* dr = dropped + (long)b * lddrop;
+                dr[c] = qs[c] * mq;
+                dr[D + c] = o * mo;
+            }
+            if (dropped_b) {                                       // bf16 copy: A operand of fn_1
+                unsigned short* db = dropped_b + (long)b * lddropb;
+                __bf16 h0 = (__bf16)(qs[c] * mq), h1 = (__bf16)(o * mo);
+                db[c] = __builtin_bit_cast(unsigned short, h0);
+                db[D + c] = __builtin_bit_cast(unsigned short, h1);
+            }
         }
     }
 }
 
 extern "C" int cst_dot_attn_fwd(const float* q, long ldq, const float* mem, float* out, long ldo, float* p,
-                                int B, int L, int D, float* dropped, long lddrop,
+                                int B, int L, int D, float* dropped, long lddrop, void* dropped_bf16, long lddropb,
                                 float drop_p, uint32_t drop_seed, uint32_t drop_stream, const void* drop_seed_dev,
                                 void* stream) {
     CST_REQUIRE(q && mem && out && p, "cst_dot_attn_fwd: null pointer");
@@ -314,7 +323,7 @@ extern "C" int cst_dot_attn_fwd(const float* q, long ldq, const float* mem, floa
     CstDrop dr = cst_make_drop(drop_p, drop_seed, drop_stream, drop_seed_dev);
     if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)dot_attn_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(dot_attn_fwd_kernel, dim3(B), dim3(B <= 1024 ? 1024 : 256), lds, (hipStream_t)stream, q, ldq, mem, out, ldo, p, L, D,
-                       1.0f / sqrtf((float)D), dropped, lddrop, dr);
+                       1.0f / sqrtf((float)D), dropped, lddrop, (unsigned short*)dropped_bf16, lddropb, dr);
     CST_LAUNCH_CHECK("cst_dot_attn_fwd");
     return CST_OK;
 }

@@ -128,6 +128,7 @@ struct BGemmArgs {
     long lda, ldb, ldc, ldcb, ldadd, ldaux;
     int M, N, K;                    // K multiple of 64
     int act;                        // 0 none, 1 relu, 2 leaky(0.1), 3 aux>0 ? v*gate_scale : 0, 4 aux>0 ? v : 0.1 v
+    int accumulate;                 // C += v (fp32 output only)
     float alpha, gate_scale;
     CstDrop drop;
     int splits, k_per_split;        // k_per_split multiple of 64
@@ -158,7 +159,7 @@ __device__ __forceinline__ void bgemm_store(const BGemmArgs& g, uint32_t dseed, 
     else if (g.act == 3) v = bf162f(g.aux[(long)m * g.ldaux + n]) > 0.f ? v * g.gate_scale : 0.f;
     else if (g.act == 4) v = bf162f(g.aux[(long)m * g.ldaux + n]) > 0.f ? v : 0.1f * v;
     if (g.drop.p > 0.f) v *= cst_drop_mask(g.drop, dseed, (uint32_t)((long)m * g.N + n));
-    if (g.C) g.C[(long)m * g.ldc + n] = v;
+    if (g.C) { float* cp = g.C + (long)m * g.ldc + n; if (g.accumulate) v += *cp; *cp = v; }
     if (g.Cb) g.Cb[(long)m * g.ldcb + n] = f2bf16(v);
 }
 
@@ -287,7 +288,7 @@ __global__ __launch_bounds__(256) void cst_gemm_bf16_kernel(BGemmArgs g) {
             for (int r = 0; r < 4; ++r) Cs[(i * 16 + lq * 4 + r) * CLD + j * 16 + lr] = acc[i][j][r];
     __builtin_amdgcn_wave_barrier();
     constexpr int C4 = WN / 4;
-    const bool simple = !g.addend && g.act < 3 && g.drop.p <= 0.f;
+    const bool simple = !g.addend && g.act < 3 && g.drop.p <= 0.f && !g.accumulate;
     const bool vecC = g.C && (g.ldc % 4 == 0) && ((reinterpret_cast<uintptr_t>(g.C) & 15) == 0);
     const bool vecB = g.Cb && (g.ldcb % 4 == 0) && ((reinterpret_cast<uintptr_t>(g.Cb) & 7) == 0);
 #pragma unroll
@@ -360,7 +361,7 @@ static int bgemm_launch(const BGemmArgs& g, hipStream_t st) {
 extern "C" int cst_gemm_bf16(const void* A, long lda, const void* B, long ldb,
                              float* C, long ldc, void* Cb, long ldcb, int M, int N, int K,
                              const float* bias, const float* addend, long ldadd, const void* aux, long ldaux,
-                             int act, float gate_scale, float alpha,
+                             int act, float gate_scale, float alpha, int accumulate,
                              float drop_p, uint32_t drop_seed, uint32_t drop_stream, const void* drop_seed_dev,
                              int tile, int splitk, float* workspace, long workspace_floats, void* stream) {
     CST_REQUIRE(A && B && (C || Cb), "cst_gemm_bf16: null operand");
@@ -374,7 +375,7 @@ extern "C" int cst_gemm_bf16(const void* A, long lda, const void* B, long ldb,
     g.A = (const bf16_t*)A; g.B = (const bf16_t*)B; g.C = C; g.Cb = (bf16_t*)Cb;
     g.bias = bias; g.addend = addend; g.aux = (const bf16_t*)aux;
     g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.ldcb = ldcb; g.ldadd = ldadd; g.ldaux = ldaux;
-    g.M = M; g.N = N; g.K = K; g.act = act; g.alpha = alpha; g.gate_scale = gate_scale;
+    g.M = M; g.N = N; g.K = K; g.act = act; g.alpha = alpha; g.gate_scale = gate_scale; g.accumulate = accumulate;
     g.drop = cst_make_drop(drop_p, drop_seed, drop_stream, drop_seed_dev);
     // tile / ring / split choice (tools/gemm_bench.py bf16nt): the 2-stage ring with two workgroups per
     // CU beats the 3-stage one at these sizes; 64x128 tiles when they alone give >= 256 workgroups,

@@ -11,6 +11,8 @@
 #include "cst_common.h"
 
 #define EW_THREADS 256
+typedef unsigned short bf16_t;
+__device__ __forceinline__ bf16_t pw_f2bf(float f) { __bf16 b = (__bf16)f; return __builtin_bit_cast(unsigned short, b); }
 static inline dim3 ew_grid(long n) {
     long b = (n + EW_THREADS - 1) / EW_THREADS;
     if (b > 256 * 16) b = 256 * 16;
@@ -24,7 +26,8 @@ static inline dim3 ew_grid(long n) {
 // ---------------------------------------------------------------------------------------------
 __global__ void lstm_cell_fwd_kernel(float* __restrict__ gates, long ldg, const float* __restrict__ c_prev, long ldcp,
                                      float* __restrict__ h_out, long ldh, float* __restrict__ c_out, long ldc,
-                                     float* __restrict__ h_out2, long ldh2, int B, int H) {
+                                     float* __restrict__ h_out2, long ldh2,
+                                     bf16_t* __restrict__ hb, long ldhb, bf16_t* __restrict__ hb2, long ldhb2, int B, int H) {
     EW_LOOP(e, (long)B * H) {
         const long b = e / H, j = e % H;
         float* g = gates + b * ldg;
@@ -38,14 +41,17 @@ __global__ void lstm_cell_fwd_kernel(float* __restrict__ gates, long ldg, const 
         c_out[b * ldc + j] = c;
         h_out[b * ldh + j] = h;
         if (h_out2) h_out2[b * ldh2 + j] = h;
+        if (hb) hb[b * ldhb + j] = pw_f2bf(h);             // bf16 copies: A operands of the next step's GEMMs
+        if (hb2) hb2[b * ldhb2 + j] = pw_f2bf(h);
     }
 }
 
 extern "C" int cst_lstm_cell_fwd(float* gates, long ldg, const float* c_prev, long ldcp, float* h_out, long ldh,
-                                 float* c_out, long ldc, float* h_out2, long ldh2, int B, int H, void* stream) {
+                                 float* c_out, long ldc, float* h_out2, long ldh2,
+                                 void* h_bf16, long ldhb, void* h_bf16_2, long ldhb2, int B, int H, void* stream) {
     CST_REQUIRE(gates && c_prev && h_out && c_out && B > 0 && H > 0, "cst_lstm_cell_fwd: bad arguments");
     hipLaunchKernelGGL(lstm_cell_fwd_kernel, ew_grid((long)B * H), dim3(EW_THREADS), 0, (hipStream_t)stream,
-                       gates, ldg, c_prev, ldcp, h_out, ldh, c_out, ldc, h_out2, ldh2, B, H);
+                       gates, ldg, c_prev, ldcp, h_out, ldh, c_out, ldc, h_out2, ldh2, (bf16_t*)h_bf16, ldhb, (bf16_t*)h_bf16_2, ldhb2, B, H);
     CST_LAUNCH_CHECK("cst_lstm_cell_fwd");
     return CST_OK;
 }
@@ -56,7 +62,7 @@ __global__ void lstm_cell_bwd_kernel(const float* __restrict__ gates, long ldg, 
                                      const float* __restrict__ c_new, long ldcn,
                                      const float* __restrict__ dh, long lddh, const float* __restrict__ dh2, long lddh2,
                                      const float* dc, long lddc, float* __restrict__ dgates, long lddg,
-                                     float* dc_prev, long lddcp, int B, int H) {
+                                     float* dc_prev, long lddcp, bf16_t* __restrict__ dgb, long lddgb, int B, int H) {
     EW_LOOP(e, (long)B * H) {
         const long b = e / H, j = e % H;
         const float* g = gates + b * ldg;
@@ -66,20 +72,24 @@ __global__ void lstm_cell_bwd_kernel(const float* __restrict__ gates, long ldg, 
         if (dh2) dht += dh2[b * lddh2 + j];
         const float dct = (dc ? dc[b * lddc + j] : 0.f) + dht * o * (1.f - tc * tc);
         float* dg = dgates + b * lddg;
-        dg[j] = dct * gg * i * (1.f - i);
-        dg[H + j] = dct * c_prev[b * ldcp + j] * f * (1.f - f);
-        dg[2 * H + j] = dct * i * (1.f - gg * gg);
-        dg[3 * H + j] = dht * tc * o * (1.f - o);
+        const float g0 = dct * gg * i * (1.f - i), g1 = dct * c_prev[b * ldcp + j] * f * (1.f - f);
+        const float g2 = dct * i * (1.f - gg * gg), g3 = dht * tc * o * (1.f - o);
+        dg[j] = g0; dg[H + j] = g1; dg[2 * H + j] = g2; dg[3 * H + j] = g3;
+        if (dgb) {
+            bf16_t* q = dgb + b * lddgb;
+            q[j] = pw_f2bf(g0); q[H + j] = pw_f2bf(g1); q[2 * H + j] = pw_f2bf(g2); q[3 * H + j] = pw_f2bf(g3);
+        }
         dc_prev[b * lddcp + j] = dct * f;
     }
 }
 
 extern "C" int cst_lstm_cell_bwd(const float* gates, long ldg, const float* c_prev, long ldcp, const float* c_new, long ldcn,
                                  const float* dh, long lddh, const float* dh2, long lddh2, const float* dc, long lddc,
-                                 float* dgates, long lddg, float* dc_prev, long lddcp, int B, int H, void* stream) {
+                                 float* dgates, long lddg, float* dc_prev, long lddcp, void* dgates_bf16, long lddgb,
+                                 int B, int H, void* stream) {
     CST_REQUIRE(gates && c_prev && c_new && dgates && dc_prev && B > 0 && H > 0, "cst_lstm_cell_bwd: bad arguments");
     hipLaunchKernelGGL(lstm_cell_bwd_kernel, ew_grid((long)B * H), dim3(EW_THREADS), 0, (hipStream_t)stream,
-                       gates, ldg, c_prev, ldcp, c_new, ldcn, dh, lddh, dh2, lddh2, dc, lddc, dgates, lddg, dc_prev, lddcp, B, H);
+                       gates, ldg, c_prev, ldcp, c_new, ldcn, dh, lddh, dh2, lddh2, dc, lddc, dgates, lddg, dc_prev, lddcp, (bf16_t*)dgates_bf16, lddgb, B, H);
     CST_LAUNCH_CHECK("cst_lstm_cell_bwd");
     return CST_OK;
 }
@@ -91,7 +101,8 @@ extern "C" int cst_lstm_cell_bwd(const float* gates, long ldg, const float* c_pr
 // ---------------------------------------------------------------------------------------------
 __global__ void embed_gather_kernel(const int64_t* __restrict__ ids_a, const int64_t* __restrict__ ids_b, long ldb,
                                     const int* __restrict__ coin, const float* __restrict__ table, long ldt, int transposed,
-                                    float* __restrict__ out, long ldo, int R, int E, int V, CstDrop drop) {
+                                    float* __restrict__ out, long ldo, bf16_t* __restrict__ outb, long ldob,
+                                    int R, int E, int V, CstDrop drop) {
     const uint32_t dseed = drop.p > 0.f ? cst_drop_seed(drop) : 0u;
     EW_LOOP(e, (long)R * E) {
         const long r = e / E, c = e % E;
@@ -101,16 +112,18 @@ __global__ void embed_gather_kernel(const int64_t* __restrict__ ids_a, const int
         if (id >= 0 && id < V) v = transposed ? table[c * ldt + id] : table[id * ldt + c];
         if (drop.p > 0.f) v *= cst_drop_mask(drop, dseed, (uint32_t)e);
         out[r * ldo + c] = v;
+        if (outb) outb[r * ldob + c] = pw_f2bf(v);
     }
 }
 
 extern "C" int cst_embed_gather(const int64_t* ids_a, const int64_t* ids_b, long ldb, const int* coin_dev,
-                                const float* table, long ldt, int transposed, float* out, long ldo, int R, int E, int V,
+                                const float* table, long ldt, int transposed, float* out, long ldo,
+                                void* out_bf16, long ldob, int R, int E, int V,
                                 float drop_p, uint32_t drop_seed, uint32_t drop_stream, const void* drop_seed_dev, void* stream) {
     CST_REQUIRE((ids_a || ids_b) && table && out && R > 0 && E > 0, "cst_embed_gather: bad arguments");
     CstDrop dr = cst_make_drop(drop_p, drop_seed, drop_stream, drop_seed_dev);
     hipLaunchKernelGGL(embed_gather_kernel, ew_grid((long)R * E), dim3(EW_THREADS), 0, (hipStream_t)stream,
-                       ids_a, ids_b, ldb, coin_dev, table, ldt, transposed, out, ldo, R, E, V, dr);
+                       ids_a, ids_b, ldb, coin_dev, table, ldt, transposed, out, ldo, (bf16_t*)out_bf16, ldob, R, E, V, dr);
     CST_LAUNCH_CHECK("cst_embed_gather");
     return CST_OK;
 }

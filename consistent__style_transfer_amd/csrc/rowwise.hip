@@ -252,7 +252,7 @@ extern "C" int cst_softmax_tau(const float* logits, long ld, float inv_tau, floa
 template <int NV4, int NTH = ROW_THREADS>
 __global__ __launch_bounds__(NTH) void softmax_tau_bwd_vec_kernel(const float* __restrict__ p, long ldp,
                                                                   const float* dp, long lddp, float inv_tau,
-                                                                  float* dx, long lddx, int V) {
+                                                                  float* dx, long lddx, unsigned short* dxb, long lddxb, int V) {
     __shared__ float red[16];
     const long r = blockIdx.x;
     RowRegs<NV4, NTH> q, g;
@@ -268,35 +268,53 @@ __global__ __launch_bounds__(NTH) void softmax_tau_bwd_vec_kernel(const float* _
         g.v[i].z = inv_tau * q.v[i].z * (g.v[i].z - s); g.v[i].w = inv_tau * q.v[i].w * (g.v[i].w - s);
     }
     g.store(dx + r * lddx, V);
+    if (dxb) {                                    // bf16 copy: A operand of the fn_2 dgrad of this decode step
+#pragma unroll
+        for (int i = 0; i < NV4; ++i) {
+            const int c = (threadIdx.x + NTH * i) * 4;
+            if (c < V) {
+                __bf16 h0 = (__bf16)g.v[i].x, h1 = (__bf16)g.v[i].y, h2 = (__bf16)g.v[i].z, h3 = (__bf16)g.v[i].w;
+                uint2 u;
+                u.x = (uint32_t)__builtin_bit_cast(unsigned short, h0) | ((uint32_t)__builtin_bit_cast(unsigned short, h1) << 16);
+                u.y = (uint32_t)__builtin_bit_cast(unsigned short, h2) | ((uint32_t)__builtin_bit_cast(unsigned short, h3) << 16);
+                *reinterpret_cast<uint2*>(dxb + r * lddxb + c) = u;
+            }
+        }
+    }
 }
 
 __global__ __launch_bounds__(ROW_THREADS) void softmax_tau_bwd_generic_kernel(const float* __restrict__ p, long ldp,
                                                                               const float* dp, long lddp, float inv_tau,
-                                                                              float* dx, long lddx, int V) {
+                                                                              float* dx, long lddx, unsigned short* dxb, long lddxb, int V) {
     __shared__ float red[16];
     const long r = blockIdx.x;
     float s = 0.f;
     for (int c = threadIdx.x; c < V; c += ROW_THREADS) s += p[r * ldp + c] * dp[r * lddp + c];
     s = block_sum(s, red);
-    for (int c = threadIdx.x; c < V; c += ROW_THREADS)
-        dx[r * lddx + c] = inv_tau * p[r * ldp + c] * (dp[r * lddp + c] - s);
+    for (int c = threadIdx.x; c < V; c += ROW_THREADS) {
+        const float v = inv_tau * p[r * ldp + c] * (dp[r * lddp + c] - s);
+        dx[r * lddx + c] = v;
+        if (dxb) { __bf16 h = (__bf16)v; dxb[r * lddxb + c] = __builtin_bit_cast(unsigned short, h); }
+    }
 }
 
 extern "C" int cst_softmax_tau_bwd(const float* p, long ldp, const float* dp, long lddp, float inv_tau,
-                                   float* dx, long lddx, int R, int V, void* stream) {
+                                   float* dx, long lddx, void* dx_bf16, long lddxb, int R, int V, void* stream) {
+    unsigned short* dxb = (unsigned short*)dx_bf16;
+    CST_REQUIRE(!dxb || (lddxb >= V && lddxb % 4 == 0 && (((uintptr_t)dxb) & 7) == 0), "cst_softmax_tau_bwd: bad bf16 output");
     CST_REQUIRE(p && dp && dx, "cst_softmax_tau_bwd: null pointer");
     CST_REQUIRE(R > 0 && V > 0 && ldp >= V && lddp >= V && lddx >= V, "cst_softmax_tau_bwd: bad shape");
     hipStream_t st = (hipStream_t)stream;
     if (row_vec_ok(p, ldp, V) && row_vec_ok(dp, lddp, V) && row_vec_ok(dx, lddx, V) && R <= 1024 && V > 4096 && V <= 12288) {
-        hipLaunchKernelGGL((softmax_tau_bwd_vec_kernel<3, 1024>), dim3(R), dim3(1024), 0, st, p, ldp, dp, lddp, inv_tau, dx, lddx, V);
+        hipLaunchKernelGGL((softmax_tau_bwd_vec_kernel<3, 1024>), dim3(R), dim3(1024), 0, st, p, ldp, dp, lddp, inv_tau, dx, lddx, dxb, lddxb, V);
     } else if (row_vec_ok(p, ldp, V) && row_vec_ok(dp, lddp, V) && row_vec_ok(dx, lddx, V) && V <= ROW_THREADS * 4 * 16) {
         const int nv4 = cst_div_up(V, ROW_THREADS * 4);
-        if (nv4 <= 1) hipLaunchKernelGGL((softmax_tau_bwd_vec_kernel<1>), dim3(R), dim3(ROW_THREADS), 0, st, p, ldp, dp, lddp, inv_tau, dx, lddx, V);
-        else if (nv4 <= 4) hipLaunchKernelGGL((softmax_tau_bwd_vec_kernel<4>), dim3(R), dim3(ROW_THREADS), 0, st, p, ldp, dp, lddp, inv_tau, dx, lddx, V);
-        else if (nv4 <= 10) hipLaunchKernelGGL((softmax_tau_bwd_vec_kernel<10>), dim3(R), dim3(ROW_THREADS), 0, st, p, ldp, dp, lddp, inv_tau, dx, lddx, V);
-        else hipLaunchKernelGGL((softmax_tau_bwd_vec_kernel<16>), dim3(R), dim3(ROW_THREADS), 0, st, p, ldp, dp, lddp, inv_tau, dx, lddx, V);
+        if (nv4 <= 1) hipLaunchKernelGGL((softmax_tau_bwd_vec_kernel<1>), dim3(R), dim3(ROW_THREADS), 0, st, p, ldp, dp, lddp, inv_tau, dx, lddx, dxb, lddxb, V);
+        else if (nv4 <= 4) hipLaunchKernelGGL((softmax_tau_bwd_vec_kernel<4>), dim3(R), dim3(ROW_THREADS), 0, st, p, ldp, dp, lddp, inv_tau, dx, lddx, dxb, lddxb, V);
+        else if (nv4 <= 10) hipLaunchKernelGGL((softmax_tau_bwd_vec_kernel<10>), dim3(R), dim3(ROW_THREADS), 0, st, p, ldp, dp, lddp, inv_tau, dx, lddx, dxb, lddxb, V);
+        else hipLaunchKernelGGL((softmax_tau_bwd_vec_kernel<16>), dim3(R), dim3(ROW_THREADS), 0, st, p, ldp, dp, lddp, inv_tau, dx, lddx, dxb, lddxb, V);
     } else {
-        hipLaunchKernelGGL(softmax_tau_bwd_generic_kernel, dim3(R), dim3(ROW_THREADS), 0, st, p, ldp, dp, lddp, inv_tau, dx, lddx, V);
+        hipLaunchKernelGGL(softmax_tau_bwd_generic_kernel, dim3(R), dim3(ROW_THREADS), 0, st, p, ldp, dp, lddp, inv_tau, dx, lddx, dxb, lddxb, V);
     }
     CST_LAUNCH_CHECK("cst_softmax_tau_bwd");
     return CST_OK;

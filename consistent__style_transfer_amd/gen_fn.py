@@ -12,8 +12,9 @@ import torch
 
 from . import ops
 from ._lib import call
-from .ops import (NO_DROP, STREAM_G_EMB_IN, STREAM_G_FFN, STREAM_G_XT, act_bwd, argmax_rows, axpby, colsum, dgrad,
-                  dropout2d, embed_gather, embed_scatter_add, gemm, linear_fwd, softmax_tau, softmax_tau_bwd, wgrad)
+from .ops import (NO_DROP, STREAM_G_EMB_IN, STREAM_G_FFN, STREAM_G_XT, act_bwd, argmax_rows, axpby, cast_bf16, colsum,
+                  dgrad, dropout2d, embed_gather, embed_scatter_add, gemm, gemm_bf16, linear_fwd, softmax_tau,
+                  softmax_tau_bwd, weight_bf16, wgrad)
 
 PARAM_KEYS = (
     "start_embedding.weight", "token_embedding.weight", "enc_style_embedding.weight", "style_embedding.weight",
@@ -29,15 +30,29 @@ def _new(dev, *shape, dtype=torch.float32):
     return torch.empty(*shape, device=dev, dtype=dtype)
 
 
-def _cell_fwd(gates, c_prev, h_out, c_out, h_out2, B, H):
+def _st(t):
+    return t.stride(0) if t is not None else 0
+
+
+def _cell_fwd(gates, c_prev, h_out, c_out, h_out2, B, H, hb=None, hb2=None):
     call("cst_lstm_cell_fwd", gates, gates.stride(0), c_prev, c_prev.stride(0), h_out, h_out.stride(0),
-         c_out, c_out.stride(0), h_out2, h_out2.stride(0) if h_out2 is not None else 0, B, H)
+         c_out, c_out.stride(0), h_out2, _st(h_out2), hb, _st(hb), hb2, _st(hb2), B, H)
 
 
-def _cell_bwd(gates, c_prev, c_new, dh, dh2, dc, dgates, dc_prev, B, H):
+def _cell_bwd(gates, c_prev, c_new, dh, dh2, dc, dgates, dc_prev, B, H, dgb=None):
     call("cst_lstm_cell_bwd", gates, gates.stride(0), c_prev, c_prev.stride(0), c_new, c_new.stride(0),
-         dh, dh.stride(0) if dh is not None else 0, dh2, dh2.stride(0) if dh2 is not None else 0,
-         dc, dc.stride(0) if dc is not None else 0, dgates, dgates.stride(0), dc_prev, dc_prev.stride(0), B, H)
+         dh, _st(dh), dh2, _st(dh2), dc, _st(dc), dgates, dgates.stride(0), dc_prev, dc_prev.stride(0),
+         dgb, _st(dgb), B, H)
+
+
+def _bf16_ok(*dims):
+    """The direct-to-LDS GEMM needs every reduction length to be a multiple of 64 (one 128-byte LDS
+    row of bf16); the reference's module constants are, toy test sizes are not."""
+    return not ops._STATE["f32"] and all(d % 64 == 0 for d in dims)
+
+
+def _i16(dev, *shape):
+    return torch.empty(*shape, device=dev, dtype=torch.int16)
 
 
 class GeneratorFn(torch.autograd.Function):
@@ -82,8 +97,12 @@ class GeneratorFn(torch.autograd.Function):
         c_cat = _new(dev, B, 2 * H)
         zeros_c = torch.zeros(B, H, device=dev, dtype=torch.float32)
         mem2 = memory.view(B, Lp * 2 * H)
+        W_ = Hd + 2 * H
+        use_b = _bf16_ok(H, 4 * H, E + Hd, 4 * Hd, W_, Hd)      # bf16-operand GEMMs for the recurrent products
+        memb = _i16(dev, B, Lp * 2 * H) if use_b else None     # bf16 copy of the encoder states (A operand of h W_hh^T)
         for d, suf in enumerate(("", "_reverse")):
             w_ih, w_hh = P["encoder.weight_ih_l0" + suf], P["encoder.weight_hh_l0" + suf]
+            whh_b = weight_bf16(w_hh)[0] if use_b else None
             bsum = axpby(P["encoder.bias_ih_l0" + suf].view(1, -1), 1.0, P["encoder.bias_hh_l0" + suf].view(1, -1), 1.0).view(-1)
             xp = linear_fwd(emb, w_ih, bsum).view(B, Lp * 4 * H)        # (B, L', 4H)
             order = list(range(Lp)) if d == 0 else list(range(Lp - 1, -1, -1))
@@ -93,16 +112,22 @@ class GeneratorFn(torch.autograd.Function):
                     h_in = h0cat[:, d * H:(d + 1) * H]
                     c_in = zeros_c
                     axpby(h_in, 1.0, out=hp2[:, t * H:(t + 1) * H])
+                    h_in_b = cast_bf16(h_in, want_t=False)[0] if use_b else None
                 else:
                     tp = order[n - 1]
                     h_in = mem2[:, tp * 2 * H + d * H: tp * 2 * H + (d + 1) * H]
                     c_in = cenc[d, tp]
+                    h_in_b = memb[:, tp * 2 * H + d * H: tp * 2 * H + (d + 1) * H] if use_b else None
                 g = genc[d, t]
-                gemm(h_in, True, w_hh, True, g, B, 4 * H, H, addend=xp[:, t * 4 * H:(t + 1) * 4 * H])
+                if use_b:
+                    gemm_bf16(h_in_b, whh_b, B, 4 * H, C=g, addend=xp[:, t * 4 * H:(t + 1) * 4 * H])
+                else:
+                    gemm(h_in, True, w_hh, True, g, B, 4 * H, H, addend=xp[:, t * 4 * H:(t + 1) * 4 * H])
                 last = n == Lp - 1
                 c_out = c_cat[:, d * H:(d + 1) * H] if last else cenc[d, t]
                 h_next = None if last else hp2[:, order[n + 1] * H:(order[n + 1] + 1) * H]
-                _cell_fwd(g, c_in, mem2[:, t * 2 * H + d * H: t * 2 * H + (d + 1) * H], c_out, h_next, B, H)
+                _cell_fwd(g, c_in, mem2[:, t * 2 * H + d * H: t * 2 * H + (d + 1) * H], c_out, h_next, B, H,
+                          hb=memb[:, t * 2 * H + d * H: t * 2 * H + (d + 1) * H] if use_b else None)
 
         # ---- decoder initial state (rnn.py:67-69) --------------------------------------------
         c0 = linear_fwd(c_cat, P["transfer.weight"], None, act=2)
@@ -116,7 +141,16 @@ class GeneratorFn(torch.autograd.Function):
         axpby(h0d, 1.0, out=XH[0][:, E:])
         gdec = _new(dev, T, B, 4 * Hd)
         cdec = _new(dev, T, B, Hd)
-        W_ = Hd + 2 * H
+        if use_b:
+            wcat_b, wcat_t = cast_bf16(wcat)          # [4Hd, E+Hd] and its transpose for the dgrad
+            fn1_b = weight_bf16(P["fn_1.weight"])[0]
+            fn2_b = weight_bf16(P["fn_2.weight"])[0]
+            XHb = _i16(dev, T, B, E + Hd)
+            call("cst_cast_bf16", XH[0], 0, E + Hd, B, E + Hd, XHb[0], E + Hd, None, 0, 0.0, 0, 0, None)
+            ifdb = _i16(dev, B, T * W_)               # bf16 dropout(i_ffn), written by the attention kernel
+            r1b = _i16(dev, B, T * Hd)
+        else:
+            wcat_t = XHb = ifdb = r1b = None
         iffn = _new(dev, B, T, W_)                    # [h_t | a_t], batch-major like `out`
         iffn_d = _new(dev, B, T, W_) if drop.p > 0 else iffn
         if2, ifd2 = iffn.view(B, T * W_), iffn_d.view(B, T * W_)
@@ -128,46 +162,57 @@ class GeneratorFn(torch.autograd.Function):
         r12 = r1.view(B, T * Hd)
         x_c = x.contiguous() if x is not None else None
         for s in range(T):
-            gemm(XH[s], True, wcat, True, gdec[s], B, 4 * Hd, E + Hd, bias=bdec)
+            if use_b:
+                gemm_bf16(XHb[s], wcat_b, B, 4 * Hd, C=gdec[s], bias=bdec)
+            else:
+                gemm(XH[s], True, wcat, True, gdec[s], B, 4 * Hd, E + Hd, bias=bdec)
             c_in = c0 if s == 0 else cdec[s - 1]
             h_next = XH[s + 1][:, E:] if s + 1 < T else None
             i_s = if2[:, s * W_:(s + 1) * W_]
-            _cell_fwd(gdec[s], c_in, i_s[:, :Hd], cdec[s], h_next, B, Hd)
+            _cell_fwd(gdec[s], c_in, i_s[:, :Hd], cdec[s], h_next, B, Hd,
+                      hb2=XHb[s + 1][:, E:] if (use_b and s + 1 < T) else None)
             id_s = ifd2[:, s * W_:(s + 1) * W_]
             fd = drop.at(STREAM_G_FFN + s)
+            idb_s = ifdb[:, s * W_:(s + 1) * W_] if use_b else None
             call("cst_dot_attn_fwd", i_s[:, :Hd], T * W_, memory, i_s[:, Hd:], T * W_, patt[s], B, Lp, Hd,
-                 id_s if drop.p > 0 else None, T * W_, *fd.args())           # also writes dropout(i_ffn)
+                 id_s if drop.p > 0 else None, T * W_, idb_s, T * W_, *fd.args())   # also writes dropout(i_ffn) (+ bf16)
             r1s = r12[:, s * Hd:(s + 1) * Hd]
-            linear_fwd(id_s, P["fn_1.weight"], P["fn_1.bias"], act=2, out=r1s)
             o_s = out2[:, s * V:(s + 1) * V]
-            linear_fwd(r1s, P["fn_2.weight"], None, out=o_s)
+            if use_b:
+                r1b_s = r1b[:, s * Hd:(s + 1) * Hd]
+                gemm_bf16(idb_s, fn1_b, B, Hd, C=r1s, Cb=r1b_s, bias=P["fn_1.bias"], act=2)
+                gemm_bf16(r1b_s, fn2_b, B, V, C=o_s)
+            else:
+                linear_fwd(id_s, P["fn_1.weight"], P["fn_1.bias"], act=2, out=r1s)
+                linear_fwd(r1s, P["fn_2.weight"], None, out=o_s)
             if soft:
                 softmax_tau(o_s, inv_tau, o_s, ids_fb[s])
             else:
                 argmax_rows(o_s, ids_fb[s])
             if s + 1 < T:
                 xd = drop.at(STREAM_G_XT + s)
+                xb_next = XHb[s + 1][:, :E] if use_b else None
                 if soft or x_c is None:
-                    embed_gather(E_tok, XH[s + 1][:, :E], ids_a=ids_fb[s], drop=xd)
+                    embed_gather(E_tok, XH[s + 1][:, :E], ids_a=ids_fb[s], drop=xd, out_b=xb_next)
                 else:
                     embed_gather(E_tok, XH[s + 1][:, :E], ids_a=ids_fb[s], ids_b=x_c[:, s], ldb=T,
-                                 coin=coins[s:s + 1], drop=xd)
+                                 coin=coins[s:s + 1], drop=xd, out_b=xb_next)
 
-        ctx.cfg = (B, Lp, T, V, E, H, Hd, soft, inv_tau, drop, in_drop, inp.dim() == 3)
+        ctx.cfg = (B, Lp, T, V, E, H, Hd, soft, inv_tau, drop, in_drop, inp.dim() == 3, use_b)
         ctx.save_for_backward(*params, emb, ids_in, label_i, label, h0cat, memory, hprev, genc, cenc, c_cat, c0,
                               wcat, XH, gdec, cdec, iffn, iffn_d, patt, r1, out, ids_fb, x_c, coins, zeros_c,
-                              inp if inp.dim() == 3 else None)
+                              inp if inp.dim() == 3 else None, wcat_t, r1b)
         ctx.mark_non_differentiable(ids_fb)
         return out, ids_fb
 
     @staticmethod
     def backward(ctx, dout, _dids):
-        B, Lp, T, V, E, H, Hd, soft, inv_tau, drop, in_drop, soft_in = ctx.cfg
+        B, Lp, T, V, E, H, Hd, soft, inv_tau, drop, in_drop, soft_in, use_b = ctx.cfg
         sv = ctx.saved_tensors
         n = len(PARAM_KEYS)
         P = dict(zip(PARAM_KEYS, sv[:n]))
         (emb, ids_in, label_i, label, h0cat, memory, hprev, genc, cenc, c_cat, c0, wcat, XH, gdec, cdec, iffn,
-         iffn_d, patt, r1, out, ids_fb, x_c, coins, zeros_c, inp3) = sv[n:]
+         iffn_d, patt, r1, out, ids_fb, x_c, coins, zeros_c, inp3, wcat_t, r1b) = sv[n:]
         dev = dout.device
         E_tok = P["token_embedding.weight"]
         dout = dout.contiguous()                      # (B,T,V); in softmax mode rewritten in place to dlogits
@@ -192,6 +237,13 @@ class GeneratorFn(torch.autograd.Function):
         dXH = _new(dev, B, E + Hd)
         dxe = _new(dev, B, E)
         dc = _new(dev, B, Hd)
+        if use_b:
+            fn1_t = weight_bf16(P["fn_1.weight"])[1]                # [W_, Hd]
+            fn2_t = weight_bf16(P["fn_2.weight"])[1]                # [Hd, up64(V)]
+            dgdb = _i16(dev, B, 4 * Hd)
+            if soft:
+                dlb = torch.zeros(B, (V + 63) // 64 * 64, device=dev, dtype=torch.int16)    # K padding stays zero
+                dp1b = _i16(dev, B, Hd)
         for s in range(T - 1, -1, -1):
             dl = dout2[:, s * V:(s + 1) * V]
             if s + 1 < T:
@@ -211,14 +263,18 @@ class GeneratorFn(torch.autograd.Function):
                 else:
                     embed_scatter_add(dE, dXH[:, :E], ids_a=ids_fb[s], ids_b=x_c[:, s], ldb=T, coin=coins[s:s + 1], drop=xd)
             if soft:
-                softmax_tau_bwd(out2[:, s * V:(s + 1) * V], dl, inv_tau, dl)
+                softmax_tau_bwd(out2[:, s * V:(s + 1) * V], dl, inv_tau, dl, dx_b=dlb if use_b else None)
             diffn = df2[:, s * W_:(s + 1) * W_]
             fd = drop.at(STREAM_G_FFN + s)
             if soft:
                 r1s = r12[:, s * Hd:(s + 1) * Hd]
                 dp1s = dp12[:, s * Hd:(s + 1) * Hd]
-                dgrad(dl, P["fn_2.weight"], out=dp1s, aux=r1s, act=4)                   # through LeakyReLU
-                dgrad(dp1s, P["fn_1.weight"], out=diffn, drop=fd)                         # through dropout(i_ffn)
+                if use_b:
+                    gemm_bf16(dlb, fn2_t, B, Hd, C=dp1s, Cb=dp1b, aux=r1b[:, s * Hd:(s + 1) * Hd], act=4)   # through LeakyReLU
+                    gemm_bf16(dp1b, fn1_t, B, W_, C=diffn, drop=fd)                                          # through dropout(i_ffn)
+                else:
+                    dgrad(dl, P["fn_2.weight"], out=dp1s, aux=r1s, act=4)                   # through LeakyReLU
+                    dgrad(dp1s, P["fn_1.weight"], out=diffn, drop=fd)                         # through dropout(i_ffn)
             elif fd.p > 0:
                 dropout2d(diffn, fd, out=diffn)
             call("cst_dot_attn_bwd", diffn[:, Hd:], T * W_, if2[:, s * W_:s * W_ + Hd], T * W_, memory, patt[s],
@@ -226,8 +282,11 @@ class GeneratorFn(torch.autograd.Function):
             c_prev = c0 if s == 0 else cdec[s - 1]
             last = s == T - 1
             _cell_bwd(gdec[s], c_prev, cdec[s], diffn[:, :Hd], None if last else dXH[:, E:], None if last else dc,
-                      dgd[s], dc, B, Hd)
-            dgrad(dgd[s], wcat, out=dXH)
+                      dgd[s], dc, B, Hd, dgb=dgdb if use_b else None)
+            if use_b:
+                gemm_bf16(dgdb, wcat_t, B, E + Hd, C=dXH)
+            else:
+                dgrad(dgd[s], wcat, out=dXH)
         # step 0 input was the start embedding (no dropout), h_{-1} the style embedding
         G["start_embedding.weight"] = colsum(dXH[:, :E]).view(1, E)
         dstyle = torch.zeros_like(P["style_embedding.weight"])
@@ -257,8 +316,10 @@ class GeneratorFn(torch.autograd.Function):
         dge = _new(dev, 2, B, Lp, 4 * H)
         dhr = _new(dev, B, H)
         dce = _new(dev, B, H)
+        dgtb = _i16(dev, B, 4 * H) if use_b else None
         for d, suf in enumerate(("", "_reverse")):
             w_ih, w_hh = P["encoder.weight_ih_l0" + suf], P["encoder.weight_hh_l0" + suf]
+            whh_t = weight_bf16(w_hh)[1] if use_b else None          # [H, 4H]
             order = list(range(Lp)) if d == 0 else list(range(Lp - 1, -1, -1))
             dg2d = dge[d].view(B, Lp * 4 * H)
             for n_ in range(Lp - 1, -1, -1):
@@ -268,8 +329,12 @@ class GeneratorFn(torch.autograd.Function):
                 c_prev = zeros_c if n_ == 0 else cenc[d, order[n_ - 1]]
                 dgt = dg2d[:, t * 4 * H:(t + 1) * 4 * H]
                 _cell_bwd(genc[d, t], c_prev, c_new, dmem2[:, t * 2 * H + d * H: t * 2 * H + (d + 1) * H],
-                          None if lastf else dhr, dc_cat[:, d * H:(d + 1) * H] if lastf else dce, dgt, dce, B, H)
-                dgrad(dgt, w_hh, out=dh0cat[:, d * H:(d + 1) * H] if n_ == 0 else dhr)
+                          None if lastf else dhr, dc_cat[:, d * H:(d + 1) * H] if lastf else dce, dgt, dce, B, H, dgb=dgtb)
+                dh_out = dh0cat[:, d * H:(d + 1) * H] if n_ == 0 else dhr
+                if use_b:
+                    gemm_bf16(dgtb, whh_t, B, H, C=dh_out)
+                else:
+                    dgrad(dgt, w_hh, out=dh_out)
             dgf = dge[d].view(B * Lp, 4 * H)
             G["encoder.weight_hh_l0" + suf] = wgrad(dgf, hprev[d].view(B * Lp, H))
             G["encoder.weight_ih_l0" + suf] = wgrad(dgf, emb)

@@ -134,14 +134,14 @@ def weight_bf16(W):
 
 
 def gemm_bf16(Ab, Bb, M, N, C=None, Cb=None, bias=None, addend=None, aux=None, act=0, gate_scale=1.0, alpha=1.0,
-              drop=NO_DROP, tile=0, splitk=0):
+              drop=NO_DROP, tile=0, splitk=0, accumulate=False):
     """C / Cb [M,N] = epi(alpha * Ab[M,Kp] Bb[N,Kp]^T); Ab, Bb zero-padded bf16 from cast_bf16."""
     Kp = Ab.shape[1]
     assert Bb.shape[1] == Kp and Ab.dtype == torch.int16 and Bb.dtype == torch.int16
     ws = _workspace(Ab.device)
     call("cst_gemm_bf16", Ab, Ab.stride(0), Bb, Bb.stride(0), C, _ld(C) if C is not None else 0,
          Cb, Cb.stride(0) if Cb is not None else 0, M, N, Kp, bias, addend, _ld(addend) if addend is not None else 0,
-         aux, aux.stride(0) if aux is not None else 0, act, float(gate_scale), float(alpha), *drop.args(),
+         aux, aux.stride(0) if aux is not None else 0, act, float(gate_scale), float(alpha), int(accumulate), *drop.args(),
          tile, splitk, ws, WS_FLOATS)
     return C if C is not None else Cb
 
@@ -225,17 +225,18 @@ def softmax_tau(logits, inv_tau, p, argmax_out=None):
     call("cst_softmax_tau", logits, _ld(logits), float(inv_tau), p, _ld(p), argmax_out, R, V)
 
 
-def softmax_tau_bwd(p, dp, inv_tau, dx):
+def softmax_tau_bwd(p, dp, inv_tau, dx, dx_b=None):
     R, V = p.shape
-    call("cst_softmax_tau_bwd", p, _ld(p), dp, _ld(dp), float(inv_tau), dx, _ld(dx), R, V)
+    call("cst_softmax_tau_bwd", p, _ld(p), dp, _ld(dp), float(inv_tau), dx, _ld(dx),
+         dx_b, dx_b.stride(0) if dx_b is not None else 0, R, V)
 
 
-def embed_gather(table, out, ids_a=None, ids_b=None, ldb=1, coin=None, transposed=False, drop=NO_DROP, V=None):
+def embed_gather(table, out, ids_a=None, ids_b=None, ldb=1, coin=None, transposed=False, drop=NO_DROP, V=None, out_b=None):
     R, E = out.shape
     if V is None:
         V = table.shape[1] if transposed else table.shape[0]
-    call("cst_embed_gather", ids_a, ids_b, ldb, coin, table, _ld(table), int(transposed), out, _ld(out), R, E, V,
-         *drop.args())
+    call("cst_embed_gather", ids_a, ids_b, ldb, coin, table, _ld(table), int(transposed), out, _ld(out),
+         out_b, out_b.stride(0) if out_b is not None else 0, R, E, V, *drop.args())
     return out
 
 

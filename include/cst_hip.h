@@ -70,7 +70,7 @@ int cst_gemm_profile_read(int which, double* total_ms_host, double* total_flops_
 int cst_gemm_bf16(const void* A, long lda, const void* B, long ldb,
                   float* C, long ldc, void* Cb, long ldcb, int M, int N, int K,
                   const float* bias, const float* addend, long ldadd, const void* aux, long ldaux,
-                  int act, float gate_scale, float alpha,
+                  int act, float gate_scale, float alpha, int accumulate,
                   float drop_p, uint32_t drop_seed, uint32_t drop_stream, const void* drop_seed_dev,
                   int tile, int splitk, float* workspace, long workspace_floats, void* stream);
 /* out[r, 0..ldo) = bf16(x[r,:] * dropmask) zero-padded, out_t[c, 0..ldot) = the transpose zero-padded
@@ -95,7 +95,7 @@ int cst_softmax_tau(const float* logits, long ld, float inv_tau, float* p, long 
                     int64_t* argmax_out, int R, int V, void* stream);
 /* dx = inv_tau * p * (dp - sum(dp * p)); dx may alias dp. */
 int cst_softmax_tau_bwd(const float* p, long ldp, const float* dp, long lddp, float inv_tau,
-                        float* dx, long lddx, int R, int V, void* stream);
+                        float* dx, long lddx, void* dx_bf16, long lddxb, int R, int V, void* stream);
 /* out[r] = first index of the row maximum (rnn.py:92; main_optimize.py:104,131,162). */
 int cst_argmax_rows(const float* x, long ld, int R, int V, int64_t* out, void* stream);
 
@@ -126,26 +126,30 @@ int cst_mha_bwd(const float* qkv, const float* dout, const float* lse, float* dq
  * `dropped` (optional, [B, lddrop]): also writes dropout([q | out]) -- the decoder's i_ffn of
  * rnn.py:78-79, dropout index b*2D + c -- saving a separate dropout launch per decode step. */
 int cst_dot_attn_fwd(const float* q, long ldq, const float* mem, float* out, long ldo, float* p,
-                     int B, int L, int D, float* dropped, long lddrop,
+                     int B, int L, int D, float* dropped, long lddrop, void* dropped_bf16, long lddropb,
                      float drop_p, uint32_t drop_seed, uint32_t drop_stream, const void* drop_seed_dev, void* stream);
 /* dq (+)= ..., dmem += ... (dmem accumulates across decode steps; zero it first). */
 int cst_dot_attn_bwd(const float* dout, long lddo, const float* q, long ldq, const float* mem, const float* p,
                      float* dq, long lddq, int dq_accumulate, float* dmem, int B, int L, int D, void* stream);
 
 /* LSTM cell (gate order i,f,g,o as nn.LSTM, rnn.py:25-33): gates [B,4H] pre-activation in,
- * activations out (kept for backward); h_out2 optional second copy of h. */
+ * activations out (kept for backward); h_out2 optional second copy of h; h_bf16 / h_bf16_2 optional
+ * bf16 copies (A operands of the next GEMMs); cell_bwd: dgates_bf16 likewise. */
 int cst_lstm_cell_fwd(float* gates, long ldg, const float* c_prev, long ldcp, float* h_out, long ldh,
-                      float* c_out, long ldc, float* h_out2, long ldh2, int B, int H, void* stream);
+                      float* c_out, long ldc, float* h_out2, long ldh2,
+                      void* h_bf16, long ldhb, void* h_bf16_2, long ldhb2, int B, int H, void* stream);
 int cst_lstm_cell_bwd(const float* gates, long ldg, const float* c_prev, long ldcp, const float* c_new, long ldcn,
                       const float* dh, long lddh, const float* dh2, long lddh2, const float* dc, long lddc,
-                      float* dgates, long lddg, float* dc_prev, long lddcp, int B, int H, void* stream);
+                      float* dgates, long lddg, float* dc_prev, long lddcp, void* dgates_bf16, long lddgb,
+                      int B, int H, void* stream);
 
 /* out[r,:] = table[id(r)] * dropmask, id(r) = (*coin_dev) ? ids_a[r] : ids_b[r*ldb] (either list may
  * be null); transposed reads table[c*ldt + id].  nn.Embedding at rnn.py:59,95; classifier.py:25;
  * the one-hot path of discriminator.py:39 (main_optimize.py:117); the scheduled-sampling choice
  * of rnn.py:91-95 is made on the device. */
 int cst_embed_gather(const int64_t* ids_a, const int64_t* ids_b, long ldb, const int* coin_dev,
-                     const float* table, long ldt, int transposed, float* out, long ldo, int R, int E, int V,
+                     const float* table, long ldt, int transposed, float* out, long ldo,
+                     void* out_bf16, long ldob, int R, int E, int V,
                      float drop_p, uint32_t drop_seed, uint32_t drop_stream, const void* drop_seed_dev, void* stream);
 int cst_embed_scatter_add(const int64_t* ids_a, const int64_t* ids_b, long ldb, const int* coin_dev,
                           const float* dout, long ldo, float* dtable, long ldt, int transposed, int R, int E, int V,

@@ -218,3 +218,29 @@ def test_dropout_train_mode_matches_oracle(cst):
             ref = run_or(P)
         np.testing.assert_allclose(y.cpu().numpy(), ref.numpy(), rtol=2e-3, atol=2e-4, err_msg=which)
     ops.set_precision("bf16")
+
+
+def test_generator_bf16_path_matches_f32_path(cst):
+    """Reference-size generator: the bf16-operand GEMM path (cst_gemm_bf16 with fused bf16 producers)
+    against the exact-fp32 path on the same weights -- single decode step (no argmax feedback yet, so
+    no token can flip), logits and all parameter gradients within the bf16 tolerance."""
+    pkg, model, ops = cst
+    name = "ref"
+    c, G = CONFIGS[name], load_golden("modules", name)
+    x1 = torch.from_numpy(G["x"]).cuda()[:, :1].contiguous()
+    nx, labels = torch.from_numpy(G["nx"]).cuda(), torch.from_numpy(G["labels"]).cuda()
+    res = {}
+    for prec in ("f32", "bf16"):
+        ops.set_precision(prec)
+        m = build(model, name, "G")
+        y = m(nx, labels, x1, labels, coins=[0])
+        m.zero_grad()
+        lossw("gen.one", y).backward()
+        res[prec] = (y.detach().float().cpu().numpy(), {k: p.grad.detach().cpu().numpy() for k, p in m.named_parameters() if p.grad is not None})
+    ops.set_precision("bf16")
+    yf, gf = res["f32"]
+    yb, gb = res["bf16"]
+    np.testing.assert_allclose(yb, yf, rtol=3e-2, atol=3e-2 * float(np.abs(yf).max()))
+    for k in gf:
+        nf, nb = np.linalg.norm(gf[k]), np.linalg.norm(gb[k] - gf[k])
+        assert nb <= 4e-2 * max(nf, 1e-6), (k, nb, nf)

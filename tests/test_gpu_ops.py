@@ -299,10 +299,12 @@ def test_dot_attn(ops, B, L, D):
     qd = dev(torch.cat([q, torch.zeros(B, 11)], 1))              # strided query rows
     out, pr = torch.empty(B, D + 5, device="cuda"), torch.empty(B, L, device="cuda")
     dropped = torch.empty(B, 2 * D + 3, device="cuda")
-    call("cst_dot_attn_fwd", qd, D + 11, dev(mem), out, D + 5, pr, B, L, D, dropped, 2 * D + 3, 0.25, 9, 105, None)
+    db = torch.zeros(B, 2 * D + 6, device="cuda", dtype=torch.int16)
+    call("cst_dot_attn_fwd", qd, D + 11, dev(mem), out, D + 5, pr, B, L, D, dropped, 2 * D + 3, db, 2 * D + 6, 0.25, 9, 105, None)
     close(out[:, :D], ref, 3e-4, 3e-5)
     mask = torch.from_numpy(orng.dropout_mask(9, 105, (B, 2 * D), 0.25))
     close(dropped[:, :2 * D], torch.cat([q, ref.detach()], 1) * mask, 3e-4, 3e-5)
+    close(db.view(torch.bfloat16).float()[:, :2 * D], torch.cat([q, ref.detach()], 1) * mask, 1e-2, 1e-2)
     close(pr, a, 3e-4, 1e-6)
     dq, dmem = torch.ones(B, D, device="cuda"), torch.zeros(B, L, D, device="cuda")
     call("cst_dot_attn_bwd", dev(w), D, qd, D + 11, dev(mem), pr, dq, D, 1, dmem, B, L, D)
