@@ -119,16 +119,24 @@ _WCACHE = {}
 
 
 def weight_bf16(W):
-    """bf16 row-major + transposed copies of a weight, cached until the weight changes: the key is
-    the torch in-place version (load_state_dict, .copy_) and the version of the optim.FlatGroup that
-    owns it (bumped by every Adam step, whose kernel writes through a raw pointer)."""
+    """bf16 row-major + transposed copies of a weight.
+
+    Frozen weights (no optim.FlatGroup owns them: the critics of the optimize stage, modules in
+    eval/transfer use) are cast once and cached; the key is the torch in-place version
+    (load_state_dict, .copy_) and the storage address.  TRAINED weights are cached only between
+    eager calls of one optimizer version and are ALWAYS recast while a hipGraph is being captured:
+    a capture must not bake in a cached tensor, because replays have to see the weights Adam has
+    updated since (and the cached tensor would be freed when the cache entry is replaced)."""
     grp = getattr(W, "_cst_group", None)
-    ver = (W._version, grp.version if grp is not None else 0, W.data_ptr())
+    capturing = torch.cuda.is_current_stream_capturing()
+    if grp is not None and capturing:
+        return cast_bf16(W.detach())
+    ver = (W._version, grp.version if grp is not None else 0, W.data_ptr(), tuple(W.shape))
     hit = _WCACHE.get(id(W))
     if hit is not None and hit[0] == ver:
         return hit[1], hit[2]
     rm, tr = cast_bf16(W.detach())
-    if not torch.cuda.is_current_stream_capturing():
+    if not capturing:
         _WCACHE[id(W)] = (ver, rm, tr)               # never cache tensors that live in a graph's private pool
     return rm, tr
 

@@ -55,6 +55,9 @@ class FlatGroup:
         self._src_host = torch.zeros(len(sizes), dtype=torch.int64).pin_memory() if dev.type == "cuda" else None
         self.srcs = torch.zeros(len(sizes), dtype=torch.int64, device=dev)
         self._keep = None
+        self._captured_tables = [(torch.zeros(len(sizes), dtype=torch.int64).pin_memory() if dev.type == "cuda" else None,
+                                  torch.zeros(len(sizes), dtype=torch.int64, device=dev)) for _ in range(8)]
+        self._next_table = 0
 
     def gather_grads(self, accumulate):
         """Move p.grad of every parameter into the flat gradient buffer (+= when `accumulate`, the
@@ -63,13 +66,21 @@ class FlatGroup:
         if not accumulate:
             if any(g is None for g in grads):
                 self.flat_g.zero_()
+        src_host, srcs = self._src_host, self.srcs
+        if torch.cuda.is_current_stream_capturing():
+            # a captured graph re-reads the pinned table on every replay: each capture needs its own
+            # (two graphs over the same group -- e.g. the optimize stage's D-update / no-update
+            # variants -- must not see each other's gradient addresses)
+            assert self._next_table < len(self._captured_tables), "more than 8 graph captures over one FlatGroup"
+            src_host, srcs = self._captured_tables[self._next_table]      # pre-allocated: no host allocation while capturing
+            self._next_table += 1
         for i, g in enumerate(grads):
             if g is not None and not g.is_contiguous():
                 grads[i] = g.contiguous()
-            self._src_host[i] = grads[i].data_ptr() if grads[i] is not None else 0
-        self.srcs.copy_(self._src_host, non_blocking=True)
+            src_host[i] = grads[i].data_ptr() if grads[i] is not None else 0
+        srcs.copy_(src_host, non_blocking=True)
         self._keep = grads                                 # keep sources alive until the kernel ran
-        call("cst_multi_accumulate", self.srcs, self.dst_off, self.sizes_dev, self.chunk_tensor, self.chunk_start,
+        call("cst_multi_accumulate", srcs, self.dst_off, self.sizes_dev, self.chunk_tensor, self.chunk_start,
              self.nchunks, self.flat_g, int(accumulate))
         for p in self.params:
             p.grad = None

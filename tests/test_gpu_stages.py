@@ -152,3 +152,39 @@ def test_warmup_and_pretrain_curves():
         rows.append([r["s_loss"].item(), r["c_loss"].item(), r["dn_loss"].item()])
     np.testing.assert_allclose(np.array(rows), G["pretrain.curve"], rtol=2e-3, atol=1e-3)
     ops.set_precision("bf16")
+
+
+@pytest.mark.parametrize("prec", ["f32", "bf16"])
+def test_graph_replay_tracks_eager_training(prec):
+    """hipGraph replay of the optimize step (D-update and no-update variants, the way
+    main_optimize.train_batch drives them) must follow the eager loop step for step: every replay
+    has to see the weights Adam wrote in the previous one (bf16 weight copies are recast inside the
+    graph, never served from the eager cache) and its own gradient pointer table."""
+    from consistent__style_transfer_amd import ops
+    from consistent__style_transfer_amd.trainer import StepCache
+    ops.set_precision(prec)
+    name = "tiny"
+    c, G = CONFIGS[name], load_golden("curves", name)
+    n = G["optimize.curve"].shape[0]
+
+    def run(graphed):
+        st = make_opt(name, lr=1e-3)
+        cache = StepCache(graphed, [st])
+        rows = []
+        for it in range(n):
+            upd = it % 4 == 0
+            x, lab = cu(opt_batch(c, it))
+            coins = torch.from_numpy(np.asarray(G["optimize.coins"][it]).astype(np.int32)).cuda()
+            out = cache.run(("o", upd), lambda x, lab, cc: st.train_step((x, lab), 0 if upd else 1, coins=cc), [x, lab, coins])
+            rows.append([out["g_total"].item(), out["G"].item(), out["STI"].item(), out["BK"].item(), out["D"].item()])
+        w = st.generator.fn_2.weight.detach().clone()
+        return np.array(rows), w
+
+    eager, we = run(False)
+    graph, wg = run(True)
+    tol = 1e-4 if prec == "f32" else 5e-3          # same kernels, same order: only atomics-free fp differences remain
+    np.testing.assert_allclose(graph, eager, rtol=tol, atol=tol)
+    np.testing.assert_allclose(wg.cpu().numpy(), we.cpu().numpy(), rtol=tol, atol=tol)
+    if prec == "f32":
+        np.testing.assert_allclose(graph[:, 0], G["optimize.curve"][:, 0], rtol=2e-3, atol=1e-3)
+    ops.set_precision("bf16")

@@ -22,7 +22,7 @@ def stats(path, steps, out):
     fam = collections.defaultdict(lambda: [0, 0.0])
     for r in rows:
         n = short(r["Name"])
-        f = "cst_gemm_kernel<*>" if n.startswith("cst_gemm_kernel") else n
+        f = "cst_gemm_kernel<*>" if n.startswith("cst_gemm_kernel") else ("cst_gemm_bf16_kernel<*>" if n.startswith("cst_gemm_bf16_kernel") else n)
         fam[f][0] += int(r["Calls"])
         fam[f][1] += float(r["TotalDurationNs"])
     with open(out, "w") as f:
@@ -44,6 +44,7 @@ def pmc(fetch, write, out):
                 continue
             k = short(r["Kernel_Name"])
             k = "cst_gemm_kernel" if k.startswith("cst_gemm_kernel") else k
+            k = "cst_gemm_bf16_kernel" if k.startswith("cst_gemm_bf16_kernel") else k
             d[k][0] += 1
             d[k][1] += float(r["Counter_Value"])
             d[k][2] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
