@@ -1,98 +1,196 @@
-// Attention kernels for gfx950 (exact fp32 VALU; tiles are tiny: S <= 64 keys).
+// Attention kernels for gfx950 (exact fp32; tiles are tiny: S <= 64 keys).
 //
 //  (1) Unmasked multi-head self-attention core of nn.TransformerEncoderLayer as the reference
 //      configures it (mlm.py:20-22, match.py:18-20; no mask is ever passed, mlm.py:43,
 //      match.py:39): per (batch row, head), P = softmax(Q K^T / sqrt(hd)), attention dropout on
 //      P, O = P V.  S = L (MLM) or L1+L2 (Matcher) <= 64.
-//      One 256-thread workgroup per (b, h); its 4 wavefronts share the head's K/V.  In the
-//      forward each lane keeps one key row (scores) and one value column (output) in registers
-//      and a wave exchanges the probability row through LDS; softmax reductions are wavefront
-//      shuffles.  The backward stages Q, K, V, dO and the S x S matrices P and dS in LDS.
+//      One 8-wave workgroup per (b, h); every product of the forward (Q K^T, P V) and of the
+//      backward (Q K^T, dO V^T, Pd^T dO, dS K, dS^T Q) runs on the exact-fp32 matrix pipe
+//      (v_mfma_f32_16x16x4_f32) from padded LDS images of Q, K, V, dO and of the S x S planes;
+//      softmax statistics are 16-lane DPP reductions.
 //  (2) Single-query dot-product attention of the generator's decoder (rnn.py:46-50, called at
 //      rnn.py:76): one workgroup per batch row, memory (L' <= 64 rows of D) streamed once.
 #include "cst_common.h"
 
 #define MHA_SMAX 64
 
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef __attribute__((address_space(1))) const void* gbl_ptr_t;
+
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+
+// Sum over each aligned group of 16 lanes, result in all 16, on the DPP path (no LDS round trip as
+// __shfl_xor's ds_bpermute would take): swap inside pairs, swap pairs inside quads, then mirror the
+// half row and the row -- after the first two steps a quad holds one value, so the mirrors deliver
+// the other quad's / the other half row's sum.
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float row16_sum(float v) {
+    v += dpp_f<0xB1>(v);        // quad_perm [1,0,3,2]
+    v += dpp_f<0x4E>(v);        // quad_perm [2,3,0,1]
+    v += dpp_f<0x141>(v);       // row_half_mirror
+    v += dpp_f<0x140>(v);       // row_mirror
+    return v;
+}
+__device__ __forceinline__ float row16_max(float v) {
+    v = fmaxf(v, dpp_f<0xB1>(v));
+    v = fmaxf(v, dpp_f<0x4E>(v));
+    v = fmaxf(v, dpp_f<0x141>(v));
+    v = fmaxf(v, dpp_f<0x140>(v));
+    return v;
+}
+
+constexpr int MHA_NW = 8;            // waves per workgroup: 2-3 resident workgroups give 4-6 waves / SIMD
+
 // ---------------------------------------------------------------------------------------------
 // MHA forward.  qkv [B,S,3d] (q | k | v thirds, heads interleaved inside each third as torch's
 // packed in_proj does), out [B,S,d], lse [B,H,S].
+//
+// Both products run on the exact-fp32 matrix pipe (v_mfma_f32_16x16x4_f32 == an fmaf chain).  One
+// workgroup of 8 waves per (batch row, head), S padded to SP = 16*ST rows (pad rows replicate row
+// S-1, pad keys get probability 0):
+//   phase A  Sc = scale * Q K^T per 16x16 tile (k split in four contiguous segments, one per
+//            16-lane group: operands are b128 row reads of the padded [SP][HD+4] images) -> LDS
+//   phase B  row softmax, one row per 16-lane group (DPP reductions), lse, attention dropout; Pd -> LDS
+//   phase C  O = Pd V per 16-row block and pair of 16-column tiles
 // ---------------------------------------------------------------------------------------------
-template <int HD>
-__global__ __launch_bounds__(256) void mha_fwd_kernel(const float* __restrict__ qkv, float* __restrict__ out,
-                                                      float* __restrict__ lse, int S, int H, float scale, CstDrop drop) {
-    constexpr int HD4 = HD / 4;
-    constexpr int NC = (HD + 63) / 64;                 // output columns per lane
-    __shared__ __attribute__((aligned(16))) float Qs[MHA_SMAX * HD];
-    __shared__ __attribute__((aligned(16))) float Ps[4][MHA_SMAX];
+__host__ __device__ inline size_t mha_fwd_lds_floats(int S, int hd) {
+    const size_t SP = (size_t)((S + 15) / 16) * 16;
+    return 3 * SP * (hd + 4) + 16 + SP * (SP + 4);
+}
+
+template <int HD, int ST>
+__global__ __launch_bounds__(MHA_NW * 64) void mha_fwd_kernel(const float* __restrict__ qkv, float* __restrict__ out,
+                                                             float* __restrict__ lse, int S, int H, float scale, CstDrop drop) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int HD4 = HD / 4, HDS = HD + 4, SEG = HD / 4, NT = (HD + 15) / 16;
+    constexpr int SP = ST * 16, SS = SP + 4, KSEG = SP / 4, NTHR = MHA_NW * 64;
+    float* Qs = smem;                    // [SP][HDS]
+    float* Ks = Qs + SP * HDS;
+    float* Vs = Ks + SP * HDS;
+    float* Pm = Vs + SP * HDS + 16;      // [SP][SS]  scores, then dropped probabilities
     const int b = blockIdx.x / H, h = blockIdx.x % H;
     const int d = H * HD;
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lr = lane & 15, lq = lane >> 4;
     const float* base = qkv + (long)b * S * 3 * d + h * HD;
-
-    // Q tile -> LDS (coalesced over the head dimension)
-    for (int e = threadIdx.x; e < S * HD; e += 256) {
-        const int i = e / HD, c = e % HD;
-        Qs[i * HD + c] = base[(long)i * 3 * d + c];
-    }
-    // key row `lane` -> registers
-    float kreg[HD];
-    if (lane < S) {
-        const float* kp = base + (long)lane * 3 * d + d;
+    {
+        constexpr int nel = SP * HD4;
+        constexpr int QIT = (nel + NTHR - 1) / NTHR;
+        float4 tq[QIT], tk[QIT], tv[QIT];
 #pragma unroll
-        for (int c = 0; c < HD; ++c) kreg[c] = kp[c];
-    } else {
-#pragma unroll
-        for (int c = 0; c < HD; ++c) kreg[c] = 0.f;
-    }
-    // value columns lane (+64) -> registers, all S keys
-    float vreg[NC][MHA_SMAX];
-#pragma unroll
-    for (int cc = 0; cc < NC; ++cc) {
-        const int c = lane + 64 * cc;
-#pragma unroll
-        for (int j = 0; j < MHA_SMAX; ++j)
-            vreg[cc][j] = (j < S && c < HD) ? base[(long)j * 3 * d + 2 * d + c] : 0.f;
-    }
-    __syncthreads();
-    const uint32_t dseed = drop.p > 0.f ? cst_drop_seed(drop) : 0u;
-
-    for (int i = w; i < S; i += 4) {
-        float s = 0.f;
-#pragma unroll
-        for (int c4 = 0; c4 < HD4; ++c4) {
-            const float4 q = *reinterpret_cast<const float4*>(&Qs[i * HD + c4 * 4]);
-            s += q.x * kreg[c4 * 4 + 0] + q.y * kreg[c4 * 4 + 1] + q.z * kreg[c4 * 4 + 2] + q.w * kreg[c4 * 4 + 3];
+        for (int it = 0; it < QIT; ++it) {
+            const int e = min((int)threadIdx.x + NTHR * it, nel - 1);
+            const int i = min(e / HD4, S - 1), c = (e % HD4) * 4;
+            const float* src = base + (long)i * 3 * d + c;
+            tq[it] = *reinterpret_cast<const float4*>(src);
+            tk[it] = *reinterpret_cast<const float4*>(src + d);
+            tv[it] = *reinterpret_cast<const float4*>(src + 2 * d);
         }
-        s = (lane < S) ? s * scale : -INFINITY;
-        const float m = wave_max(s);
-        const float e = (lane < S) ? expf(s - m) : 0.f;
-        const float sum = wave_sum(e);
-        float p = e / sum;
-        if (lane == 0) lse[((long)b * H + h) * S + i] = m + logf(sum);
-        if (drop.p > 0.f && lane < S)
-            p *= cst_drop_mask(drop, dseed, (uint32_t)((((long)b * H + h) * S + i) * S + lane));
-        Ps[w][lane] = p;
-        __builtin_amdgcn_wave_barrier();
-        // O[i][c] = sum_j P[i][j] V[j][c]; this wave's own LDS row, lanes now index columns
-        float o[NC];
 #pragma unroll
-        for (int cc = 0; cc < NC; ++cc) o[cc] = 0.f;
-#pragma unroll
-        for (int j4 = 0; j4 < MHA_SMAX / 4; ++j4) {
-            if (j4 * 4 < S) {
-                const float4 pj = *reinterpret_cast<const float4*>(&Ps[w][j4 * 4]);
-#pragma unroll
-                for (int cc = 0; cc < NC; ++cc)
-                    o[cc] += pj.x * vreg[cc][j4 * 4 + 0] + pj.y * vreg[cc][j4 * 4 + 1] + pj.z * vreg[cc][j4 * 4 + 2] + pj.w * vreg[cc][j4 * 4 + 3];
+        for (int it = 0; it < QIT; ++it) {
+            const int e = threadIdx.x + NTHR * it;
+            if (e < nel) {
+                const int o = (e / HD4) * HDS + (e % HD4) * 4;
+                *reinterpret_cast<float4*>(&Qs[o]) = tq[it];
+                *reinterpret_cast<float4*>(&Ks[o]) = tk[it];
+                *reinterpret_cast<float4*>(&Vs[o]) = tv[it];
             }
         }
+    }
+    __syncthreads();
+    // ---- phase A -----------------------------------------------------------------------------
+    constexpr int ntile = ST * ST;
+    for (int t = w; t < ntile; t += MHA_NW) {
+        const int mt = t / ST, nt = t % ST;
+        const float* qa = Qs + (mt * 16 + lr) * HDS + lq * SEG;
+        const float* ka = Ks + (nt * 16 + lr) * HDS + lq * SEG;
+        f32x4_t acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};       // two chains over alternate k
+        if constexpr (SEG % 4 == 0) {
 #pragma unroll
-        for (int cc = 0; cc < NC; ++cc) {
-            const int c = lane + 64 * cc;
-            if (c < HD) out[((long)b * S + i) * d + h * HD + c] = o[cc];
+            for (int k4 = 0; k4 < SEG / 4; ++k4) {
+                const float4 q4 = *reinterpret_cast<const float4*>(qa + k4 * 4);
+                const float4 kx = *reinterpret_cast<const float4*>(ka + k4 * 4);
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(q4.x, kx.x, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(q4.y, kx.y, acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(q4.z, kx.z, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(q4.w, kx.w, acc1, 0, 0, 0);
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < SEG; ++k) acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[k], ka[k], acc0, 0, 0, 0);
         }
-        __builtin_amdgcn_wave_barrier();
+        const int j = nt * 16 + lr;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Pm[(mt * 16 + lq * 4 + r) * SS + j] = (acc0[r] + acc1[r]) * scale;
+    }
+    __syncthreads();
+    // ---- phase B: 16-lane group g of wave w owns rows i = 4 * (w + NW * pass) + g; lane lr holds keys lr + 16 n
+    const uint32_t dseed = drop.p > 0.f ? cst_drop_seed(drop) : 0u;
+    for (int i0 = 4 * w; i0 < S; i0 += 4 * MHA_NW) {
+        const int i = i0 + lq;
+        const bool row_ok = i < S;
+        const int ic = row_ok ? i : S - 1;
+        float sv[ST];
+        float m = -INFINITY;
+#pragma unroll
+        for (int n = 0; n < ST; ++n) {
+            const int j = lr + 16 * n;
+            sv[n] = j < S ? Pm[ic * SS + j] : -INFINITY;
+            m = fmaxf(m, sv[n]);
+        }
+        m = row16_max(m);
+        float sum = 0.f;
+#pragma unroll
+        for (int n = 0; n < ST; ++n) {
+            sv[n] = (lr + 16 * n < S) ? expf(sv[n] - m) : 0.f;
+            sum += sv[n];
+        }
+        sum = row16_sum(sum);
+        const float inv = 1.f / sum;
+        if (row_ok) {
+            if (lr == 0) lse[((long)b * H + h) * S + i] = m + logf(sum);
+#pragma unroll
+            for (int n = 0; n < ST; ++n) {
+                const int j = lr + 16 * n;
+                float pv = sv[n] * inv;
+                if (drop.p > 0.f && j < S)
+                    pv *= cst_drop_mask(drop, dseed, (uint32_t)((((long)b * H + h) * S + i) * S + j));
+                Pm[i * SS + j] = pv;                  // keys >= S: exactly 0
+            }
+        }
+    }
+    __syncthreads();
+    // ---- phase C: O[i][c] = sum_j Pd[i][j] V[j][c]
+    float* ob = out + (long)b * S * d + h * HD;
+    constexpr int PAIR = (NT % 2 == 0) ? 2 : 1, NP = NT / PAIR;
+    constexpr int nout = ST * NP;
+    for (int u = w; u < nout; u += MHA_NW) {
+        const int mt = u / NP, n0 = (u - mt * NP) * PAIR * 16;
+        const float* a = Pm + (mt * 16 + lr) * SS + lq * KSEG;
+        const float* bp = Vs + (lq * KSEG) * HDS + n0 + lr;
+        f32x4_t acc[PAIR];
+#pragma unroll
+        for (int q = 0; q < PAIR; ++q) acc[q] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < KSEG; ++k) {
+            const float av = a[k];
+#pragma unroll
+            for (int q = 0; q < PAIR; ++q)
+                acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bp[k * HDS + q * 16], acc[q], 0, 0, 0);
+        }
+#pragma unroll
+        for (int q = 0; q < PAIR; ++q) {
+            const int n = n0 + q * 16 + lr;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int mrow = mt * 16 + lq * 4 + r;
+                if (mrow < S && n < HD) ob[(long)mrow * d + n] = acc[q][r];
+            }
+        }
     }
 }
 
@@ -100,19 +198,35 @@ extern "C" int cst_mha_fwd(const float* qkv, float* out, float* lse, int B, int 
                            float drop_p, uint32_t drop_seed, uint32_t drop_stream, const void* drop_seed_dev,
                            void* stream) {
     CST_REQUIRE(qkv && out && lse, "cst_mha_fwd: null pointer");
+    CST_REQUIRE(((uintptr_t)qkv & 15) == 0, "cst_mha_fwd: qkv must be 16-byte aligned");
     CST_REQUIRE(B > 0 && S > 0 && S <= MHA_SMAX && H > 0, "cst_mha_fwd: S=%d unsupported (max %d)", S, MHA_SMAX);
     CstDrop dr = cst_make_drop(drop_p, drop_seed, drop_stream, drop_seed_dev);
     const float scale = 1.0f / sqrtf((float)hd);
-    dim3 grid(B * H), block(256);
+    const size_t lds = sizeof(float) * mha_fwd_lds_floats(S, hd);
+    CST_REQUIRE(lds <= 160 * 1024, "cst_mha_fwd: LDS need %zu exceeds 160 KiB", lds);
+    dim3 grid(B * H), block(MHA_NW * 64);
     hipStream_t st = (hipStream_t)stream;
+#define MHA_FWD_LAUNCH(HDV, STV)                                                                                  \
+    {                                                                                                             \
+        if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)mha_fwd_kernel<HDV, STV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL((mha_fwd_kernel<HDV, STV>), grid, block, lds, st, qkv, out, lse, S, H, scale, dr);     \
+    }
+#define MHA_FWD_CASE(HDV)                                                                                         \
+    case HDV: {                                                                                                   \
+        switch ((S + 15) / 16) {                                                                                  \
+            case 1: MHA_FWD_LAUNCH(HDV, 1) break;                                                                 \
+            case 2: MHA_FWD_LAUNCH(HDV, 2) break;                                                                 \
+            case 3: MHA_FWD_LAUNCH(HDV, 3) break;                                                                 \
+            default: MHA_FWD_LAUNCH(HDV, 4) break;                                                                \
+        }                                                                                                         \
+        break;                                                                                                    \
+    }
     switch (hd) {
-        case 8: hipLaunchKernelGGL((mha_fwd_kernel<8>), grid, block, 0, st, qkv, out, lse, S, H, scale, dr); break;
-        case 16: hipLaunchKernelGGL((mha_fwd_kernel<16>), grid, block, 0, st, qkv, out, lse, S, H, scale, dr); break;
-        case 32: hipLaunchKernelGGL((mha_fwd_kernel<32>), grid, block, 0, st, qkv, out, lse, S, H, scale, dr); break;
-        case 64: hipLaunchKernelGGL((mha_fwd_kernel<64>), grid, block, 0, st, qkv, out, lse, S, H, scale, dr); break;
-        case 96: hipLaunchKernelGGL((mha_fwd_kernel<96>), grid, block, 0, st, qkv, out, lse, S, H, scale, dr); break;
+        MHA_FWD_CASE(8) MHA_FWD_CASE(16) MHA_FWD_CASE(32) MHA_FWD_CASE(64) MHA_FWD_CASE(96)
         default: cst_set_error("cst_mha_fwd: head dim %d unsupported (8, 16, 32, 64, 96)", hd); return CST_ERR_ARG;
     }
+#undef MHA_FWD_LAUNCH
+#undef MHA_FWD_CASE
     CST_LAUNCH_CHECK("cst_mha_fwd");
     return CST_OK;
 }
@@ -121,100 +235,186 @@ extern "C" int cst_mha_fwd(const float* qkv, float* out, float* lse, int B, int 
 // MHA backward: recompute P from Q, K and the saved log-sum-exp, then
 //   dV = Pd^T dO ; dPd = dO V^T ; dS = P o (dP - rowsum(dP o P)) * scale ; dQ = dS K ; dK = dS^T Q
 // with Pd the dropped probabilities.  dqkv [B,S,3d].
+//
+// All five products run on the exact-fp32 matrix pipe (v_mfma_f32_16x16x4_f32 == an fmaf chain):
+// a VALU formulation needs one wave-wide LDS broadcast (1 KiB of LDS return bandwidth) per 4
+// FMAs and was LDS-bound at ~650 GB/s of HBM traffic.  One workgroup per (batch row, head), S
+// padded to SP = 16*ST rows (pad rows replicate row S-1; P and dS are forced to 0 there):
+//   phase A  per 16x16 tile of the S x S plane: Sc = Q K^T and dPd = dO V^T (k split in four
+//            contiguous segments, one per 16-lane group, so operands are b128 row reads of the
+//            padded [SP][HD+4] images); P, dP, the tile's row sums of dP o P; Pd -> LDS
+//   phase B  delta = sum of the row-sum partials in tile order (deterministic); dS -> LDS
+//   phase C  the 3 * ST * ceil(HD/16) output tiles of dQ, dK, dV, contraction over the S x S images
 // ---------------------------------------------------------------------------------------------
-template <int HD>
-__global__ __launch_bounds__(256) void mha_bwd_kernel(const float* __restrict__ qkv, const float* __restrict__ dout,
+__host__ __device__ inline size_t mha_bwd_lds_floats(int S, int hd) {
+    const size_t SP = (size_t)((S + 15) / 16) * 16;
+    return 4 * SP * (hd + 4) + 16 + 2 * SP * (SP + 4) + SP * 4 + SP;
+}
+
+template <int HD, int ST>
+__global__ __launch_bounds__(MHA_NW * 64) void mha_bwd_kernel(const float* __restrict__ qkv, const float* __restrict__ dout,
                                                       const float* __restrict__ lse, float* __restrict__ dqkv,
                                                       int S, int H, float scale, CstDrop drop) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    constexpr int HD4 = HD / 4;
-    constexpr int RMAX = MHA_SMAX / 4;   // rows per wave (row i belongs to wave i % 4)
-    const int SP = (S + 3) / 4 * 4 + 4;  // row stride of the S x S images: multiple of 4 (b128 reads), keys >= S hold 0
-    float* Qs = smem;                    // [S][HD]
-    float* Ks = Qs + S * HD;             // [S][HD]
-    float* Vs = Ks + S * HD;             // [S][HD]
-    float* Os = Vs + S * HD;             // [S][HD]  (dO)
-    float* Dm = Os + S * HD;             // [S][SP]  dS[i][j]
-    float* DmT = Dm + S * SP;            // [S][SP]  dS[j][i]
-    float* PmT = DmT + S * SP;           // [S][SP]  Pd[j][i] (dropped probabilities, transposed)
+    constexpr int HD4 = HD / 4, HDS = HD + 4, SEG = HD / 4, NT = (HD + 15) / 16;
+    constexpr int SP = ST * 16, SS = SP + 4, KSEG = SP / 4;     // ST = ceil(S / 16): every loop below unrolls
+    float* Qs = smem;                    // [SP][HDS]
+    float* Ks = Qs + SP * HDS;
+    float* Vs = Ks + SP * HDS;
+    float* Os = Vs + SP * HDS;           // dO
+    float* Pm = Os + SP * HDS + 16;      // [SP][SS]  Pd[i][j]   (16 floats of slack: HD < 16 reads past a row end)
+    float* Dm = Pm + SP * SS;            // [SP][SS]  dS[i][j]
+    float* part = Dm + SP * SS;          // [SP][4]   row sums of dP o P per column tile
+    float* lse_s = part + SP * 4;        // [SP]
     const int b = blockIdx.x / H, h = blockIdx.x % H;
     const int d = H * HD;
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lr = lane & 15, lq = lane >> 4;
     const float* base = qkv + (long)b * S * 3 * d + h * HD;
     const float* dob = dout + (long)b * S * d + h * HD;
-    for (int e = threadIdx.x; e < S * HD; e += 256) {
-        const int i = e / HD, c = e % HD;
-        Qs[e] = base[(long)i * 3 * d + c];
-        Ks[e] = base[(long)i * 3 * d + d + c];
-        Vs[e] = base[(long)i * 3 * d + 2 * d + c];
-        Os[e] = dob[(long)i * d + c];
-    }
-    for (int e = threadIdx.x; e < 3 * S * SP; e += 256) Dm[e] = 0.f;      // zero incl. the padding keys
-    __syncthreads();
-    // pass 1: lane = key j; key and value rows in registers
-    float kreg[HD], vreg[HD];
+
+    // stage Q, K, V, dO: every 16-byte load is issued before the first LDS store
+    {
+        constexpr int nel = SP * HD4;
+        constexpr int NTHR = MHA_NW * 64, QIT = (nel + NTHR - 1) / NTHR;
+        float4 tq[QIT], tk[QIT], tv[QIT], to[QIT];
 #pragma unroll
-    for (int c = 0; c < HD; ++c) {
-        kreg[c] = (lane < S) ? Ks[lane * HD + c] : 0.f;
-        vreg[c] = (lane < S) ? Vs[lane * HD + c] : 0.f;
+        for (int it = 0; it < QIT; ++it) {
+            // unconditional (clamped) loads: iterations past the tile re-read its last element
+            const int e = min((int)threadIdx.x + NTHR * it, nel - 1);
+            const int i = min(e / HD4, S - 1), c = (e % HD4) * 4;
+            const float* src = base + (long)i * 3 * d + c;
+            tq[it] = *reinterpret_cast<const float4*>(src);
+            tk[it] = *reinterpret_cast<const float4*>(src + d);
+            tv[it] = *reinterpret_cast<const float4*>(src + 2 * d);
+            to[it] = *reinterpret_cast<const float4*>(dob + (long)i * d + c);
+        }
+        if (threadIdx.x < SP) lse_s[threadIdx.x] = (int)threadIdx.x < S ? lse[((long)b * H + h) * S + threadIdx.x] : 0.f;
+#pragma unroll
+        for (int it = 0; it < QIT; ++it) {
+            const int e = threadIdx.x + NTHR * it;
+            if (e < nel) {
+                const int o = (e / HD4) * HDS + (e % HD4) * 4;
+                *reinterpret_cast<float4*>(&Qs[o]) = tq[it];
+                *reinterpret_cast<float4*>(&Ks[o]) = tk[it];
+                *reinterpret_cast<float4*>(&Vs[o]) = tv[it];
+                *reinterpret_cast<float4*>(&Os[o]) = to[it];
+            }
+        }
     }
+    __syncthreads();
+
+    // ---- phase A -----------------------------------------------------------------------------
     const uint32_t dseed = drop.p > 0.f ? cst_drop_seed(drop) : 0u;
-    for (int i = w; i < S; i += 4) {
-        float s = 0.f, dpd = 0.f;
+    constexpr int ntile = ST * ST, TPW = (ntile + MHA_NW - 1) / MHA_NW;
+    f32x4_t Pf[TPW], Df[TPW];            // this wave's tiles, kept for phase B
 #pragma unroll
-        for (int c4 = 0; c4 < HD4; ++c4) {
-            const float4 q = *reinterpret_cast<const float4*>(&Qs[i * HD + c4 * 4]);
-            const float4 g = *reinterpret_cast<const float4*>(&Os[i * HD + c4 * 4]);
-            s += q.x * kreg[c4 * 4 + 0] + q.y * kreg[c4 * 4 + 1] + q.z * kreg[c4 * 4 + 2] + q.w * kreg[c4 * 4 + 3];
-            dpd += g.x * vreg[c4 * 4 + 0] + g.y * vreg[c4 * 4 + 1] + g.z * vreg[c4 * 4 + 2] + g.w * vreg[c4 * 4 + 3];
-        }
-        const float l = lse[((long)b * H + h) * S + i];
-        const float p = (lane < S) ? expf(s * scale - l) : 0.f;
-        float mask = 1.f;
-        if (drop.p > 0.f && lane < S)
-            mask = cst_drop_mask(drop, dseed, (uint32_t)((((long)b * H + h) * S + i) * S + lane));
-        const float dp = (lane < S) ? dpd * mask : 0.f;
-        const float delta = wave_sum(dp * p);
-        if (lane < S) {
-            const float dsv = p * (dp - delta) * scale;
-            Dm[i * SP + lane] = dsv;
-            DmT[lane * SP + i] = dsv;
-            PmT[lane * SP + i] = p * mask;
-        }
-    }
-    __syncthreads();
-    // pass 2: lane = head-dim column c; each wave keeps its rows i = w, w+4, ... as accumulators and
-    // walks the keys 4 at a time: one broadcast b128 of the S x S image per row + 4 operand reads
-    // per 4 keys feed 4*rows FMAs.
-    float* dq = dqkv + (long)b * S * 3 * d + h * HD;
-    const int S4 = (S + 3) / 4;
-    for (int c = lane; c < HD; c += 64) {
+    for (int tt = 0; tt < TPW; ++tt) {
+        const int t = w + MHA_NW * tt;
+        Pf[tt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        Df[tt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        if (t < ntile) {
+            const int mt = t / ST, nt = t % ST;
+            const float* qa = Qs + (mt * 16 + lr) * HDS + lq * SEG;
+            const float* oa = Os + (mt * 16 + lr) * HDS + lq * SEG;
+            const float* ka = Ks + (nt * 16 + lr) * HDS + lq * SEG;
+            const float* va = Vs + (nt * 16 + lr) * HDS + lq * SEG;
+            f32x4_t accS = {0.f, 0.f, 0.f, 0.f}, accD = {0.f, 0.f, 0.f, 0.f};
+            if constexpr (SEG % 4 == 0) {
 #pragma unroll
-        for (int which = 0; which < 3; ++which) {
-            const float* img = which == 0 ? Dm : (which == 1 ? DmT : PmT);     // dQ = dS K ; dK = dS^T Q ; dV = Pd^T dO
-            const float* opr = which == 0 ? Ks : (which == 1 ? Qs : Os);
-            float acc[RMAX];
+                for (int k4 = 0; k4 < SEG / 4; ++k4) {
+                    const float4 q4 = *reinterpret_cast<const float4*>(qa + k4 * 4);
+                    const float4 kx = *reinterpret_cast<const float4*>(ka + k4 * 4);
+                    const float4 o4 = *reinterpret_cast<const float4*>(oa + k4 * 4);
+                    const float4 v4 = *reinterpret_cast<const float4*>(va + k4 * 4);
+                    accS = __builtin_amdgcn_mfma_f32_16x16x4f32(q4.x, kx.x, accS, 0, 0, 0);
+                    accD = __builtin_amdgcn_mfma_f32_16x16x4f32(o4.x, v4.x, accD, 0, 0, 0);
+                    accS = __builtin_amdgcn_mfma_f32_16x16x4f32(q4.y, kx.y, accS, 0, 0, 0);
+                    accD = __builtin_amdgcn_mfma_f32_16x16x4f32(o4.y, v4.y, accD, 0, 0, 0);
+                    accS = __builtin_amdgcn_mfma_f32_16x16x4f32(q4.z, kx.z, accS, 0, 0, 0);
+                    accD = __builtin_amdgcn_mfma_f32_16x16x4f32(o4.z, v4.z, accD, 0, 0, 0);
+                    accS = __builtin_amdgcn_mfma_f32_16x16x4f32(q4.w, kx.w, accS, 0, 0, 0);
+                    accD = __builtin_amdgcn_mfma_f32_16x16x4f32(o4.w, v4.w, accD, 0, 0, 0);
+                }
+            } else {
 #pragma unroll
-            for (int r = 0; r < RMAX; ++r) acc[r] = 0.f;
-            for (int j4 = 0; j4 < S4; ++j4) {
-                const int j = j4 * 4;
-                const float o0 = opr[j * HD + c];
-                const float o1 = (j + 1 < S) ? opr[(j + 1) * HD + c] : 0.f;
-                const float o2 = (j + 2 < S) ? opr[(j + 2) * HD + c] : 0.f;
-                const float o3 = (j + 3 < S) ? opr[(j + 3) * HD + c] : 0.f;
-#pragma unroll
-                for (int r = 0; r < RMAX; ++r) {
-                    const int i = w + 4 * r;
-                    if (i < S) {
-                        const float4 m4 = *reinterpret_cast<const float4*>(&img[i * SP + j]);
-                        acc[r] += m4.x * o0 + m4.y * o1 + m4.z * o2 + m4.w * o3;
-                    }
+                for (int k = 0; k < SEG; ++k) {
+                    accS = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[k], ka[k], accS, 0, 0, 0);
+                    accD = __builtin_amdgcn_mfma_f32_16x16x4f32(oa[k], va[k], accD, 0, 0, 0);
                 }
             }
+            const int j = nt * 16 + lr;
 #pragma unroll
-            for (int r = 0; r < RMAX; ++r) {
-                const int i = w + 4 * r;
-                if (i < S) dq[(long)i * 3 * d + which * d + c] = acc[r];
+            for (int r = 0; r < 4; ++r) {
+                const int i = mt * 16 + lq * 4 + r;
+                const bool valid = i < S && j < S;
+                const float pv = valid ? expf(accS[r] * scale - lse_s[i]) : 0.f;
+                float mask = 1.f;
+                if (drop.p > 0.f && valid)
+                    mask = cst_drop_mask(drop, dseed, (uint32_t)((((long)b * H + h) * S + i) * S + j));
+                const float dp = valid ? accD[r] * mask : 0.f;
+                Pm[i * SS + j] = pv * mask;
+                float rs = dp * pv;                       // row sum over this tile's 16 columns (one 16-lane group)
+                rs = row16_sum(rs);
+                if (lr == 0) part[i * 4 + nt] = rs;
+                Pf[tt][r] = pv;
+                Df[tt][r] = dp;
+            }
+        }
+    }
+    __syncthreads();
+    // ---- phase B -----------------------------------------------------------------------------
+#pragma unroll
+    for (int tt = 0; tt < TPW; ++tt) {
+        const int t = w + MHA_NW * tt;
+        if (t < ntile) {
+            const int mt = t / ST, nt = t % ST;
+            const int j = nt * 16 + lr;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i = mt * 16 + lq * 4 + r;
+                float delta = 0.f;
+#pragma unroll
+                for (int n = 0; n < ST; ++n) delta += part[i * 4 + n];
+                Dm[i * SS + j] = Pf[tt][r] * (Df[tt][r] - delta) * scale;
+            }
+        }
+    }
+    __syncthreads();
+    // ---- phase C -----------------------------------------------------------------------------
+    // Each work item is one 16-row block of dQ, dK or dV times PAIR adjacent 16-column tiles: the two
+    // accumulator chains share the A operand and hide each other's MFMA latency.
+    float* dq = dqkv + (long)b * S * 3 * d + h * HD;
+    constexpr int PAIR = (NT % 2 == 0) ? 2 : 1, NP = NT / PAIR;
+    constexpr int per = ST * NP, nout = 3 * per;
+    for (int u = w; u < nout; u += MHA_NW) {
+        const int which = u / per, rem = u - which * per;
+        const int mt = rem / NP, n0 = (rem - mt * NP) * PAIR * 16;
+        // which 0: dQ[i][c] = sum_j dS[i][j] K[j][c]   A[m=i][k=j] = Dm[i][j]  (k walks a row)
+        // which 1: dK[j][c] = sum_i dS[i][j] Q[i][c]   A[m=j][k=i] = Dm[i][j]  (k walks a column)
+        // which 2: dV[j][c] = sum_i Pd[i][j] dO[i][c]
+        const float* a = which == 0 ? Dm + (mt * 16 + lr) * SS + lq * KSEG
+                                    : (which == 1 ? Dm : Pm) + (lq * KSEG) * SS + mt * 16 + lr;
+        const int as = which == 0 ? 1 : SS;
+        const float* bp = (which == 0 ? Ks : (which == 1 ? Qs : Os)) + (lq * KSEG) * HDS + n0 + lr;
+        f32x4_t acc[PAIR];
+#pragma unroll
+        for (int q = 0; q < PAIR; ++q) acc[q] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < KSEG; ++k) {
+            const float av = a[k * as];
+#pragma unroll
+            for (int q = 0; q < PAIR; ++q)
+                acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bp[k * HDS + q * 16], acc[q], 0, 0, 0);
+        }
+#pragma unroll
+        for (int q = 0; q < PAIR; ++q) {
+            const int n = n0 + q * 16 + lr;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = mt * 16 + lq * 4 + r;
+                if (m < S && n < HD) dq[(long)m * 3 * d + which * d + n] = acc[q][r];
             }
         }
     }
@@ -225,23 +425,34 @@ extern "C" int cst_mha_bwd(const float* qkv, const float* dout, const float* lse
                            float drop_p, uint32_t drop_seed, uint32_t drop_stream, const void* drop_seed_dev,
                            void* stream) {
     CST_REQUIRE(qkv && dout && lse && dqkv, "cst_mha_bwd: null pointer");
+    CST_REQUIRE((((uintptr_t)qkv | (uintptr_t)dout) & 15) == 0, "cst_mha_bwd: qkv / dout must be 16-byte aligned");
     CST_REQUIRE(B > 0 && S > 0 && S <= MHA_SMAX && H > 0, "cst_mha_bwd: S=%d unsupported (max %d)", S, MHA_SMAX);
     CstDrop dr = cst_make_drop(drop_p, drop_seed, drop_stream, drop_seed_dev);
     const float scale = 1.0f / sqrtf((float)hd);
-    const size_t lds = sizeof(float) * ((size_t)4 * S * hd + (size_t)3 * S * ((S + 3) / 4 * 4 + 4));
+    const size_t lds = sizeof(float) * mha_bwd_lds_floats(S, hd);
     CST_REQUIRE(lds <= 160 * 1024, "cst_mha_bwd: LDS need %zu exceeds 160 KiB", lds);
-    dim3 grid(B * H), block(256);
+    dim3 grid(B * H), block(MHA_NW * 64);
     hipStream_t st = (hipStream_t)stream;
+#define MHA_BWD_LAUNCH(HDV, STV)                                                                                  \
+    {                                                                                                             \
+        if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)mha_bwd_kernel<HDV, STV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL((mha_bwd_kernel<HDV, STV>), grid, block, lds, st, qkv, dout, lse, dqkv, S, H, scale, dr); \
+    }
 #define MHA_BWD_CASE(HDV)                                                                                         \
     case HDV: {                                                                                                   \
-        if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)mha_bwd_kernel<HDV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-        hipLaunchKernelGGL((mha_bwd_kernel<HDV>), grid, block, lds, st, qkv, dout, lse, dqkv, S, H, scale, dr);   \
+        switch ((S + 15) / 16) {                                                                                  \
+            case 1: MHA_BWD_LAUNCH(HDV, 1) break;                                                                 \
+            case 2: MHA_BWD_LAUNCH(HDV, 2) break;                                                                 \
+            case 3: MHA_BWD_LAUNCH(HDV, 3) break;                                                                 \
+            default: MHA_BWD_LAUNCH(HDV, 4) break;                                                                \
+        }                                                                                                         \
         break;                                                                                                    \
     }
     switch (hd) {
         MHA_BWD_CASE(8) MHA_BWD_CASE(16) MHA_BWD_CASE(32) MHA_BWD_CASE(64) MHA_BWD_CASE(96)
         default: cst_set_error("cst_mha_bwd: head dim %d unsupported (8, 16, 32, 64, 96)", hd); return CST_ERR_ARG;
     }
+#undef MHA_BWD_LAUNCH
 #undef MHA_BWD_CASE
     CST_LAUNCH_CHECK("cst_mha_bwd");
     return CST_OK;

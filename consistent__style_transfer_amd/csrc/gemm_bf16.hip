@@ -163,6 +163,52 @@ __device__ __forceinline__ void bgemm_store(const BGemmArgs& g, uint32_t dseed, 
     if (g.Cb) g.Cb[(long)m * g.ldcb + n] = f2bf16(v);
 }
 
+// Which of the epilogue's streams can move as 16-byte (fp32) / 8-byte (bf16) vectors: four
+// consecutive columns per lane.  Evaluated once per kernel (wave-uniform).
+__device__ __forceinline__ bool bgemm_vec_ok(const BGemmArgs& g) {
+    const bool vc = !g.C || ((g.ldc % 4 == 0) && ((reinterpret_cast<uintptr_t>(g.C) & 15) == 0));
+    const bool vb = !g.Cb || ((g.ldcb % 4 == 0) && ((reinterpret_cast<uintptr_t>(g.Cb) & 7) == 0));
+    const bool va = !g.addend || ((g.ldadd % 4 == 0) && ((reinterpret_cast<uintptr_t>(g.addend) & 15) == 0));
+    const bool vx = g.act < 3 || ((g.ldaux % 4 == 0) && ((reinterpret_cast<uintptr_t>(g.aux) & 7) == 0));
+    const bool vbias = !g.bias || ((reinterpret_cast<uintptr_t>(g.bias) & 15) == 0);
+    return vc && vb && va && vx && vbias;
+}
+
+// columns n..n+3 of row m (n % 4 == 0, n + 3 < N, bgemm_vec_ok): same arithmetic as bgemm_store
+__device__ __forceinline__ void bgemm_store4(const BGemmArgs& g, uint32_t dseed, int m, int n, const float av[4]) {
+    float o[4];
+    float b4[4] = {0.f, 0.f, 0.f, 0.f}, a4[4] = {0.f, 0.f, 0.f, 0.f}, x4[4] = {1.f, 1.f, 1.f, 1.f};
+    if (g.bias) { const float4 t = *reinterpret_cast<const float4*>(g.bias + n); b4[0] = t.x; b4[1] = t.y; b4[2] = t.z; b4[3] = t.w; }
+    if (g.addend) { const float4 t = *reinterpret_cast<const float4*>(g.addend + (long)m * g.ldadd + n); a4[0] = t.x; a4[1] = t.y; a4[2] = t.z; a4[3] = t.w; }
+    if (g.act >= 3) {
+        const uint2 u = *reinterpret_cast<const uint2*>(g.aux + (long)m * g.ldaux + n);
+        x4[0] = bf162f((bf16_t)(u.x & 0xffffu)); x4[1] = bf162f((bf16_t)(u.x >> 16));
+        x4[2] = bf162f((bf16_t)(u.y & 0xffffu)); x4[3] = bf162f((bf16_t)(u.y >> 16));
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        float v = g.alpha * av[e] + b4[e];
+        v += a4[e];
+        if (g.act == 1) v = v > 0.f ? v : 0.f;
+        else if (g.act == 2) v = v > 0.f ? v : 0.1f * v;
+        else if (g.act == 3) v = x4[e] > 0.f ? v * g.gate_scale : 0.f;
+        else if (g.act == 4) v = x4[e] > 0.f ? v : 0.1f * v;
+        if (g.drop.p > 0.f) v *= cst_drop_mask(g.drop, dseed, (uint32_t)((long)m * g.N + n + e));
+        o[e] = v;
+    }
+    if (g.C) {
+        float4* cp = reinterpret_cast<float4*>(g.C + (long)m * g.ldc + n);
+        if (g.accumulate) { const float4 t = *cp; o[0] += t.x; o[1] += t.y; o[2] += t.z; o[3] += t.w; }
+        *cp = make_float4(o[0], o[1], o[2], o[3]);
+    }
+    if (g.Cb) {
+        uint2 u;
+        u.x = (uint32_t)f2bf16(o[0]) | ((uint32_t)f2bf16(o[1]) << 16);
+        u.y = (uint32_t)f2bf16(o[2]) | ((uint32_t)f2bf16(o[3]) << 16);
+        *reinterpret_cast<uint2*>(g.Cb + (long)m * g.ldcb + n) = u;
+    }
+}
+
 template <int BM, int BN, int NSTAGE>
 __global__ __launch_bounds__(256) void cst_gemm_bf16_kernel(BGemmArgs g) {
     constexpr int A_BYTES = BM * BROW, B_BYTES = BN * BROW, ST_BYTES = A_BYTES + B_BYTES;
@@ -288,9 +334,7 @@ __global__ __launch_bounds__(256) void cst_gemm_bf16_kernel(BGemmArgs g) {
             for (int r = 0; r < 4; ++r) Cs[(i * 16 + lq * 4 + r) * CLD + j * 16 + lr] = acc[i][j][r];
     __builtin_amdgcn_wave_barrier();
     constexpr int C4 = WN / 4;
-    const bool simple = !g.addend && g.act < 3 && g.drop.p <= 0.f && !g.accumulate;
-    const bool vecC = g.C && (g.ldc % 4 == 0) && ((reinterpret_cast<uintptr_t>(g.C) & 15) == 0);
-    const bool vecB = g.Cb && (g.ldcb % 4 == 0) && ((reinterpret_cast<uintptr_t>(g.Cb) & 7) == 0);
+    const bool vec = bgemm_vec_ok(g);
 #pragma unroll
     for (int it = 0; it < WM * C4 / 64; ++it) {
         const int idx = lane + 64 * it;
@@ -299,23 +343,8 @@ __global__ __launch_bounds__(256) void cst_gemm_bf16_kernel(BGemmArgs g) {
         if (m >= g.M || n >= g.N) continue;
         const float4 a4 = *reinterpret_cast<const float4*>(&Cs[rr * CLD + cc]);
         const float av[4] = {a4.x, a4.y, a4.z, a4.w};
-        if (simple && n + 3 < g.N && (!g.C || vecC) && (!g.Cb || vecB)) {
-            float o[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                float v = g.alpha * av[e] + (g.bias ? g.bias[n + e] : 0.f);
-                if (g.act == 1) v = v > 0.f ? v : 0.f;
-                else if (g.act == 2) v = v > 0.f ? v : 0.1f * v;
-                o[e] = v;
-            }
-            if (g.C) *reinterpret_cast<float4*>(g.C + (long)m * g.ldc + n) = make_float4(o[0], o[1], o[2], o[3]);
-            if (g.Cb) {
-                uint2 u;
-                u.x = (uint32_t)f2bf16(o[0]) | ((uint32_t)f2bf16(o[1]) << 16);
-                u.y = (uint32_t)f2bf16(o[2]) | ((uint32_t)f2bf16(o[3]) << 16);
-                *reinterpret_cast<uint2*>(g.Cb + (long)m * g.ldcb + n) = u;
-            }
-        } else {
+        if (vec && n + 3 < g.N) bgemm_store4(g, dseed, m, n, av);
+        else {
 #pragma unroll
             for (int e = 0; e < 4; ++e)
                 if (n + e < g.N) bgemm_store(g, dseed, m, n + e, av[e]);
@@ -326,6 +355,20 @@ __global__ __launch_bounds__(256) void cst_gemm_bf16_kernel(BGemmArgs g) {
 __global__ __launch_bounds__(256) void cst_gemm_bf16_reduce(BGemmArgs g) {
     const uint32_t dseed = g.drop.p > 0.f ? cst_drop_seed(g.drop) : 0u;
     const long MN = (long)g.M * g.N;
+    if ((g.N & 3) == 0 && bgemm_vec_ok(g) && (reinterpret_cast<uintptr_t>(g.slab) & 15) == 0) {
+        const long Q = MN >> 2;
+        for (long q = (long)blockIdx.x * 256 + threadIdx.x; q < Q; q += (long)gridDim.x * 256) {
+            float4 acc = *reinterpret_cast<const float4*>(g.slab + 4 * q);
+            for (int s = 1; s < g.splits; ++s) {
+                const float4 t = *reinterpret_cast<const float4*>(g.slab + s * MN + 4 * q);
+                acc.x += t.x; acc.y += t.y; acc.z += t.z; acc.w += t.w;
+            }
+            const long e = 4 * q;
+            const float av[4] = {acc.x, acc.y, acc.z, acc.w};
+            bgemm_store4(g, dseed, (int)(e / g.N), (int)(e % g.N), av);
+        }
+        return;
+    }
     for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < MN; e += (long)gridDim.x * 256) {
         float acc = 0.f;
         for (int s = 0; s < g.splits; ++s) acc += g.slab[s * MN + e];
@@ -408,7 +451,7 @@ extern "C" int cst_gemm_bf16(const void* A, long lda, const void* B, long ldb,
     else { if (three) bgemm_launch<64, 128, 3>(g, st); else bgemm_launch<64, 128, 2>(g, st); }
     CST_LAUNCH_CHECK("cst_gemm_bf16");
     if (splits > 1) {
-        long mn = (long)M * N;
+        long mn = ((long)M * N + 3) / 4;          // four columns per thread on the vector path
         int rb = (int)((mn + 255) / 256); if (rb > 2048) rb = 2048;
         hipLaunchKernelGGL(cst_gemm_bf16_reduce, dim3(rb), dim3(256), 0, st, g);
         CST_LAUNCH_CHECK("cst_gemm_bf16_reduce");

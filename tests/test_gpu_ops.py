@@ -265,7 +265,8 @@ def test_colsum_and_reduce(ops):
 
 # ----------------------------------------------------------------------------------- attention
 @pytest.mark.parametrize("B,S,H,hd,p", [(2, 6, 4, 8, 0.0), (3, 13, 2, 32, 0.1), (2, 36, 8, 64, 0.0), (2, 36, 8, 64, 0.1),
-                                        (1, 60, 8, 64, 0.0), (2, 18, 8, 96, 0.1), (1, 64, 2, 64, 0.0)])
+                                        (1, 60, 8, 64, 0.0), (2, 18, 8, 96, 0.1), (1, 64, 2, 64, 0.0),
+                                        (2, 1, 2, 16, 0.0), (2, 17, 4, 16, 0.1), (2, 48, 2, 32, 0.1), (3, 33, 2, 64, 0.1)])
 def test_mha(ops, B, S, H, hd, p):
     from consistent__style_transfer_amd._lib import call
     d = H * hd
