@@ -5,6 +5,7 @@ PyTorch supplies device memory, streams and the autograd tape only -- every numb
 by libcst_hip.so.  Nothing here falls back to torch arithmetic.
 """
 import math
+import weakref
 
 import torch
 
@@ -132,12 +133,13 @@ def weight_bf16(W):
     if grp is not None and capturing:
         return cast_bf16(W.detach())
     ver = (W._version, grp.version if grp is not None else 0, W.data_ptr(), tuple(W.shape))
-    hit = _WCACHE.get(id(W))
-    if hit is not None and hit[0] == ver:
-        return hit[1], hit[2]
+    key = id(W)
+    hit = _WCACHE.get(key)
+    if hit is not None and hit[0]() is W and hit[1] == ver:      # the weak reference guards against a recycled id()
+        return hit[2], hit[3]
     rm, tr = cast_bf16(W.detach())
-    if not capturing:
-        _WCACHE[id(W)] = (ver, rm, tr)               # never cache tensors that live in a graph's private pool
+    if not capturing:                                # never cache tensors that live in a graph's private pool
+        _WCACHE[key] = (weakref.ref(W, lambda _r, k=key: _WCACHE.pop(k, None)), ver, rm, tr)
     return rm, tr
 
 
@@ -615,6 +617,12 @@ def bce_logits_loss(x, const, weight=1.0):
 # convolution bank = im2col + MFMA GEMM (bias, relu) + max over time, all branches into one
 # feature matrix (TextCNN classifier.py:30-34; RelGAN_D discriminator.py:41-44)
 # =============================================================================================
+def _relconv_ok(L, E, R, w):
+    """Limits of the fused RelGAN_D convolution kernels (csrc/relconv.hip)."""
+    k, es = w.shape[2], E // R
+    return E % R == 0 and es % 4 == 0 and k * es <= 40 and 1 <= L - k + 1 <= 144 and w.shape[0] <= 320
+
+
 class ConvBankFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, e, mode, R, *wb):
@@ -628,11 +636,18 @@ class ConvBankFn(torch.autograd.Function):
         dev = e.device
         feats = torch.empty(G, Ftot, device=dev, dtype=torch.float32)
         saved, off = [], 0
+        fused = mode == 1 and all(_relconv_ok(L, E, R, w) for w in ws)
         for w, b in zip(ws, bs):
             F_, k = w.shape[0], w.shape[2]
             if mode == 1 and L < k:
                 raise RuntimeError(f"RelGAN_D convolution needs L >= k (sequence length {L} < filter size {k}; "
                                    "discriminator.py:21-24 has no padding)")
+            if fused:                                      # conv + relu + max over time in one kernel, no [G*T, F] plane
+                arg = torch.empty(G, F_, device=dev, dtype=torch.int32)
+                call("cst_relconv_fwd", e, B, L, E, R, k, w, b, F_, feats[:, off:], Ftot, arg)
+                saved += [e, arg]
+                off += F_
+                continue
             T = L + k - 1 if mode == 0 else L - k + 1
             KE = k * (E if mode == 0 else E // R)
             col = torch.empty(G * T, KE, device=dev, dtype=torch.float32)
@@ -644,6 +659,7 @@ class ConvBankFn(torch.autograd.Function):
             off += F_
         ctx.save_for_backward(feats, *ws, *saved)
         ctx.cfg = (B, L, E, mode, R, len(ws))
+        ctx.fused = fused
         return feats
 
     @staticmethod
@@ -661,6 +677,19 @@ class ConvBankFn(torch.autograd.Function):
         for i, w in enumerate(ws):
             col, arg = saved[2 * i], saved[2 * i + 1]
             F_, k = w.shape[0], w.shape[2]
+            if ctx.fused:                                  # `col` is the embedded input e itself
+                if wg:
+                    dw, db = torch.empty_like(w), torch.empty(F_, device=dev, dtype=torch.float32)
+                    call("cst_relconv_bwd_weight", dfeats[:, off:], Ftot, feats[:, off:], Ftot, arg, col, B, L, E, R, k, F_,
+                         dw, db, _workspace(dev), WS_FLOATS)
+                    grads += [dw, db]
+                else:
+                    grads += [None, None]
+                if de is not None:
+                    call("cst_relconv_bwd_input", dfeats[:, off:], Ftot, feats[:, off:], Ftot, arg, w, B, L, E, R, k, F_,
+                         de, int(i > 0))
+                off += F_
+                continue
             T = col.shape[0] // G
             KE = col.shape[1]
             dy = torch.empty(G * T, F_, device=dev, dtype=torch.float32)

@@ -166,6 +166,24 @@ int cst_tps_embed_bwd(const float* dx, const int64_t* ids, float* dpre, float* d
 int cst_im2col(const float* e, float* col, int B, int L, int E, int k, int mode, int R, void* stream);
 int cst_col2im(const float* dcol, float* de, int B, int L, int E, int k, int mode, int R, int accumulate, void* stream);
 
+/* One filter size of the RelGAN_D convolution bank, fused: Conv2d(1, F, (k, E/R), stride (1, E/R)) over
+ * the R representations of e [B, L, E], relu, max over time (discriminator.py:21-24, 41-44).
+ *   feats[g, f] = max_t relu(bias[f] + sum_{x<k, c<E/R} e[b, t+x, rep*E/R + c] * w[f, x*E/R + c]),  g = b*R + rep
+ *   arg[g, f]   = first t attaining the maximum (int32 [B*R, F])
+ * feats may be a column slice of the concatenated feature matrix (leading dimension ldf).
+ * bwd_input:  de (+)= d feats/d e (the relu gate is feats > 0); bwd_weight: dw [F, k*E/R], db [F]
+ * (workspace: cst_relconv_bwd_weight_workspace_floats floats of scratch, contents irrelevant).
+ * Limits: k*E/R <= 40, (E/R) % 4 == 0, L-k+1 <= 144, F <= 320 -- status 1 outside them. */
+int cst_relconv_fwd(const float* e, int B, int L, int E, int R, int k, const float* w, const float* bias, int F,
+                    float* feats, long ldf, int* arg, void* stream);
+int cst_relconv_bwd_input(const float* dfeats, long ldd, const float* feats, long ldf, const int* arg,
+                          const float* w, int B, int L, int E, int R, int k, int F,
+                          float* de, int accumulate, void* stream);
+long cst_relconv_bwd_weight_workspace_floats(int B, int R, int k, int E, int F);
+int cst_relconv_bwd_weight(const float* dfeats, long ldd, const float* feats, long ldf, const int* arg,
+                           const float* e, int B, int L, int E, int R, int k, int F,
+                           float* dw, float* db, float* workspace, long workspace_floats, void* stream);
+
 /* max over the middle axis of x [G,T,F] with argmax (classifier.py:32; discriminator.py:42; match.py:41). */
 int cst_seqmax_fwd(const float* x, float* out, long ldo, int* arg, int G, int T, int F, void* stream);
 int cst_seqmax_bwd(const float* dout, long ldd, const int* arg, const float* y, long ldy, int relu_gate,

@@ -383,18 +383,21 @@ def test_tps_embed(ops):
         close(a.grad, b.grad, 3e-4, 3e-5)
 
 
-@pytest.mark.parametrize("mode", [0, 1])
-def test_conv_bank(ops, mode):
+@pytest.mark.parametrize("mode,B,L,E,R,nf", [(0, 3, 7, 16, 4, 5), (1, 3, 7, 16, 4, 6),
+                                              (1, 2, 7, 128, 16, 300),        # reference constants, fused kernels
+                                              (1, 40, 18, 128, 16, 300),      # several workgroups, > 1 sample per gather workgroup
+                                              (1, 5, 5, 32, 4, 13),           # T = 1 for k = 5, ragged filter tile
+                                              (1, 2, 6, 24, 2, 7)])           # k * E/R > 40 for k >= 4: im2col fallback
+def test_conv_bank(ops, mode, B, L, E, R, nf):
     ops.set_precision("f32")
-    B, L, E, R = 3, 7, 16, 4
     e = rnd(B, L, E, seed=1).requires_grad_(True)
     if mode == 0:
-        convs = [torch.nn.Conv2d(1, 5, (k, E), padding=(k - 1, 0)) for k in (3, 4, 5)]
+        convs = [torch.nn.Conv2d(1, nf, (k, E), padding=(k - 1, 0)) for k in (3, 4, 5)]
         ys = [F.relu(c(e.unsqueeze(1))).squeeze(3) for c in convs]
         ref = torch.cat([F.max_pool1d(y, y.size(2)).squeeze(2) for y in ys], 1)
     else:
         es = E // R
-        convs = [torch.nn.Conv2d(1, 6, (f, es), stride=(1, es)) for f in (2, 3, 4, 5)]
+        convs = [torch.nn.Conv2d(1, nf, (f, es), stride=(1, es)) for f in (2, 3, 4, 5)]
         cons = [F.relu(c(e.unsqueeze(1))) for c in convs]
         pools = [F.max_pool2d(c, (c.size(2), 1)).squeeze(2) for c in cons]
         ref = torch.cat(pools, 1).permute(0, 2, 1).contiguous().view(B * R, -1)
