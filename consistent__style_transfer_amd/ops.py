@@ -620,7 +620,7 @@ def bce_logits_loss(x, const, weight=1.0):
 def _relconv_ok(L, E, R, w):
     """Limits of the fused RelGAN_D convolution kernels (csrc/relconv.hip)."""
     k, es = w.shape[2], E // R
-    return E % R == 0 and es % 4 == 0 and k * es <= 40 and 1 <= L - k + 1 <= 144 and w.shape[0] <= 320
+    return E % R == 0 and es % 4 == 0 and k * es <= 40 and 1 <= L - k + 1 <= 128 and w.shape[0] <= 320
 
 
 class ConvBankFn(torch.autograd.Function):

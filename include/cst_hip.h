@@ -173,7 +173,7 @@ int cst_col2im(const float* dcol, float* de, int B, int L, int E, int k, int mod
  * feats may be a column slice of the concatenated feature matrix (leading dimension ldf).
  * bwd_input:  de (+)= d feats/d e (the relu gate is feats > 0); bwd_weight: dw [F, k*E/R], db [F]
  * (workspace: cst_relconv_bwd_weight_workspace_floats floats of scratch, contents irrelevant).
- * Limits: k*E/R <= 40, (E/R) % 4 == 0, L-k+1 <= 144, F <= 320 -- status 1 outside them. */
+ * Limits: k*E/R <= 40, (E/R) % 4 == 0, L-k+1 <= 128, F <= 320 -- status 1 outside them. */
 int cst_relconv_fwd(const float* e, int B, int L, int E, int R, int k, const float* w, const float* bias, int F,
                     float* feats, long ldf, int* arg, void* stream);
 int cst_relconv_bwd_input(const float* dfeats, long ldd, const float* feats, long ldf, const int* arg,
