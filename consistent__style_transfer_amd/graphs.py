@@ -13,6 +13,7 @@ counter.
 """
 import torch
 
+from . import ops
 from ._lib import call
 
 
@@ -37,8 +38,12 @@ class GraphedStep:
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
-            self.static_out = self._body()
+        ops.capture_scope_reset()
+        try:
+            with torch.cuda.graph(self.graph):
+                self.static_out = self._body()
+        finally:
+            ops.capture_scope_reset()
         torch.cuda.synchronize()
 
     def _body(self):

@@ -117,6 +117,7 @@ def cast_bf16(x, want_rm=True, want_t=True, drop=NO_DROP):
 
 
 _WCACHE = {}
+_WCACHE_CAPTURE = {}
 
 
 def weight_bf16(W):
@@ -127,13 +128,21 @@ def weight_bf16(W):
     (load_state_dict, .copy_) and the storage address.  TRAINED weights are cached only between
     eager calls of one optimizer version and are ALWAYS recast while a hipGraph is being captured:
     a capture must not bake in a cached tensor, because replays have to see the weights Adam has
-    updated since (and the cached tensor would be freed when the cache entry is replaced)."""
+    updated since (and the cached tensor would be freed when the cache entry is replaced); within one
+    capture they are shared between the uses that see the same optimizer version."""
     grp = getattr(W, "_cst_group", None)
     capturing = torch.cuda.is_current_stream_capturing()
-    if grp is not None and capturing:
-        return cast_bf16(W.detach())
     ver = (W._version, grp.version if grp is not None else 0, W.data_ptr(), tuple(W.shape))
     key = id(W)
+    if grp is not None and capturing:
+        # inside one capture the copies made earlier in the same capture stay valid until the next
+        # optimizer step of the group (forward and backward of a layer, the decodes of one stage step)
+        hit = _WCACHE_CAPTURE.get(key)
+        if hit is not None and hit[0]() is W and hit[1] == ver:
+            return hit[2], hit[3]
+        rm, tr = cast_bf16(W.detach())
+        _WCACHE_CAPTURE[key] = (weakref.ref(W), ver, rm, tr)
+        return rm, tr
     hit = _WCACHE.get(key)
     if hit is not None and hit[0]() is W and hit[1] == ver:      # the weak reference guards against a recycled id()
         return hit[2], hit[3]
@@ -141,6 +150,12 @@ def weight_bf16(W):
     if not capturing:                                # never cache tensors that live in a graph's private pool
         _WCACHE[key] = (weakref.ref(W, lambda _r, k=key: _WCACHE.pop(k, None)), ver, rm, tr)
     return rm, tr
+
+
+def capture_scope_reset():
+    """Called by graphs.GraphedStep right before and right after a capture: copies cached during a
+    capture live in that graph's private pool and mean nothing to any other capture or to eager code."""
+    _WCACHE_CAPTURE.clear()
 
 
 def gemm_bf16(Ab, Bb, M, N, C=None, Cb=None, bias=None, addend=None, aux=None, act=0, gate_scale=1.0, alpha=1.0,
