@@ -132,6 +132,7 @@ struct BGemmArgs {
     float alpha, gate_scale;
     CstDrop drop;
     int splits, k_per_split;        // k_per_split multiple of 64
+    int slab_only;                  // write the raw partial product(s) to the slab even when splits == 1
     float* slab;
 };
 
@@ -304,7 +305,7 @@ __global__ __launch_bounds__(256) void cst_gemm_bf16_kernel(BGemmArgs g) {
     }
     __syncthreads();                                  // all tile reads done before smem is reused for C
 
-    if (g.splits > 1) {
+    if (g.splits > 1 || g.slab_only) {
         float* slab = g.slab + ((long)blockIdx.y * g.M) * g.N;
 #pragma unroll
         for (int i = 0; i < TM; ++i)
@@ -419,6 +420,7 @@ extern "C" int cst_gemm_bf16(const void* A, long lda, const void* B, long ldb,
     g.bias = bias; g.addend = addend; g.aux = (const bf16_t*)aux;
     g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.ldcb = ldcb; g.ldadd = ldadd; g.ldaux = ldaux;
     g.M = M; g.N = N; g.K = K; g.act = act; g.alpha = alpha; g.gate_scale = gate_scale; g.accumulate = accumulate;
+    g.slab_only = 0;
     g.drop = cst_make_drop(drop_p, drop_seed, drop_stream, drop_seed_dev);
     // tile / ring / split choice (tools/gemm_bench.py bf16nt): the 2-stage ring with two workgroups per
     // CU beats the 3-stage one at these sizes; 64x128 tiles when they alone give >= 256 workgroups,
@@ -456,5 +458,116 @@ extern "C" int cst_gemm_bf16(const void* A, long lda, const void* B, long ldb,
         hipLaunchKernelGGL(cst_gemm_bf16_reduce, dim3(rb), dim3(256), 0, st, g);
         CST_LAUNCH_CHECK("cst_gemm_bf16_reduce");
     }
+    return CST_OK;
+}
+
+// =============================================================================================
+// Gate GEMM + LSTM cell in two launches (rnn.py:25-33 nn.LSTM step; gate order i, f, g, o).
+// The GEMM kernel leaves its split-K partial products in the workspace; the second kernel sums them
+// (split order), adds bias / the precomputed input projection and applies the cell of
+// cst_lstm_cell_fwd, one thread per 4 hidden units -- the separate reduce and cell launches and the
+// round trip of the pre-activations disappear from every recurrent step.
+// =============================================================================================
+struct LstmEpi {
+    const float* slab; int splits; int M, H;
+    const float* bias; const float* addend; long ldadd;
+    float* gates; long ldg; const float* c_prev; long ldcp;
+    float* h_out; long ldh; float* c_out; long ldc; float* h_out2; long ldh2;
+    bf16_t* hb; long ldhb; bf16_t* hb2; long ldhb2;
+};
+
+__device__ __forceinline__ float lstm_sigmoid(float x) { return 1.f / (1.f + expf(-x)); }
+
+__global__ __launch_bounds__(256) void cst_gemm_bf16_lstm_reduce(LstmEpi p) {
+    const int H4 = p.H >> 2;
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= p.M * H4) return;
+    const int m = idx / H4, u = (idx - m * H4) * 4;
+    const long MN = (long)p.M * 4 * p.H;
+    float pre[4][4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const long off = (long)m * 4 * p.H + (long)q * p.H + u;
+        float4 a = *reinterpret_cast<const float4*>(p.slab + off);
+        for (int s = 1; s < p.splits; ++s) {
+            const float4 t = *reinterpret_cast<const float4*>(p.slab + s * MN + off);
+            a.x += t.x; a.y += t.y; a.z += t.z; a.w += t.w;
+        }
+        if (p.bias) { const float4 t = *reinterpret_cast<const float4*>(p.bias + q * p.H + u); a.x += t.x; a.y += t.y; a.z += t.z; a.w += t.w; }
+        if (p.addend) {
+            const float4 t = *reinterpret_cast<const float4*>(p.addend + (long)m * p.ldadd + q * p.H + u);
+            a.x += t.x; a.y += t.y; a.z += t.z; a.w += t.w;
+        }
+        pre[q][0] = a.x; pre[q][1] = a.y; pre[q][2] = a.z; pre[q][3] = a.w;
+    }
+    const float4 cp4 = *reinterpret_cast<const float4*>(p.c_prev + (long)m * p.ldcp + u);
+    const float cp[4] = {cp4.x, cp4.y, cp4.z, cp4.w};
+    float gi[4], gf[4], gg[4], go[4], c[4], h[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        gi[e] = lstm_sigmoid(pre[0][e]);
+        gf[e] = lstm_sigmoid(pre[1][e]);
+        gg[e] = tanhf(pre[2][e]);
+        go[e] = lstm_sigmoid(pre[3][e]);
+        c[e] = gf[e] * cp[e] + gi[e] * gg[e];
+        h[e] = go[e] * tanhf(c[e]);
+    }
+    float* g = p.gates + (long)m * p.ldg + u;
+    *reinterpret_cast<float4*>(g) = make_float4(gi[0], gi[1], gi[2], gi[3]);
+    *reinterpret_cast<float4*>(g + p.H) = make_float4(gf[0], gf[1], gf[2], gf[3]);
+    *reinterpret_cast<float4*>(g + 2 * p.H) = make_float4(gg[0], gg[1], gg[2], gg[3]);
+    *reinterpret_cast<float4*>(g + 3 * p.H) = make_float4(go[0], go[1], go[2], go[3]);
+    *reinterpret_cast<float4*>(p.c_out + (long)m * p.ldc + u) = make_float4(c[0], c[1], c[2], c[3]);
+    const float4 h4 = make_float4(h[0], h[1], h[2], h[3]);
+    *reinterpret_cast<float4*>(p.h_out + (long)m * p.ldh + u) = h4;
+    if (p.h_out2) *reinterpret_cast<float4*>(p.h_out2 + (long)m * p.ldh2 + u) = h4;
+    uint2 hb;
+    hb.x = (uint32_t)f2bf16(h[0]) | ((uint32_t)f2bf16(h[1]) << 16);
+    hb.y = (uint32_t)f2bf16(h[2]) | ((uint32_t)f2bf16(h[3]) << 16);
+    if (p.hb) *reinterpret_cast<uint2*>(p.hb + (long)m * p.ldhb + u) = hb;
+    if (p.hb2) *reinterpret_cast<uint2*>(p.hb2 + (long)m * p.ldhb2 + u) = hb;
+}
+
+extern "C" int cst_gemm_bf16_lstm(const void* A, long lda, const void* B, long ldb, int M, int H, int K,
+                                  const float* bias, const float* addend, long ldadd,
+                                  float* gates, long ldg, const float* c_prev, long ldcp,
+                                  float* h_out, long ldh, float* c_out, long ldc, float* h_out2, long ldh2,
+                                  void* h_bf16, long ldhb, void* h_bf16_2, long ldhb2,
+                                  int splitk, float* workspace, long workspace_floats, void* stream) {
+    CST_REQUIRE(A && B && gates && c_prev && h_out && c_out && workspace, "cst_gemm_bf16_lstm: null pointer");
+    CST_REQUIRE(M > 0 && H > 0 && H % 4 == 0 && K > 0 && K % 64 == 0, "cst_gemm_bf16_lstm: H %% 4 and K %% 64 must be 0 (H=%d, K=%d)", H, K);
+    CST_REQUIRE(lda >= K && ldb >= K && lda % 8 == 0 && ldb % 8 == 0 && (((uintptr_t)A | (uintptr_t)B) & 15) == 0,
+                "cst_gemm_bf16_lstm: operands must be 16-byte aligned with leading dimensions >= K, multiples of 8");
+    const bool al = ((ldg | ldcp | ldh | ldc | (addend ? ldadd : 0) | (h_out2 ? ldh2 : 0) | (h_bf16 ? ldhb : 0) | (h_bf16_2 ? ldhb2 : 0)) % 4 == 0) &&
+                    ((((uintptr_t)gates | (uintptr_t)c_prev | (uintptr_t)h_out | (uintptr_t)c_out | (uintptr_t)bias | (uintptr_t)addend |
+                       (uintptr_t)h_out2 | (uintptr_t)workspace) & 15) == 0) &&
+                    ((((uintptr_t)h_bf16 | (uintptr_t)h_bf16_2) & 7) == 0);
+    CST_REQUIRE(al, "cst_gemm_bf16_lstm: every row pointer must be 16-byte aligned (leading dimensions multiples of 4)");
+    const int N = 4 * H;
+    BGemmArgs g;
+    g.A = (const bf16_t*)A; g.B = (const bf16_t*)B; g.C = nullptr; g.Cb = nullptr;
+    g.bias = nullptr; g.addend = nullptr; g.aux = nullptr;
+    g.lda = lda; g.ldb = ldb; g.ldc = 0; g.ldcb = 0; g.ldadd = 0; g.ldaux = 0;
+    g.M = M; g.N = N; g.K = K; g.act = 0; g.alpha = 1.f; g.gate_scale = 1.f; g.accumulate = 0;
+    g.drop = cst_make_drop(0.f, 0, 0, nullptr);
+    g.slab_only = 1;
+    const long tiles = (long)cst_div_up(M, 64) * cst_div_up(N, 128);
+    int splits = splitk > 0 ? splitk : (int)((384 + tiles - 1) / tiles);
+    if (splits > K / 128) splits = K / 128;
+    if (splits < 1) splits = 1;
+    int kps = cst_div_up(cst_div_up(K, splits), 64) * 64;
+    splits = cst_div_up(K, kps);
+    CST_REQUIRE((long)splits * M * N <= workspace_floats, "cst_gemm_bf16_lstm: workspace too small");
+    g.splits = splits; g.k_per_split = kps; g.slab = workspace;
+    hipStream_t st = (hipStream_t)stream;
+    bgemm_launch<64, 128, 2>(g, st);
+    CST_LAUNCH_CHECK("cst_gemm_bf16_lstm");
+    LstmEpi p;
+    p.slab = workspace; p.splits = splits; p.M = M; p.H = H; p.bias = bias; p.addend = addend; p.ldadd = ldadd;
+    p.gates = gates; p.ldg = ldg; p.c_prev = c_prev; p.ldcp = ldcp; p.h_out = h_out; p.ldh = ldh; p.c_out = c_out; p.ldc = ldc;
+    p.h_out2 = h_out2; p.ldh2 = ldh2; p.hb = (bf16_t*)h_bf16; p.ldhb = ldhb; p.hb2 = (bf16_t*)h_bf16_2; p.ldhb2 = ldhb2;
+    const int nthr = M * (H / 4);
+    hipLaunchKernelGGL(cst_gemm_bf16_lstm_reduce, dim3((nthr + 255) / 256), dim3(256), 0, st, p);
+    CST_LAUNCH_CHECK("cst_gemm_bf16_lstm_reduce");
     return CST_OK;
 }

@@ -39,6 +39,13 @@ def _cell_fwd(gates, c_prev, h_out, c_out, h_out2, B, H, hb=None, hb2=None):
          c_out, c_out.stride(0), h_out2, _st(h_out2), hb, _st(hb), hb2, _st(hb2), B, H)
 
 
+def _gemm_cell_fwd(Ab, Bb, gates, c_prev, h_out, c_out, h_out2, B, H, bias=None, addend=None, hb=None, hb2=None):
+    """Gate product + cell in two launches (no separate split-K reduce, no cell kernel)."""
+    call("cst_gemm_bf16_lstm", Ab, Ab.stride(0), Bb, Bb.stride(0), B, H, Ab.shape[1], bias, addend, _st(addend),
+         gates, gates.stride(0), c_prev, c_prev.stride(0), h_out, h_out.stride(0), c_out, c_out.stride(0),
+         h_out2, _st(h_out2), hb, _st(hb), hb2, _st(hb2), ops.LSTM_SPLITK, ops._workspace(gates.device), ops.WS_FLOATS)
+
+
 def _cell_bwd(gates, c_prev, c_new, dh, dh2, dc, dgates, dc_prev, B, H, dgb=None):
     call("cst_lstm_cell_bwd", gates, gates.stride(0), c_prev, c_prev.stride(0), c_new, c_new.stride(0),
          dh, _st(dh), dh2, _st(dh2), dc, _st(dc), dgates, dgates.stride(0), dc_prev, dc_prev.stride(0),
@@ -119,15 +126,16 @@ class GeneratorFn(torch.autograd.Function):
                     c_in = cenc[d, tp]
                     h_in_b = memb[:, tp * 2 * H + d * H: tp * 2 * H + (d + 1) * H] if use_b else None
                 g = genc[d, t]
-                if use_b:
-                    gemm_bf16(h_in_b, whh_b, B, 4 * H, C=g, addend=xp[:, t * 4 * H:(t + 1) * 4 * H])
-                else:
-                    gemm(h_in, True, w_hh, True, g, B, 4 * H, H, addend=xp[:, t * 4 * H:(t + 1) * 4 * H])
                 last = n == Lp - 1
                 c_out = c_cat[:, d * H:(d + 1) * H] if last else cenc[d, t]
                 h_next = None if last else hp2[:, order[n + 1] * H:(order[n + 1] + 1) * H]
-                _cell_fwd(g, c_in, mem2[:, t * 2 * H + d * H: t * 2 * H + (d + 1) * H], c_out, h_next, B, H,
-                          hb=memb[:, t * 2 * H + d * H: t * 2 * H + (d + 1) * H] if use_b else None)
+                h_t = mem2[:, t * 2 * H + d * H: t * 2 * H + (d + 1) * H]
+                if use_b:
+                    _gemm_cell_fwd(h_in_b, whh_b, g, c_in, h_t, c_out, h_next, B, H, addend=xp[:, t * 4 * H:(t + 1) * 4 * H],
+                                   hb=memb[:, t * 2 * H + d * H: t * 2 * H + (d + 1) * H])
+                else:
+                    gemm(h_in, True, w_hh, True, g, B, 4 * H, H, addend=xp[:, t * 4 * H:(t + 1) * 4 * H])
+                    _cell_fwd(g, c_in, h_t, c_out, h_next, B, H)
 
         # ---- decoder initial state (rnn.py:67-69) --------------------------------------------
         c0 = linear_fwd(c_cat, P["transfer.weight"], None, act=2)
@@ -162,15 +170,15 @@ class GeneratorFn(torch.autograd.Function):
         r12 = r1.view(B, T * Hd)
         x_c = x.contiguous() if x is not None else None
         for s in range(T):
-            if use_b:
-                gemm_bf16(XHb[s], wcat_b, B, 4 * Hd, C=gdec[s], bias=bdec)
-            else:
-                gemm(XH[s], True, wcat, True, gdec[s], B, 4 * Hd, E + Hd, bias=bdec)
             c_in = c0 if s == 0 else cdec[s - 1]
             h_next = XH[s + 1][:, E:] if s + 1 < T else None
             i_s = if2[:, s * W_:(s + 1) * W_]
-            _cell_fwd(gdec[s], c_in, i_s[:, :Hd], cdec[s], h_next, B, Hd,
-                      hb2=XHb[s + 1][:, E:] if (use_b and s + 1 < T) else None)
+            if use_b:
+                _gemm_cell_fwd(XHb[s], wcat_b, gdec[s], c_in, i_s[:, :Hd], cdec[s], h_next, B, Hd, bias=bdec,
+                               hb2=XHb[s + 1][:, E:] if s + 1 < T else None)
+            else:
+                gemm(XH[s], True, wcat, True, gdec[s], B, 4 * Hd, E + Hd, bias=bdec)
+                _cell_fwd(gdec[s], c_in, i_s[:, :Hd], cdec[s], h_next, B, Hd)
             id_s = ifd2[:, s * W_:(s + 1) * W_]
             fd = drop.at(STREAM_G_FFN + s)
             idb_s = ifdb[:, s * W_:(s + 1) * W_] if use_b else None

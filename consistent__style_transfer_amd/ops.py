@@ -68,6 +68,7 @@ def _f32(t):
 # raw wrappers
 # =============================================================================================
 _WS = {}
+LSTM_SPLITK = 2                      # split-K of the fused gate GEMM + LSTM cell (measured best of 0..4 on the bench step)
 WS_FLOATS = 16 * 1024 * 1024         # 64 MiB split-K slab workspace per device
 
 

@@ -138,6 +138,17 @@ int cst_dot_attn_bwd(const float* dout, long lddo, const float* q, long ldq, con
 int cst_lstm_cell_fwd(float* gates, long ldg, const float* c_prev, long ldcp, float* h_out, long ldh,
                       float* c_out, long ldc, float* h_out2, long ldh2,
                       void* h_bf16, long ldhb, void* h_bf16_2, long ldhb2, int B, int H, void* stream);
+/* Gate product + LSTM cell for one recurrent step: gates = A B^T (+ bias) (+ addend) as cst_gemm_bf16 (A [M,K],
+ * B [4H,K] bf16, K % 64 == 0), then the cell of cst_lstm_cell_fwd.  The product's split-K partials go to the
+ * workspace (>= splits*M*4H floats; splitk 0 = heuristic) and ONE second kernel sums them and applies the
+ * cell, so no pre-activation is written and no separate reduce / cell launch remains (rnn.py:57, :75).
+ * Every fp32 row pointer must be 16-byte aligned (H % 4 == 0, leading dimensions multiples of 4). */
+int cst_gemm_bf16_lstm(const void* A, long lda, const void* B, long ldb, int M, int H, int K,
+                       const float* bias, const float* addend, long ldadd,
+                       float* gates, long ldg, const float* c_prev, long ldcp,
+                       float* h_out, long ldh, float* c_out, long ldc, float* h_out2, long ldh2,
+                       void* h_bf16, long ldhb, void* h_bf16_2, long ldhb2,
+                       int splitk, float* workspace, long workspace_floats, void* stream);
 int cst_lstm_cell_bwd(const float* gates, long ldg, const float* c_prev, long ldcp, const float* c_new, long ldcn,
                       const float* dh, long lddh, const float* dh2, long lddh2, const float* dc, long lddc,
                       float* dgates, long lddg, float* dc_prev, long lddcp, void* dgates_bf16, long lddgb,
