@@ -19,29 +19,6 @@ typedef __attribute__((address_space(1))) const void* gbl_ptr_t;
 
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
 
-// Sum over each aligned group of 16 lanes, result in all 16, on the DPP path (no LDS round trip as
-// __shfl_xor's ds_bpermute would take): swap inside pairs, swap pairs inside quads, then mirror the
-// half row and the row -- after the first two steps a quad holds one value, so the mirrors deliver
-// the other quad's / the other half row's sum.
-template <int CTRL>
-__device__ __forceinline__ float dpp_f(float v) {
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
-}
-__device__ __forceinline__ float row16_sum(float v) {
-    v += dpp_f<0xB1>(v);        // quad_perm [1,0,3,2]
-    v += dpp_f<0x4E>(v);        // quad_perm [2,3,0,1]
-    v += dpp_f<0x141>(v);       // row_half_mirror
-    v += dpp_f<0x140>(v);       // row_mirror
-    return v;
-}
-__device__ __forceinline__ float row16_max(float v) {
-    v = fmaxf(v, dpp_f<0xB1>(v));
-    v = fmaxf(v, dpp_f<0x4E>(v));
-    v = fmaxf(v, dpp_f<0x141>(v));
-    v = fmaxf(v, dpp_f<0x140>(v));
-    return v;
-}
-
 constexpr int MHA_NW = 8;            // waves per workgroup: 2-3 resident workgroups give 4-6 waves / SIMD
 
 // ---------------------------------------------------------------------------------------------
@@ -465,6 +442,22 @@ extern "C" int cst_mha_bwd(const float* qkv, const float* dout, const float* lse
 // from LDS.  Optionally also writes the dropped copy [q | out] * mask of the decoder's i_ffn
 // (rnn.py:78-79) so the step needs no separate dropout launch.
 // ---------------------------------------------------------------------------------------------
+// global -> LDS copy of n4 float4 with four loads in flight per thread (a run-time-bounded one-load
+// loop waits out a full memory round trip per iteration)
+__device__ __forceinline__ void stage_f4(const float4* __restrict__ src, float4* dst, int n4) {
+    const int bd = blockDim.x;
+    for (int base = 0; base < n4; base += 4 * bd) {
+        float4 t[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) t[u] = src[min(base + u * bd + (int)threadIdx.x, n4 - 1)];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int e = base + u * bd + threadIdx.x;
+            if (e < n4) dst[e] = t[u];
+        }
+    }
+}
+
 __global__ __launch_bounds__(1024) void dot_attn_fwd_kernel(const float* __restrict__ q, long ldq,
                                                            const float* __restrict__ mem, float* __restrict__ out, long ldo,
                                                            float* __restrict__ p, int L, int D, float scale,
@@ -478,8 +471,10 @@ __global__ __launch_bounds__(1024) void dot_attn_fwd_kernel(const float* __restr
     const float* qb = q + (long)b * ldq;
     const float4* mb4 = reinterpret_cast<const float4*>(mem + (long)b * L * D);
     const int n4 = L * D / 4;
-    for (int e = threadIdx.x; e < n4; e += blockDim.x) reinterpret_cast<float4*>(ms)[e] = mb4[e];
-    for (int c = threadIdx.x; c < D; c += blockDim.x) qs[c] = qb[c];
+    const float qv = qb[min((int)threadIdx.x, D - 1)];             // in flight together with the tile
+    stage_f4(mb4, reinterpret_cast<float4*>(ms), n4);
+    if (threadIdx.x < D) qs[threadIdx.x] = qv;
+    for (int c = threadIdx.x + blockDim.x; c < D; c += blockDim.x) qs[c] = qb[c];
     __syncthreads();
     for (int j = w; j < L; j += (int)(blockDim.x >> 6)) {
         float s = 0.f;
@@ -555,9 +550,12 @@ __global__ __launch_bounds__(1024) void dot_attn_bwd_kernel(const float* __restr
     const float* qb = q + (long)b * ldq;
     const float4* mb4 = reinterpret_cast<const float4*>(mem + (long)b * L * D);
     const int n4 = L * D / 4;
-    for (int e = threadIdx.x; e < n4; e += blockDim.x) reinterpret_cast<float4*>(ms)[e] = mb4[e];
-    for (int c = threadIdx.x; c < D; c += blockDim.x) gs[c] = gb[c];
-    if (threadIdx.x < L) ps[threadIdx.x] = p[(long)b * L + threadIdx.x];
+    const float gv = gb[min((int)threadIdx.x, D - 1)];             // in flight together with the tile
+    const float pv = p[(long)b * L + min((int)threadIdx.x, L - 1)];
+    stage_f4(mb4, reinterpret_cast<float4*>(ms), n4);
+    if (threadIdx.x < D) gs[threadIdx.x] = gv;
+    for (int c = threadIdx.x + blockDim.x; c < D; c += blockDim.x) gs[c] = gb[c];
+    if (threadIdx.x < L) ps[threadIdx.x] = pv;
     __syncthreads();
     for (int j = w; j < L; j += (int)(blockDim.x >> 6)) {
         float s = 0.f;
@@ -574,13 +572,23 @@ __global__ __launch_bounds__(1024) void dot_attn_bwd_kernel(const float* __restr
     float* dmb = dmem + (long)b * L * D;
     for (int c = threadIdx.x; c < D; c += blockDim.x) {
         const float g = gs[c], qc = qb[c];
-        float a = 0.f;
-        for (int j = 0; j < L; ++j) {
-            a += ds[j] * ms[j * D + c];
-            dmb[(long)j * D + c] += ps[j] * g + ds[j] * qc;
-        }
         float* o = dq + (long)b * lddq + c;
-        *o = dq_accumulate ? *o + a : a;
+        const float prev = dq_accumulate ? *o : 0.f;
+        float a = 0.f;
+        for (int j0 = 0; j0 < L; j0 += 8) {               // dmem += ...: eight read-modify-writes in flight
+            float old[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) old[u] = dmb[(long)min(j0 + u, L - 1) * D + c];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int j = j0 + u;
+                if (j < L) {
+                    a += ds[j] * ms[j * D + c];
+                    dmb[(long)j * D + c] = old[u] + ps[j] * g + ds[j] * qc;
+                }
+            }
+        }
+        *o = prev + a;
     }
 }
 

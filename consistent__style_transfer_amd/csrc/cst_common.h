@@ -71,15 +71,39 @@ __device__ __forceinline__ float cst_drop_mask(const CstDrop& d, uint32_t seed, 
 }
 
 // ---- wave / block reductions -----------------------------------------------------------------
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+// On the DPP path: __shfl_xor lowers to ds_bpermute_b32, an LDS-pipe round trip per step (six dependent
+// ones per wave reduction).  Inside each row of 16 lanes: swap inside pairs, swap pairs inside quads,
+// mirror the half row, mirror the row (after the first two steps a quad holds one value, so the
+// mirrors deliver the other quad's / the other half row's partial); the four row results are then read
+// through SGPRs.  All 64 lanes must be active.
+template <int CTRL>
+__device__ __forceinline__ float cst_dpp(float v, float old) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float row16_sum(float v) {
+    v += cst_dpp<0xB1>(v, 0.f);         // quad_perm [1,0,3,2]
+    v += cst_dpp<0x4E>(v, 0.f);         // quad_perm [2,3,0,1]
+    v += cst_dpp<0x141>(v, 0.f);        // row_half_mirror
+    v += cst_dpp<0x140>(v, 0.f);        // row_mirror
     return v;
 }
-__device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+__device__ __forceinline__ float row16_max(float v) {
+    v = fmaxf(v, cst_dpp<0xB1>(v, v));
+    v = fmaxf(v, cst_dpp<0x4E>(v, v));
+    v = fmaxf(v, cst_dpp<0x141>(v, v));
+    v = fmaxf(v, cst_dpp<0x140>(v, v));
     return v;
+}
+__device__ __forceinline__ float cst_readlane(float v, int l) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
+}
+__device__ __forceinline__ float wave_sum(float v) {
+    v = row16_sum(v);
+    return (cst_readlane(v, 0) + cst_readlane(v, 16)) + (cst_readlane(v, 32) + cst_readlane(v, 48));
+}
+__device__ __forceinline__ float wave_max(float v) {
+    v = row16_max(v);
+    return fmaxf(fmaxf(cst_readlane(v, 0), cst_readlane(v, 16)), fmaxf(cst_readlane(v, 32), cst_readlane(v, 48)));
 }
 
 // block-wide reductions for blockDim.x multiple of 64, <= 1024.  `red` is >= 16 floats of LDS.
