@@ -123,6 +123,7 @@ extern "C" int cst_colsum_bf16(const void* X, long ld, int M, int N, float* out,
 // =============================================================================================
 struct BGemmArgs {
     const bf16_t* A; const bf16_t* B;
+    const bf16_t* A2; const bf16_t* B2;   // second independent problem of the same shape (gridDim.z == 2; slab output only)
     float* C; bf16_t* Cb;           // either or both
     const float* bias; const float* addend; const bf16_t* aux;
     long lda, ldb, ldc, ldcb, ldadd, ldaux;
@@ -245,12 +246,12 @@ __global__ __launch_bounds__(256) void cst_gemm_bf16_kernel(BGemmArgs g) {
 #pragma unroll
     for (int c = 0; c < A_CH; ++c) {
         const int r = (wave * A_CH + c) * 8 + lrow;
-        asrc[c] = g.A + (long)min(m0 + r, g.M - 1) * g.lda + ((lps ^ (r & 7)) << 3);
+        asrc[c] = (blockIdx.z ? g.A2 : g.A) + (long)min(m0 + r, g.M - 1) * g.lda + ((lps ^ (r & 7)) << 3);
     }
 #pragma unroll
     for (int c = 0; c < B_CH; ++c) {
         const int r = (wave * B_CH + c) * 8 + lrow;
-        bsrc[c] = g.B + (long)min(n0 + r, g.N - 1) * g.ldb + ((lps ^ (r & 7)) << 3);
+        bsrc[c] = (blockIdx.z ? g.B2 : g.B) + (long)min(n0 + r, g.N - 1) * g.ldb + ((lps ^ (r & 7)) << 3);
     }
     const int kbeg = blockIdx.y * g.k_per_split;
     const int kend = min(g.K, kbeg + g.k_per_split);
@@ -275,38 +276,55 @@ __global__ __launch_bounds__(256) void cst_gemm_bf16_kernel(BGemmArgs g) {
 
     const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
     issue(0);
-    if (NSTAGE > 2 && nk > 1) issue(1);
+#pragma unroll
+    for (int pt = 1; pt < NSTAGE - 1; ++pt)
+        if (pt < nk) issue(pt);
     for (int t = 0; t < nk; ++t) {
         // tile t has landed once all but the (one) newer tile's loads of THIS wave are done, and every
         // wave has said so at the barrier; the barrier also retires all reads of tile t-1, whose ring
         // slot tile t+2 may now overwrite.
-        if (NSTAGE > 2 && t + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // tiles t+1 .. t+NSTAGE-2 (those that exist) are newer than tile t and may stay in flight
+        {
+            const int newer = min(NSTAGE - 2, nk - 1 - t);
+            if (NSTAGE > 3 && newer >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LOADS) : "memory");
+            else if (NSTAGE > 2 && newer >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
         __builtin_amdgcn_s_barrier();
         if (t + NSTAGE - 1 < nk) issue(t + NSTAGE - 1);
         const unsigned As = lds_base + (t % NSTAGE) * ST_BYTES;
         const unsigned Bs = As + A_BYTES;
+        // both 32-wide k halves of the tile are requested before the first MFMA: one LDS round trip per
+        // tile instead of two (the second half's reads retire under the first half's MFMAs)
+        u32x4_t af[2][TM], bfr[2][TN];
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
-            u32x4_t af[TM], bfr[TN];
 #pragma unroll
-            for (int i = 0; i < TM; ++i) af[i] = lds_read128(As + blds_off(wm * (BM / 2) + i * 16 + lr, kk * 4 + lq));
+            for (int i = 0; i < TM; ++i) af[kk][i] = lds_read128(As + blds_off(wm * (BM / 2) + i * 16 + lr, kk * 4 + lq));
 #pragma unroll
-            for (int j = 0; j < TN; ++j) bfr[j] = lds_read128(Bs + blds_off(wn * (BN / 2) + j * 16 + lr, kk * 4 + lq));
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, af[i]),
-                                                                        __builtin_bit_cast(bf16x8_t, bfr[j]), acc[i][j], 0, 0, 0);
+            for (int j = 0; j < TN; ++j) bfr[kk][j] = lds_read128(Bs + blds_off(wn * (BN / 2) + j * 16 + lr, kk * 4 + lq));
         }
+        asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(TM + TN) : "memory");      // first half landed
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, af[0][i]),
+                                                                    __builtin_bit_cast(bf16x8_t, bfr[0][j]), acc[i][j], 0, 0, 0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, af[1][i]),
+                                                                    __builtin_bit_cast(bf16x8_t, bfr[1][j]), acc[i][j], 0, 0, 0);
     }
     __syncthreads();                                  // all tile reads done before smem is reused for C
 
     if (g.splits > 1 || g.slab_only) {
-        float* slab = g.slab + ((long)blockIdx.y * g.M) * g.N;
+        float* slab = g.slab + (((long)blockIdx.z * g.splits + blockIdx.y) * g.M) * g.N;
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -390,7 +408,7 @@ static int bgemm_launch(const BGemmArgs& g, hipStream_t st) {
         (void)hipFuncSetAttribute((const void*)cst_gemm_bf16_kernel<BM, BN, NSTAGE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_done = true;
     }
-    dim3 grid(cst_div_up(g.M, BM) * cst_div_up(g.N, BN), g.splits), block(256);
+    dim3 grid(cst_div_up(g.M, BM) * cst_div_up(g.N, BN), g.splits, g.A2 ? 2 : 1), block(256);
     if (cst_prof_on()) {
         hipEvent_t ea, eb;
         (void)hipEventCreate(&ea); (void)hipEventCreate(&eb);
@@ -416,7 +434,7 @@ extern "C" int cst_gemm_bf16(const void* A, long lda, const void* B, long ldb,
     CST_REQUIRE(!Cb || ldcb >= N, "cst_gemm_bf16: ldcb < N");
     CST_REQUIRE(act >= 0 && act <= 4 && (act < 3 || aux), "cst_gemm_bf16: bad activation / missing aux");
     BGemmArgs g;
-    g.A = (const bf16_t*)A; g.B = (const bf16_t*)B; g.C = C; g.Cb = (bf16_t*)Cb;
+    g.A = (const bf16_t*)A; g.B = (const bf16_t*)B; g.A2 = nullptr; g.B2 = nullptr; g.C = C; g.Cb = (bf16_t*)Cb;
     g.bias = bias; g.addend = addend; g.aux = (const bf16_t*)aux;
     g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.ldcb = ldcb; g.ldadd = ldadd; g.ldaux = ldaux;
     g.M = M; g.N = N; g.K = K; g.act = act; g.alpha = alpha; g.gate_scale = gate_scale; g.accumulate = accumulate;
@@ -425,8 +443,8 @@ extern "C" int cst_gemm_bf16(const void* A, long lda, const void* B, long ldb,
     // tile / ring / split choice (tools/gemm_bench.py bf16nt): the 2-stage ring with two workgroups per
     // CU beats the 3-stage one at these sizes; 64x128 tiles when they alone give >= 256 workgroups,
     // 128x128 + split-K for long-K products with few output tiles (wgrad), 64x128 (+split) otherwise.
-    int three = tile & 1;                        // odd tile codes force the 3-stage ring
-    tile &= ~1;
+    int ring = tile & 3;                         // tile code + 1 / + 2: force the 3- / 4-stage ring
+    tile &= ~3;
     const long big = (long)cst_div_up(M, 128) * cst_div_up(N, 128);
     const long mid = (long)cst_div_up(M, 64) * cst_div_up(N, 128);
     int use_big, splits = 1;
@@ -449,8 +467,9 @@ extern "C" int cst_gemm_bf16(const void* A, long lda, const void* B, long ldb,
     CST_REQUIRE(splits == 1 || workspace, "cst_gemm_bf16: split-K needs a workspace");
     g.splits = splits; g.slab = workspace;
     hipStream_t st = (hipStream_t)stream;
-    if (use_big) { if (three) bgemm_launch<128, 128, 3>(g, st); else bgemm_launch<128, 128, 2>(g, st); }
-    else { if (three) bgemm_launch<64, 128, 3>(g, st); else bgemm_launch<64, 128, 2>(g, st); }
+    if (ring == 0 && getenv("CST_RING4") && !use_big && tiles * splits <= 256 && g.k_per_split >= 256) ring = 2;
+    if (use_big) { if (ring == 1) bgemm_launch<128, 128, 3>(g, st); else bgemm_launch<128, 128, 2>(g, st); }
+    else { if (ring == 2) bgemm_launch<64, 128, 4>(g, st); else if (ring == 1) bgemm_launch<64, 128, 3>(g, st); else bgemm_launch<64, 128, 2>(g, st); }
     CST_LAUNCH_CHECK("cst_gemm_bf16");
     if (splits > 1) {
         long mn = ((long)M * N + 3) / 4;          // four columns per thread on the vector path
@@ -462,46 +481,59 @@ extern "C" int cst_gemm_bf16(const void* A, long lda, const void* B, long ldb,
 }
 
 // =============================================================================================
-// Gate GEMM + LSTM cell in two launches (rnn.py:25-33 nn.LSTM step; gate order i, f, g, o).
-// The GEMM kernel leaves its split-K partial products in the workspace; the second kernel sums them
-// (split order), adds bias / the precomputed input projection and applies the cell of
-// cst_lstm_cell_fwd, one thread per 4 hidden units -- the separate reduce and cell launches and the
-// round trip of the pre-activations disappear from every recurrent step.
+// Recurrent step of nn.LSTM (rnn.py:25-33; gate order i, f, g, o) in two launches, forward and backward,
+// for one problem or for two independent problems of one shape (the two directions of the encoder):
+//   forward   gates = h W_hh^T (+ bias) (+ input projection); cell            (cst_gemm_bf16_lstm)
+//   backward  dh = dgates_next W_hh; cell backward of the step before         (cst_gemm_bf16_lstm_bwd)
+// The GEMM kernel leaves its split-K partial products in the workspace; the second kernel sums them in
+// split order and applies the cell, one thread per 4 hidden units.  The separate reduce and cell
+// launches and the round trip of the pre-activations / dh disappear from every recurrent step.
 // =============================================================================================
 struct LstmEpi {
+    const float* bias; const float* addend;
+    float* gates; const float* c_prev; float* h_out; float* c_out; float* h_out2;
+    bf16_t* hb; bf16_t* hb2;
+};
+struct LstmEpi2 {
+    LstmEpi e[2];
     const float* slab; int splits; int M, H;
-    const float* bias; const float* addend; long ldadd;
-    float* gates; long ldg; const float* c_prev; long ldcp;
-    float* h_out; long ldh; float* c_out; long ldc; float* h_out2; long ldh2;
-    bf16_t* hb; long ldhb; bf16_t* hb2; long ldhb2;
+    long ldadd, ldg, ldcp, ldh, ldc, ldh2, ldhb, ldhb2;
 };
 
 __device__ __forceinline__ float lstm_sigmoid(float x) { return 1.f / (1.f + expf(-x)); }
 
-__global__ __launch_bounds__(256) void cst_gemm_bf16_lstm_reduce(LstmEpi p) {
-    const int H4 = p.H >> 2;
+__device__ __forceinline__ void f4_add(float (&a)[4], const float* p) {
+    const float4 t = *reinterpret_cast<const float4*>(p);
+    a[0] += t.x; a[1] += t.y; a[2] += t.z; a[3] += t.w;
+}
+__device__ __forceinline__ void f4_store(float* p, const float (&a)[4]) { *reinterpret_cast<float4*>(p) = make_float4(a[0], a[1], a[2], a[3]); }
+__device__ __forceinline__ void bf4_store(bf16_t* p, const float (&a)[4]) {
+    uint2 u;
+    u.x = (uint32_t)f2bf16(a[0]) | ((uint32_t)f2bf16(a[1]) << 16);
+    u.y = (uint32_t)f2bf16(a[2]) | ((uint32_t)f2bf16(a[3]) << 16);
+    *reinterpret_cast<uint2*>(p) = u;
+}
+
+__global__ __launch_bounds__(256) void cst_gemm_bf16_lstm_reduce(LstmEpi2 q) {
+    const LstmEpi& p = q.e[blockIdx.y];
+    const int H4 = q.H >> 2;
     const int idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx >= p.M * H4) return;
+    if (idx >= q.M * H4) return;
     const int m = idx / H4, u = (idx - m * H4) * 4;
-    const long MN = (long)p.M * 4 * p.H;
+    const long MN = (long)q.M * 4 * q.H;
+    const float* slab = q.slab + (long)blockIdx.y * q.splits * MN;
     float pre[4][4];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const long off = (long)m * 4 * p.H + (long)q * p.H + u;
-        float4 a = *reinterpret_cast<const float4*>(p.slab + off);
-        for (int s = 1; s < p.splits; ++s) {
-            const float4 t = *reinterpret_cast<const float4*>(p.slab + s * MN + off);
-            a.x += t.x; a.y += t.y; a.z += t.z; a.w += t.w;
-        }
-        if (p.bias) { const float4 t = *reinterpret_cast<const float4*>(p.bias + q * p.H + u); a.x += t.x; a.y += t.y; a.z += t.z; a.w += t.w; }
-        if (p.addend) {
-            const float4 t = *reinterpret_cast<const float4*>(p.addend + (long)m * p.ldadd + q * p.H + u);
-            a.x += t.x; a.y += t.y; a.z += t.z; a.w += t.w;
-        }
-        pre[q][0] = a.x; pre[q][1] = a.y; pre[q][2] = a.z; pre[q][3] = a.w;
+    for (int g = 0; g < 4; ++g) {
+        const long off = (long)m * 4 * q.H + (long)g * q.H + u;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) pre[g][e] = 0.f;
+        for (int s = 0; s < q.splits; ++s) f4_add(pre[g], slab + s * MN + off);
+        if (p.bias) f4_add(pre[g], p.bias + g * q.H + u);
+        if (p.addend) f4_add(pre[g], p.addend + (long)m * q.ldadd + g * q.H + u);
     }
-    const float4 cp4 = *reinterpret_cast<const float4*>(p.c_prev + (long)m * p.ldcp + u);
-    const float cp[4] = {cp4.x, cp4.y, cp4.z, cp4.w};
+    float cp[4] = {0.f, 0.f, 0.f, 0.f};
+    f4_add(cp, p.c_prev + (long)m * q.ldcp + u);
     float gi[4], gf[4], gg[4], go[4], c[4], h[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -512,20 +544,44 @@ __global__ __launch_bounds__(256) void cst_gemm_bf16_lstm_reduce(LstmEpi p) {
         c[e] = gf[e] * cp[e] + gi[e] * gg[e];
         h[e] = go[e] * tanhf(c[e]);
     }
-    float* g = p.gates + (long)m * p.ldg + u;
-    *reinterpret_cast<float4*>(g) = make_float4(gi[0], gi[1], gi[2], gi[3]);
-    *reinterpret_cast<float4*>(g + p.H) = make_float4(gf[0], gf[1], gf[2], gf[3]);
-    *reinterpret_cast<float4*>(g + 2 * p.H) = make_float4(gg[0], gg[1], gg[2], gg[3]);
-    *reinterpret_cast<float4*>(g + 3 * p.H) = make_float4(go[0], go[1], go[2], go[3]);
-    *reinterpret_cast<float4*>(p.c_out + (long)m * p.ldc + u) = make_float4(c[0], c[1], c[2], c[3]);
-    const float4 h4 = make_float4(h[0], h[1], h[2], h[3]);
-    *reinterpret_cast<float4*>(p.h_out + (long)m * p.ldh + u) = h4;
-    if (p.h_out2) *reinterpret_cast<float4*>(p.h_out2 + (long)m * p.ldh2 + u) = h4;
-    uint2 hb;
-    hb.x = (uint32_t)f2bf16(h[0]) | ((uint32_t)f2bf16(h[1]) << 16);
-    hb.y = (uint32_t)f2bf16(h[2]) | ((uint32_t)f2bf16(h[3]) << 16);
-    if (p.hb) *reinterpret_cast<uint2*>(p.hb + (long)m * p.ldhb + u) = hb;
-    if (p.hb2) *reinterpret_cast<uint2*>(p.hb2 + (long)m * p.ldhb2 + u) = hb;
+    float* g = p.gates + (long)m * q.ldg + u;
+    f4_store(g, gi); f4_store(g + q.H, gf); f4_store(g + 2 * q.H, gg); f4_store(g + 3 * q.H, go);
+    f4_store(p.c_out + (long)m * q.ldc + u, c);
+    f4_store(p.h_out + (long)m * q.ldh + u, h);
+    if (p.h_out2) f4_store(p.h_out2 + (long)m * q.ldh2 + u, h);
+    if (p.hb) bf4_store(p.hb + (long)m * q.ldhb + u, h);
+    if (p.hb2) bf4_store(p.hb2 + (long)m * q.ldhb2 + u, h);
+}
+
+static bool al16(const void* p) { return ((uintptr_t)p & 15) == 0; }
+
+// shared front end: shape checks, split choice and the slab-only GEMM launch for 1 or 2 problems
+static int lstm_gemm_front(const char* who, BGemmArgs& g, const void* A, const void* B, const void* A2, const void* B2,
+                           long lda, long ldb, int M, int N, int K, int splitk, float* workspace, long workspace_floats,
+                           hipStream_t st) {
+    CST_REQUIRE(A && B && workspace, "%s: null pointer", who);
+    CST_REQUIRE((A2 == nullptr) == (B2 == nullptr), "%s: the second problem needs both operands", who);
+    CST_REQUIRE(M > 0 && N > 0 && K > 0 && K % 64 == 0, "%s: K=%d must be a positive multiple of 64", who, K);
+    CST_REQUIRE(lda >= K && ldb >= K && lda % 8 == 0 && ldb % 8 == 0 && al16(A) && al16(B) && al16(A2) && al16(B2),
+                "%s: operands must be 16-byte aligned with leading dimensions >= K, multiples of 8", who);
+    g.A = (const bf16_t*)A; g.B = (const bf16_t*)B; g.A2 = (const bf16_t*)A2; g.B2 = (const bf16_t*)B2;
+    g.C = nullptr; g.Cb = nullptr; g.bias = nullptr; g.addend = nullptr; g.aux = nullptr;
+    g.lda = lda; g.ldb = ldb; g.ldc = 0; g.ldcb = 0; g.ldadd = 0; g.ldaux = 0;
+    g.M = M; g.N = N; g.K = K; g.act = 0; g.alpha = 1.f; g.gate_scale = 1.f; g.accumulate = 0;
+    g.drop = cst_make_drop(0.f, 0, 0, nullptr);
+    g.slab_only = 1;
+    const int np = A2 ? 2 : 1;
+    const long tiles = (long)cst_div_up(M, 64) * cst_div_up(N, 128) * np;
+    int splits = splitk > 0 ? splitk : (int)((384 + tiles - 1) / tiles);
+    if (splits > K / 128) splits = K / 128;
+    if (splits < 1) splits = 1;
+    int kps = cst_div_up(cst_div_up(K, splits), 64) * 64;
+    splits = cst_div_up(K, kps);
+    CST_REQUIRE((long)np * splits * M * N <= workspace_floats, "%s: workspace too small", who);
+    g.splits = splits; g.k_per_split = kps; g.slab = workspace;
+    bgemm_launch<64, 128, 2>(g, st);
+    CST_LAUNCH_CHECK(who);
+    return CST_OK;
 }
 
 extern "C" int cst_gemm_bf16_lstm(const void* A, long lda, const void* B, long ldb, int M, int H, int K,
@@ -533,41 +589,106 @@ extern "C" int cst_gemm_bf16_lstm(const void* A, long lda, const void* B, long l
                                   float* gates, long ldg, const float* c_prev, long ldcp,
                                   float* h_out, long ldh, float* c_out, long ldc, float* h_out2, long ldh2,
                                   void* h_bf16, long ldhb, void* h_bf16_2, long ldhb2,
+                                  const void* A2, const void* B2, const float* bias2, const float* addend2,
+                                  float* gates2, const float* c_prev2, float* h_out_2, float* c_out2, float* h_out2_2,
+                                  void* h_bf16_p2, void* h_bf16_2_p2,
                                   int splitk, float* workspace, long workspace_floats, void* stream) {
-    CST_REQUIRE(A && B && gates && c_prev && h_out && c_out && workspace, "cst_gemm_bf16_lstm: null pointer");
-    CST_REQUIRE(M > 0 && H > 0 && H % 4 == 0 && K > 0 && K % 64 == 0, "cst_gemm_bf16_lstm: H %% 4 and K %% 64 must be 0 (H=%d, K=%d)", H, K);
-    CST_REQUIRE(lda >= K && ldb >= K && lda % 8 == 0 && ldb % 8 == 0 && (((uintptr_t)A | (uintptr_t)B) & 15) == 0,
-                "cst_gemm_bf16_lstm: operands must be 16-byte aligned with leading dimensions >= K, multiples of 8");
-    const bool al = ((ldg | ldcp | ldh | ldc | (addend ? ldadd : 0) | (h_out2 ? ldh2 : 0) | (h_bf16 ? ldhb : 0) | (h_bf16_2 ? ldhb2 : 0)) % 4 == 0) &&
-                    ((((uintptr_t)gates | (uintptr_t)c_prev | (uintptr_t)h_out | (uintptr_t)c_out | (uintptr_t)bias | (uintptr_t)addend |
-                       (uintptr_t)h_out2 | (uintptr_t)workspace) & 15) == 0) &&
-                    ((((uintptr_t)h_bf16 | (uintptr_t)h_bf16_2) & 7) == 0);
+    CST_REQUIRE(gates && c_prev && h_out && c_out, "cst_gemm_bf16_lstm: null pointer");
+    CST_REQUIRE(H > 0 && H % 4 == 0, "cst_gemm_bf16_lstm: H=%d must be a positive multiple of 4", H);
+    CST_REQUIRE(!A2 || (gates2 && c_prev2 && h_out_2 && c_out2), "cst_gemm_bf16_lstm: second problem incomplete");
+    const bool al = ((ldg | ldcp | ldh | ldc | ldadd | ldh2 | ldhb | ldhb2) % 4 == 0) &&
+                    al16(gates) && al16(c_prev) && al16(h_out) && al16(c_out) && al16(bias) && al16(addend) && al16(h_out2) &&
+                    al16(gates2) && al16(c_prev2) && al16(h_out_2) && al16(c_out2) && al16(bias2) && al16(addend2) && al16(h_out2_2) &&
+                    al16(workspace) && ((((uintptr_t)h_bf16 | (uintptr_t)h_bf16_2 | (uintptr_t)h_bf16_p2 | (uintptr_t)h_bf16_2_p2) & 7) == 0);
     CST_REQUIRE(al, "cst_gemm_bf16_lstm: every row pointer must be 16-byte aligned (leading dimensions multiples of 4)");
-    const int N = 4 * H;
-    BGemmArgs g;
-    g.A = (const bf16_t*)A; g.B = (const bf16_t*)B; g.C = nullptr; g.Cb = nullptr;
-    g.bias = nullptr; g.addend = nullptr; g.aux = nullptr;
-    g.lda = lda; g.ldb = ldb; g.ldc = 0; g.ldcb = 0; g.ldadd = 0; g.ldaux = 0;
-    g.M = M; g.N = N; g.K = K; g.act = 0; g.alpha = 1.f; g.gate_scale = 1.f; g.accumulate = 0;
-    g.drop = cst_make_drop(0.f, 0, 0, nullptr);
-    g.slab_only = 1;
-    const long tiles = (long)cst_div_up(M, 64) * cst_div_up(N, 128);
-    int splits = splitk > 0 ? splitk : (int)((384 + tiles - 1) / tiles);
-    if (splits > K / 128) splits = K / 128;
-    if (splits < 1) splits = 1;
-    int kps = cst_div_up(cst_div_up(K, splits), 64) * 64;
-    splits = cst_div_up(K, kps);
-    CST_REQUIRE((long)splits * M * N <= workspace_floats, "cst_gemm_bf16_lstm: workspace too small");
-    g.splits = splits; g.k_per_split = kps; g.slab = workspace;
     hipStream_t st = (hipStream_t)stream;
-    bgemm_launch<64, 128, 2>(g, st);
-    CST_LAUNCH_CHECK("cst_gemm_bf16_lstm");
-    LstmEpi p;
-    p.slab = workspace; p.splits = splits; p.M = M; p.H = H; p.bias = bias; p.addend = addend; p.ldadd = ldadd;
-    p.gates = gates; p.ldg = ldg; p.c_prev = c_prev; p.ldcp = ldcp; p.h_out = h_out; p.ldh = ldh; p.c_out = c_out; p.ldc = ldc;
-    p.h_out2 = h_out2; p.ldh2 = ldh2; p.hb = (bf16_t*)h_bf16; p.ldhb = ldhb; p.hb2 = (bf16_t*)h_bf16_2; p.ldhb2 = ldhb2;
+    BGemmArgs g;
+    if (int rc = lstm_gemm_front("cst_gemm_bf16_lstm", g, A, B, A2, B2, lda, ldb, M, 4 * H, K, splitk, workspace, workspace_floats, st)) return rc;
+    LstmEpi2 q;
+    q.e[0] = LstmEpi{bias, addend, gates, c_prev, h_out, c_out, h_out2, (bf16_t*)h_bf16, (bf16_t*)h_bf16_2};
+    q.e[1] = LstmEpi{bias2, addend2, gates2, c_prev2, h_out_2, c_out2, h_out2_2, (bf16_t*)h_bf16_p2, (bf16_t*)h_bf16_2_p2};
+    q.slab = workspace; q.splits = g.splits; q.M = M; q.H = H;
+    q.ldadd = ldadd; q.ldg = ldg; q.ldcp = ldcp; q.ldh = ldh; q.ldc = ldc; q.ldh2 = ldh2; q.ldhb = ldhb; q.ldhb2 = ldhb2;
     const int nthr = M * (H / 4);
-    hipLaunchKernelGGL(cst_gemm_bf16_lstm_reduce, dim3((nthr + 255) / 256), dim3(256), 0, st, p);
+    hipLaunchKernelGGL(cst_gemm_bf16_lstm_reduce, dim3((nthr + 255) / 256, A2 ? 2 : 1), dim3(256), 0, st, q);
     CST_LAUNCH_CHECK("cst_gemm_bf16_lstm_reduce");
+    return CST_OK;
+}
+
+// ---- backward --------------------------------------------------------------------------------
+struct LstmBwdEpi {
+    const float* gates; const float* c_prev; const float* c_new; const float* dh_extra; const float* dc_in;
+    float* dgates; float* dc_prev; bf16_t* dgb;
+};
+struct LstmBwdEpi2 {
+    LstmBwdEpi e[2];
+    const float* slab; int splits; int M, H;
+    long ldg, ldcp, ldcn, lddh, lddc, lddg, lddcp, lddgb;
+};
+
+__global__ __launch_bounds__(256) void cst_gemm_bf16_lstm_bwd_reduce(LstmBwdEpi2 q) {
+    const LstmBwdEpi& p = q.e[blockIdx.y];
+    const int H4 = q.H >> 2;
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= q.M * H4) return;
+    const int m = idx / H4, u = (idx - m * H4) * 4;
+    const long MN = (long)q.M * q.H;
+    const float* slab = q.slab + (long)blockIdx.y * q.splits * MN;
+    float dht[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int s = 0; s < q.splits; ++s) f4_add(dht, slab + s * MN + (long)m * q.H + u);
+    if (p.dh_extra) f4_add(dht, p.dh_extra + (long)m * q.lddh + u);
+    float gi[4] = {0.f, 0.f, 0.f, 0.f}, gf[4] = {0.f, 0.f, 0.f, 0.f}, gg[4] = {0.f, 0.f, 0.f, 0.f}, go[4] = {0.f, 0.f, 0.f, 0.f};
+    const float* g = p.gates + (long)m * q.ldg + u;
+    f4_add(gi, g); f4_add(gf, g + q.H); f4_add(gg, g + 2 * q.H); f4_add(go, g + 3 * q.H);
+    float cp[4] = {0.f, 0.f, 0.f, 0.f}, cn[4] = {0.f, 0.f, 0.f, 0.f}, dc[4] = {0.f, 0.f, 0.f, 0.f};
+    f4_add(cp, p.c_prev + (long)m * q.ldcp + u);
+    f4_add(cn, p.c_new + (long)m * q.ldcn + u);
+    if (p.dc_in) f4_add(dc, p.dc_in + (long)m * q.lddc + u);
+    float d0[4], d1[4], d2[4], d3[4], dcp[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {                     // same arithmetic as lstm_cell_bwd_kernel
+        const float tc = tanhf(cn[e]);
+        const float dct = dc[e] + dht[e] * go[e] * (1.f - tc * tc);
+        d0[e] = dct * gg[e] * gi[e] * (1.f - gi[e]);
+        d1[e] = dct * cp[e] * gf[e] * (1.f - gf[e]);
+        d2[e] = dct * gi[e] * (1.f - gg[e] * gg[e]);
+        d3[e] = dht[e] * tc * go[e] * (1.f - go[e]);
+        dcp[e] = dct * gf[e];
+    }
+    float* dg = p.dgates + (long)m * q.lddg + u;
+    f4_store(dg, d0); f4_store(dg + q.H, d1); f4_store(dg + 2 * q.H, d2); f4_store(dg + 3 * q.H, d3);
+    if (p.dgb) {
+        bf16_t* b = p.dgb + (long)m * q.lddgb + u;
+        bf4_store(b, d0); bf4_store(b + q.H, d1); bf4_store(b + 2 * q.H, d2); bf4_store(b + 3 * q.H, d3);
+    }
+    f4_store(p.dc_prev + (long)m * q.lddcp + u, dcp);
+}
+
+extern "C" int cst_gemm_bf16_lstm_bwd(const void* A, long lda, const void* B, long ldb, int M, int H, int K,
+                                      const float* gates, long ldg, const float* c_prev, long ldcp, const float* c_new, long ldcn,
+                                      const float* dh_extra, long lddh, const float* dc_in, long lddc,
+                                      float* dgates, long lddg, float* dc_prev, long lddcp, void* dgates_bf16, long lddgb,
+                                      const void* A2, const void* B2, const float* gates2, const float* c_prev2, const float* c_new2,
+                                      const float* dh_extra2, const float* dc_in2, float* dgates2, float* dc_prev2, void* dgates_bf16_2,
+                                      int splitk, float* workspace, long workspace_floats, void* stream) {
+    CST_REQUIRE(gates && c_prev && c_new && dgates && dc_prev, "cst_gemm_bf16_lstm_bwd: null pointer");
+    CST_REQUIRE(H > 0 && H % 4 == 0, "cst_gemm_bf16_lstm_bwd: H=%d must be a positive multiple of 4", H);
+    CST_REQUIRE(!A2 || (gates2 && c_prev2 && c_new2 && dgates2 && dc_prev2), "cst_gemm_bf16_lstm_bwd: second problem incomplete");
+    const bool al = ((ldg | ldcp | ldcn | lddh | lddc | lddg | lddcp | lddgb) % 4 == 0) &&
+                    al16(gates) && al16(c_prev) && al16(c_new) && al16(dh_extra) && al16(dc_in) && al16(dgates) && al16(dc_prev) &&
+                    al16(gates2) && al16(c_prev2) && al16(c_new2) && al16(dh_extra2) && al16(dc_in2) && al16(dgates2) && al16(dc_prev2) &&
+                    al16(workspace) && ((((uintptr_t)dgates_bf16 | (uintptr_t)dgates_bf16_2) & 7) == 0);
+    CST_REQUIRE(al, "cst_gemm_bf16_lstm_bwd: every row pointer must be 16-byte aligned (leading dimensions multiples of 4)");
+    hipStream_t st = (hipStream_t)stream;
+    BGemmArgs g;
+    if (int rc = lstm_gemm_front("cst_gemm_bf16_lstm_bwd", g, A, B, A2, B2, lda, ldb, M, H, K, splitk, workspace, workspace_floats, st)) return rc;
+    LstmBwdEpi2 q;
+    q.e[0] = LstmBwdEpi{gates, c_prev, c_new, dh_extra, dc_in, dgates, dc_prev, (bf16_t*)dgates_bf16};
+    q.e[1] = LstmBwdEpi{gates2, c_prev2, c_new2, dh_extra2, dc_in2, dgates2, dc_prev2, (bf16_t*)dgates_bf16_2};
+    q.slab = workspace; q.splits = g.splits; q.M = M; q.H = H;
+    q.ldg = ldg; q.ldcp = ldcp; q.ldcn = ldcn; q.lddh = lddh; q.lddc = lddc; q.lddg = lddg; q.lddcp = lddcp; q.lddgb = lddgb;
+    const int nthr = M * (H / 4);
+    hipLaunchKernelGGL(cst_gemm_bf16_lstm_bwd_reduce, dim3((nthr + 255) / 256, A2 ? 2 : 1), dim3(256), 0, st, q);
+    CST_LAUNCH_CHECK("cst_gemm_bf16_lstm_bwd_reduce");
     return CST_OK;
 }

@@ -39,11 +39,32 @@ def _cell_fwd(gates, c_prev, h_out, c_out, h_out2, B, H, hb=None, hb2=None):
          c_out, c_out.stride(0), h_out2, _st(h_out2), hb, _st(hb), hb2, _st(hb2), B, H)
 
 
-def _gemm_cell_fwd(Ab, Bb, gates, c_prev, h_out, c_out, h_out2, B, H, bias=None, addend=None, hb=None, hb2=None):
-    """Gate product + cell in two launches (no separate split-K reduce, no cell kernel)."""
-    call("cst_gemm_bf16_lstm", Ab, Ab.stride(0), Bb, Bb.stride(0), B, H, Ab.shape[1], bias, addend, _st(addend),
-         gates, gates.stride(0), c_prev, c_prev.stride(0), h_out, h_out.stride(0), c_out, c_out.stride(0),
-         h_out2, _st(h_out2), hb, _st(hb), hb2, _st(hb2), ops.LSTM_SPLITK, ops._workspace(gates.device), ops.WS_FLOATS)
+def _gemm_cell_fwd(probs, B, H):
+    """Gate product + cell in two launches for one or two problems (dicts with Ab, Bb, gates, c_prev, h_out,
+    c_out and optional bias, addend, h_out2, hb, hb2); both problems share shapes and leading dimensions."""
+    p, q = probs[0], (probs[1] if len(probs) > 1 else {})
+    g = lambda d, k: d.get(k)
+    call("cst_gemm_bf16_lstm", p["Ab"], p["Ab"].stride(0), p["Bb"], p["Bb"].stride(0), B, H, p["Ab"].shape[1],
+         g(p, "bias"), g(p, "addend"), _st(g(p, "addend")),
+         p["gates"], p["gates"].stride(0), p["c_prev"], p["c_prev"].stride(0), p["h_out"], p["h_out"].stride(0),
+         p["c_out"], p["c_out"].stride(0), g(p, "h_out2"), _st(g(p, "h_out2")), g(p, "hb"), _st(g(p, "hb")), g(p, "hb2"), _st(g(p, "hb2")),
+         g(q, "Ab"), g(q, "Bb"), g(q, "bias"), g(q, "addend"), g(q, "gates"), g(q, "c_prev"), g(q, "h_out"), g(q, "c_out"),
+         g(q, "h_out2"), g(q, "hb"), g(q, "hb2"),
+         ops.LSTM_SPLITK, ops._workspace(p["gates"].device), ops.WS_FLOATS)
+
+
+def _gemm_cell_bwd(probs, B, H):
+    """dh = dgates_next W_hh (+ dh_extra) and the cell backward of this step, two launches, one or two problems
+    (dicts with Ab, Bb, gates, c_prev, c_new, dgates, dc_prev and optional dh_extra, dc_in, dgb)."""
+    p, q = probs[0], (probs[1] if len(probs) > 1 else {})
+    g = lambda d, k: d.get(k)
+    call("cst_gemm_bf16_lstm_bwd", p["Ab"], p["Ab"].stride(0), p["Bb"], p["Bb"].stride(0), B, H, p["Ab"].shape[1],
+         p["gates"], p["gates"].stride(0), p["c_prev"], p["c_prev"].stride(0), p["c_new"], p["c_new"].stride(0),
+         g(p, "dh_extra"), _st(g(p, "dh_extra")), g(p, "dc_in"), _st(g(p, "dc_in")),
+         p["dgates"], p["dgates"].stride(0), p["dc_prev"], p["dc_prev"].stride(0), g(p, "dgb"), _st(g(p, "dgb")),
+         g(q, "Ab"), g(q, "Bb"), g(q, "gates"), g(q, "c_prev"), g(q, "c_new"), g(q, "dh_extra"), g(q, "dc_in"),
+         g(q, "dgates"), g(q, "dc_prev"), g(q, "dgb"),
+         ops.LSTM_SPLITK, ops._workspace(p["gates"].device), ops.WS_FLOATS)
 
 
 def _cell_bwd(gates, c_prev, c_new, dh, dh2, dc, dgates, dc_prev, B, H, dgb=None):
@@ -107,14 +128,17 @@ class GeneratorFn(torch.autograd.Function):
         W_ = Hd + 2 * H
         use_b = _bf16_ok(H, 4 * H, E + Hd, 4 * Hd, W_, Hd)      # bf16-operand GEMMs for the recurrent products
         memb = _i16(dev, B, Lp * 2 * H) if use_b else None     # bf16 copy of the encoder states (A operand of h W_hh^T)
+        enc = []
         for d, suf in enumerate(("", "_reverse")):
             w_ih, w_hh = P["encoder.weight_ih_l0" + suf], P["encoder.weight_hh_l0" + suf]
-            whh_b = weight_bf16(w_hh)[0] if use_b else None
             bsum = axpby(P["encoder.bias_ih_l0" + suf].view(1, -1), 1.0, P["encoder.bias_hh_l0" + suf].view(1, -1), 1.0).view(-1)
             xp = linear_fwd(emb, w_ih, bsum).view(B, Lp * 4 * H)        # (B, L', 4H)
             order = list(range(Lp)) if d == 0 else list(range(Lp - 1, -1, -1))
-            hp2 = hprev[d].view(B, Lp * H)
-            for n, t in enumerate(order):
+            enc.append((w_hh, weight_bf16(w_hh)[0] if use_b else None, xp, order, hprev[d].view(B, Lp * H)))
+        for n in range(Lp):
+            probs = []
+            for d, (w_hh, whh_b, xp, order, hp2) in enumerate(enc):
+                t = order[n]
                 if n == 0:
                     h_in = h0cat[:, d * H:(d + 1) * H]
                     c_in = zeros_c
@@ -130,12 +154,15 @@ class GeneratorFn(torch.autograd.Function):
                 c_out = c_cat[:, d * H:(d + 1) * H] if last else cenc[d, t]
                 h_next = None if last else hp2[:, order[n + 1] * H:(order[n + 1] + 1) * H]
                 h_t = mem2[:, t * 2 * H + d * H: t * 2 * H + (d + 1) * H]
+                xa = xp[:, t * 4 * H:(t + 1) * 4 * H]
                 if use_b:
-                    _gemm_cell_fwd(h_in_b, whh_b, g, c_in, h_t, c_out, h_next, B, H, addend=xp[:, t * 4 * H:(t + 1) * 4 * H],
-                                   hb=memb[:, t * 2 * H + d * H: t * 2 * H + (d + 1) * H])
+                    probs.append(dict(Ab=h_in_b, Bb=whh_b, gates=g, c_prev=c_in, h_out=h_t, c_out=c_out, h_out2=h_next, addend=xa,
+                                      hb=memb[:, t * 2 * H + d * H: t * 2 * H + (d + 1) * H]))
                 else:
-                    gemm(h_in, True, w_hh, True, g, B, 4 * H, H, addend=xp[:, t * 4 * H:(t + 1) * 4 * H])
+                    gemm(h_in, True, w_hh, True, g, B, 4 * H, H, addend=xa)
                     _cell_fwd(g, c_in, h_t, c_out, h_next, B, H)
+            if use_b:
+                _gemm_cell_fwd(probs, B, H)            # both directions in one pair of launches (same shapes and strides)
 
         # ---- decoder initial state (rnn.py:67-69) --------------------------------------------
         c0 = linear_fwd(c_cat, P["transfer.weight"], None, act=2)
@@ -174,8 +201,8 @@ class GeneratorFn(torch.autograd.Function):
             h_next = XH[s + 1][:, E:] if s + 1 < T else None
             i_s = if2[:, s * W_:(s + 1) * W_]
             if use_b:
-                _gemm_cell_fwd(XHb[s], wcat_b, gdec[s], c_in, i_s[:, :Hd], cdec[s], h_next, B, Hd, bias=bdec,
-                               hb2=XHb[s + 1][:, E:] if s + 1 < T else None)
+                _gemm_cell_fwd([dict(Ab=XHb[s], Bb=wcat_b, gates=gdec[s], c_prev=c_in, h_out=i_s[:, :Hd], c_out=cdec[s], h_out2=h_next,
+                                     bias=bdec, hb2=XHb[s + 1][:, E:] if s + 1 < T else None)], B, Hd)
             else:
                 gemm(XH[s], True, wcat, True, gdec[s], B, 4 * Hd, E + Hd, bias=bdec)
                 _cell_fwd(gdec[s], c_in, i_s[:, :Hd], cdec[s], h_next, B, Hd)
@@ -322,28 +349,40 @@ class GeneratorFn(torch.autograd.Function):
         demb = _new(dev, B * Lp, E)
         dmem2 = dmem.view(B, Lp * 2 * H)
         dge = _new(dev, 2, B, Lp, 4 * H)
-        dhr = _new(dev, B, H)
-        dce = _new(dev, B, H)
-        dgtb = _i16(dev, B, 4 * H) if use_b else None
+        dhr2 = _new(dev, 2, B, H)
+        dce2 = _new(dev, 2, B, H)
+        dgtb2 = _i16(dev, 2, B, 4 * H) if use_b else None
+        encb = []
         for d, suf in enumerate(("", "_reverse")):
             w_ih, w_hh = P["encoder.weight_ih_l0" + suf], P["encoder.weight_hh_l0" + suf]
-            whh_t = weight_bf16(w_hh)[1] if use_b else None          # [H, 4H]
             order = list(range(Lp)) if d == 0 else list(range(Lp - 1, -1, -1))
-            dg2d = dge[d].view(B, Lp * 4 * H)
-            for n_ in range(Lp - 1, -1, -1):
+            encb.append((w_ih, w_hh, weight_bf16(w_hh)[1] if use_b else None, order, dge[d].view(B, Lp * 4 * H)))   # whh_t [H, 4H]
+        for n_ in range(Lp - 1, -1, -1):
+            probs = []
+            for d, (w_ih, w_hh, whh_t, order, dg2d) in enumerate(encb):
                 t = order[n_]
                 lastf = n_ == Lp - 1
                 c_new = c_cat[:, d * H:(d + 1) * H] if lastf else cenc[d, t]
                 c_prev = zeros_c if n_ == 0 else cenc[d, order[n_ - 1]]
                 dgt = dg2d[:, t * 4 * H:(t + 1) * 4 * H]
-                _cell_bwd(genc[d, t], c_prev, c_new, dmem2[:, t * 2 * H + d * H: t * 2 * H + (d + 1) * H],
-                          None if lastf else dhr, dc_cat[:, d * H:(d + 1) * H] if lastf else dce, dgt, dce, B, H, dgb=dgtb)
-                dh_out = dh0cat[:, d * H:(d + 1) * H] if n_ == 0 else dhr
-                if use_b:
-                    gemm_bf16(dgtb, whh_t, B, H, C=dh_out)
-                else:
-                    dgrad(dgt, w_hh, out=dh_out)
+                dmt = dmem2[:, t * 2 * H + d * H: t * 2 * H + (d + 1) * H]
+                dce = dce2[d]
+                if use_b and not lastf:
+                    # dgtb2[d] holds dgates of the step after; the fused reduce overwrites it with this step's
+                    probs.append(dict(Ab=dgtb2[d], Bb=whh_t, gates=genc[d, t], c_prev=c_prev, c_new=c_new, dh_extra=dmt, dc_in=dce,
+                                      dgates=dgt, dc_prev=dce, dgb=dgtb2[d]))
+                    continue
+                _cell_bwd(genc[d, t], c_prev, c_new, dmt, None if lastf else dhr2[d], dc_cat[:, d * H:(d + 1) * H] if lastf else dce,
+                          dgt, dce, B, H, dgb=dgtb2[d] if use_b else None)
+                if not use_b:
+                    dgrad(dgt, w_hh, out=dh0cat[:, d * H:(d + 1) * H] if n_ == 0 else dhr2[d])
+            if probs:
+                _gemm_cell_bwd(probs, B, H)
+        for d, (w_ih, w_hh, whh_t, order, dg2d) in enumerate(encb):
+            if use_b:
+                gemm_bf16(dgtb2[d], whh_t, B, H, C=dh0cat[:, d * H:(d + 1) * H])
             dgf = dge[d].view(B * Lp, 4 * H)
+            suf = "" if d == 0 else "_reverse"
             G["encoder.weight_hh_l0" + suf] = wgrad(dgf, hprev[d].view(B * Lp, H))
             G["encoder.weight_ih_l0" + suf] = wgrad(dgf, emb)
             dbe = colsum(dgf)

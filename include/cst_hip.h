@@ -138,17 +138,32 @@ int cst_dot_attn_bwd(const float* dout, long lddo, const float* q, long ldq, con
 int cst_lstm_cell_fwd(float* gates, long ldg, const float* c_prev, long ldcp, float* h_out, long ldh,
                       float* c_out, long ldc, float* h_out2, long ldh2,
                       void* h_bf16, long ldhb, void* h_bf16_2, long ldhb2, int B, int H, void* stream);
-/* Gate product + LSTM cell for one recurrent step: gates = A B^T (+ bias) (+ addend) as cst_gemm_bf16 (A [M,K],
- * B [4H,K] bf16, K % 64 == 0), then the cell of cst_lstm_cell_fwd.  The product's split-K partials go to the
- * workspace (>= splits*M*4H floats; splitk 0 = heuristic) and ONE second kernel sums them and applies the
- * cell, so no pre-activation is written and no separate reduce / cell launch remains (rnn.py:57, :75).
- * Every fp32 row pointer must be 16-byte aligned (H % 4 == 0, leading dimensions multiples of 4). */
+/* One recurrent step of nn.LSTM (rnn.py:25-33, called at rnn.py:57 and :75) in two launches, for one problem
+ * or for two independent problems of one shape (the *2 / *_p2 arguments; A2 == NULL: single) -- the two
+ * directions of the bidirectional encoder share every dimension and leading dimension.
+ *   forward:  gates = A B^T (+ bias) (+ addend) as cst_gemm_bf16 (A [M,K], B [4H,K] bf16, K % 64 == 0), then the
+ *             cell of cst_lstm_cell_fwd.
+ *   backward: dh = A B^T (A = dgates of the step after [M,4H] bf16, B = W_hh^T [H,4H] bf16, K = 4H) (+ dh_extra),
+ *             then the cell backward of cst_lstm_cell_bwd for this step (dc_in NULL = 0).
+ * The product's split-K partials go to the workspace (>= problems*splits*M*N floats; splitk 0 = heuristic) and ONE
+ * second kernel sums them and applies the cell: no pre-activation / dh round trip, no separate reduce and cell
+ * launches.  Every fp32 row pointer must be 16-byte aligned (H % 4 == 0, leading dimensions multiples of 4). */
 int cst_gemm_bf16_lstm(const void* A, long lda, const void* B, long ldb, int M, int H, int K,
                        const float* bias, const float* addend, long ldadd,
                        float* gates, long ldg, const float* c_prev, long ldcp,
                        float* h_out, long ldh, float* c_out, long ldc, float* h_out2, long ldh2,
                        void* h_bf16, long ldhb, void* h_bf16_2, long ldhb2,
+                       const void* A2, const void* B2, const float* bias2, const float* addend2,
+                       float* gates2, const float* c_prev2, float* h_out_2, float* c_out2, float* h_out2_2,
+                       void* h_bf16_p2, void* h_bf16_2_p2,
                        int splitk, float* workspace, long workspace_floats, void* stream);
+int cst_gemm_bf16_lstm_bwd(const void* A, long lda, const void* B, long ldb, int M, int H, int K,
+                           const float* gates, long ldg, const float* c_prev, long ldcp, const float* c_new, long ldcn,
+                           const float* dh_extra, long lddh, const float* dc_in, long lddc,
+                           float* dgates, long lddg, float* dc_prev, long lddcp, void* dgates_bf16, long lddgb,
+                           const void* A2, const void* B2, const float* gates2, const float* c_prev2, const float* c_new2,
+                           const float* dh_extra2, const float* dc_in2, float* dgates2, float* dc_prev2, void* dgates_bf16_2,
+                           int splitk, float* workspace, long workspace_floats, void* stream);
 int cst_lstm_cell_bwd(const float* gates, long ldg, const float* c_prev, long ldcp, const float* c_new, long ldcn,
                       const float* dh, long lddh, const float* dh2, long lddh2, const float* dc, long lddc,
                       float* dgates, long lddg, float* dc_prev, long lddcp, void* dgates_bf16, long lddgb,

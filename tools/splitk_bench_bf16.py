@@ -12,11 +12,12 @@ for M, N, K, note in SH:
     C = torch.empty(M, N, device="cuda")
     junk = torch.empty(64 * 1024 * 1024, device="cuda")          # 256 MB stream between GEMMs: evicts L2 like the real step
     res = []
+    TILE = int(os.environ.get("TILE", "0"))
     for sk in (0, 1, 2, 4):
         row = []
         for evict in (False, True):
             for _ in range(2):
-                ops.gemm_bf16(Ab, Bb, M, N, C=C, splitk=sk)
+                ops.gemm_bf16(Ab, Bb, M, N, C=C, splitk=sk, tile=TILE)
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
             n = 10
@@ -24,7 +25,7 @@ for M, N, K, note in SH:
                 for _ in range(n):
                     if evict:
                         junk[:8 * 1024 * 1024].zero_()
-                    ops.gemm_bf16(Ab, Bb, M, N, C=C, splitk=sk)
+                    ops.gemm_bf16(Ab, Bb, M, N, C=C, splitk=sk, tile=TILE)
             g2 = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g2):
                 for _ in range(n):
