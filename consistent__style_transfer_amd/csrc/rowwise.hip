@@ -165,12 +165,40 @@ __device__ __forceinline__ void upd(float v, int i, float& bv, int& bi) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// Optional tail of the row kernels that know the row's argmax: the embedding of the token fed to the
+// next decode step (rnn.py:88-95: scheduled sampling picks the fed-back id or the teacher token by a
+// per-step coin; embedding dropout rnn.py:96), i.e. cst_embed_gather without its own launch.
+// ---------------------------------------------------------------------------------------------
+struct GatherTail {
+    const float* table; long ldt;          // [V, E]; null = no tail
+    float* out; long ldo; unsigned short* outb; long ldob;
+    const int64_t* ids_b; long ldb; const int* coin;
+    int E, V;
+    CstDrop drop;
+};
+
+__device__ __forceinline__ void gather_tail(const GatherTail& t, long r, int id_a) {
+    if (!t.table) return;
+    long id = id_a;
+    if (t.ids_b && !(t.coin && *t.coin)) id = t.ids_b[r * t.ldb];
+    const uint32_t dseed = t.drop.p > 0.f ? cst_drop_seed(t.drop) : 0u;
+    const bool ok = id >= 0 && id < t.V;
+    const float* row = t.table + (ok ? id : 0) * t.ldt;
+    for (int c = threadIdx.x; c < t.E; c += blockDim.x) {
+        float v = ok ? row[c] : 0.f;
+        if (t.drop.p > 0.f) v *= cst_drop_mask(t.drop, dseed, (uint32_t)(r * t.E + c));
+        t.out[r * t.ldo + c] = v;
+        if (t.outb) { __bf16 h = (__bf16)v; t.outb[r * t.ldob + c] = __builtin_bit_cast(unsigned short, h); }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // temperature softmax + argmax(p)
 // ---------------------------------------------------------------------------------------------
 template <int NV4, int NTH = ROW_THREADS>
 __global__ __launch_bounds__(NTH) void softmax_tau_vec_kernel(const float* __restrict__ logits, long ld, float inv_tau,
                                                               float* __restrict__ p, long ldp,
-                                                              int64_t* __restrict__ amax, int V) {
+                                                              int64_t* __restrict__ amax, int V, GatherTail tail) {
     __shared__ float red[16];
     __shared__ int redi[16];
     const long r = blockIdx.x;
@@ -200,15 +228,16 @@ __global__ __launch_bounds__(NTH) void softmax_tau_vec_kernel(const float* __res
         if (c < V) { upd(x.v[i].x, c, bv, bi); upd(x.v[i].y, c + 1, bv, bi); upd(x.v[i].z, c + 2, bv, bi); upd(x.v[i].w, c + 3, bv, bi); }
     }
     x.store(p + r * ldp, V);
-    if (amax) {
+    if (amax || tail.table) {
         block_argmax(bv, bi, red, redi);
-        if (threadIdx.x == 0) amax[r] = bi;
+        if (amax && threadIdx.x == 0) amax[r] = bi;
+        gather_tail(tail, r, bi);
     }
 }
 
 __global__ __launch_bounds__(ROW_THREADS) void softmax_tau_generic_kernel(const float* __restrict__ logits, long ld, float inv_tau,
                                                                           float* __restrict__ p, long ldp,
-                                                                          int64_t* __restrict__ amax, int V) {
+                                                                          int64_t* __restrict__ amax, int V, GatherTail tail) {
     __shared__ float red[16];
     __shared__ int redi[16];
     const long r = blockIdx.x;
@@ -225,27 +254,55 @@ __global__ __launch_bounds__(ROW_THREADS) void softmax_tau_generic_kernel(const 
         p[r * ldp + c] = q;
         upd(q, c, bv, bi);
     }
-    if (amax) {
+    if (amax || tail.table) {
         block_argmax(bv, bi, red, redi);
-        if (threadIdx.x == 0) amax[r] = bi;
+        if (amax && threadIdx.x == 0) amax[r] = bi;
+        gather_tail(tail, r, bi);
     }
 }
 
-extern "C" int cst_softmax_tau(const float* logits, long ld, float inv_tau, float* p, long ldp,
-                               int64_t* argmax_out, int R, int V, void* stream) {
+static GatherTail make_tail(const float* table, long ldt, int E, float* out, long ldo, void* out_bf16, long ldob,
+                            const int64_t* ids_b, long ldb, const int* coin_dev, int V,
+                            float drop_p, uint32_t drop_seed, uint32_t drop_stream, const void* drop_seed_dev) {
+    GatherTail t;
+    t.table = table; t.ldt = ldt; t.out = out; t.ldo = ldo; t.outb = (unsigned short*)out_bf16; t.ldob = ldob;
+    t.ids_b = ids_b; t.ldb = ldb; t.coin = coin_dev; t.E = E; t.V = V;
+    t.drop = cst_make_drop(drop_p, drop_seed, drop_stream, drop_seed_dev);
+    return t;
+}
+
+static int softmax_tau_launch(const float* logits, long ld, float inv_tau, float* p, long ldp,
+                              int64_t* argmax_out, int R, int V, const GatherTail& tail, void* stream) {
     CST_REQUIRE(logits && p, "cst_softmax_tau: null pointer");
     CST_REQUIRE(R > 0 && V > 0 && ld >= V && ldp >= V, "cst_softmax_tau: bad shape");
     hipStream_t st = (hipStream_t)stream;
     if (row_vec_ok(logits, ld, V) && row_vec_ok(p, ldp, V) && R <= 1024 && V > 4096 && V <= 12288) {
         // few rows (one decode step): 1024-thread workgroups keep 4x the loads in flight per CU
-        hipLaunchKernelGGL((softmax_tau_vec_kernel<3, 1024>), dim3(R), dim3(1024), 0, st, logits, ld, inv_tau, p, ldp, argmax_out, V);
+        hipLaunchKernelGGL((softmax_tau_vec_kernel<3, 1024>), dim3(R), dim3(1024), 0, st, logits, ld, inv_tau, p, ldp, argmax_out, V, tail);
     } else if (row_vec_ok(logits, ld, V) && row_vec_ok(p, ldp, V)) {
-        ROW_DISPATCH(V, softmax_tau_vec_kernel, dim3(R), dim3(ROW_THREADS), 0, st, logits, ld, inv_tau, p, ldp, argmax_out, V);
+        ROW_DISPATCH(V, softmax_tau_vec_kernel, dim3(R), dim3(ROW_THREADS), 0, st, logits, ld, inv_tau, p, ldp, argmax_out, V, tail);
     } else {
-        hipLaunchKernelGGL(softmax_tau_generic_kernel, dim3(R), dim3(ROW_THREADS), 0, st, logits, ld, inv_tau, p, ldp, argmax_out, V);
+        hipLaunchKernelGGL(softmax_tau_generic_kernel, dim3(R), dim3(ROW_THREADS), 0, st, logits, ld, inv_tau, p, ldp, argmax_out, V, tail);
     }
     CST_LAUNCH_CHECK("cst_softmax_tau");
     return CST_OK;
+}
+
+extern "C" int cst_softmax_tau(const float* logits, long ld, float inv_tau, float* p, long ldp,
+                               int64_t* argmax_out, int R, int V, void* stream) {
+    GatherTail none = make_tail(nullptr, 0, 0, nullptr, 0, nullptr, 0, nullptr, 0, nullptr, 0, 0.f, 0, 0, nullptr);
+    return softmax_tau_launch(logits, ld, inv_tau, p, ldp, argmax_out, R, V, none, stream);
+}
+
+extern "C" int cst_softmax_tau_gather(const float* logits, long ld, float inv_tau, float* p, long ldp,
+                                      int64_t* argmax_out, int R, int V,
+                                      const float* table, long ldt, int E, float* out, long ldo, void* out_bf16, long ldob,
+                                      const int64_t* ids_b, long ldb, const int* coin_dev,
+                                      float drop_p, uint32_t drop_seed, uint32_t drop_stream, const void* drop_seed_dev,
+                                      void* stream) {
+    CST_REQUIRE(table && out && E > 0 && ldt >= E && ldo >= E, "cst_softmax_tau_gather: bad gather arguments");
+    GatherTail t = make_tail(table, ldt, E, out, ldo, out_bf16, ldob, ids_b, ldb, coin_dev, V, drop_p, drop_seed, drop_stream, drop_seed_dev);
+    return softmax_tau_launch(logits, ld, inv_tau, p, ldp, argmax_out, R, V, t, stream);
 }
 
 // backward: dx = inv_tau * p * (dp - sum(dp * p));  dx may alias dp
@@ -324,7 +381,7 @@ extern "C" int cst_softmax_tau_bwd(const float* p, long ldp, const float* dp, lo
 // row argmax (first index among equal maxima), int64 out
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(1024) void argmax_kernel(const float* __restrict__ x, long ld, int V, int vec,
-                                                      int64_t* __restrict__ out) {
+                                                      int64_t* __restrict__ out, GatherTail tail) {
     __shared__ float red[16];
     __shared__ int redi[16];
     const long r = blockIdx.x;
@@ -340,16 +397,33 @@ __global__ __launch_bounds__(1024) void argmax_kernel(const float* __restrict__ 
         for (int c = threadIdx.x; c < V; c += nth) upd(row[c], c, bv, bi);
     }
     block_argmax(bv, bi, red, redi);
-    if (threadIdx.x == 0) out[r] = bi == 0x7fffffff ? 0 : bi;
+    if (bi == 0x7fffffff) bi = 0;
+    if (threadIdx.x == 0) out[r] = bi;
+    gather_tail(tail, r, bi);
 }
 
-extern "C" int cst_argmax_rows(const float* x, long ld, int R, int V, int64_t* out, void* stream) {
+static int argmax_launch(const float* x, long ld, int R, int V, int64_t* out, const GatherTail& tail, void* stream) {
     CST_REQUIRE(x && out && R > 0 && V > 0 && ld >= V, "cst_argmax_rows: bad arguments");
     const int vec = (((uintptr_t)x & 15) == 0) && (ld % 4 == 0) && (V % 4 == 0);
     const int nth = (R <= 1024 && V >= 4096) ? 1024 : ROW_THREADS;
-    hipLaunchKernelGGL(argmax_kernel, dim3(R), dim3(nth), 0, (hipStream_t)stream, x, ld, V, vec, out);
+    hipLaunchKernelGGL(argmax_kernel, dim3(R), dim3(nth), 0, (hipStream_t)stream, x, ld, V, vec, out, tail);
     CST_LAUNCH_CHECK("cst_argmax_rows");
     return CST_OK;
+}
+
+extern "C" int cst_argmax_rows(const float* x, long ld, int R, int V, int64_t* out, void* stream) {
+    GatherTail none = make_tail(nullptr, 0, 0, nullptr, 0, nullptr, 0, nullptr, 0, nullptr, 0, 0.f, 0, 0, nullptr);
+    return argmax_launch(x, ld, R, V, out, none, stream);
+}
+
+extern "C" int cst_argmax_rows_gather(const float* x, long ld, int R, int V, int64_t* out,
+                                      const float* table, long ldt, int E, float* gout, long ldo, void* out_bf16, long ldob,
+                                      const int64_t* ids_b, long ldb, const int* coin_dev,
+                                      float drop_p, uint32_t drop_seed, uint32_t drop_stream, const void* drop_seed_dev,
+                                      void* stream) {
+    CST_REQUIRE(table && gout && E > 0 && ldt >= E && ldo >= E, "cst_argmax_rows_gather: bad gather arguments");
+    GatherTail t = make_tail(table, ldt, E, gout, ldo, out_bf16, ldob, ids_b, ldb, coin_dev, V, drop_p, drop_seed, drop_stream, drop_seed_dev);
+    return argmax_launch(x, ld, R, V, out, t, stream);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -220,18 +220,16 @@ class GeneratorFn(torch.autograd.Function):
             else:
                 linear_fwd(id_s, P["fn_1.weight"], P["fn_1.bias"], act=2, out=r1s)
                 linear_fwd(r1s, P["fn_2.weight"], None, out=o_s)
-            if soft:
-                softmax_tau(o_s, inv_tau, o_s, ids_fb[s])
-            else:
-                argmax_rows(o_s, ids_fb[s])
+            # the row kernel that finds the argmax also embeds the token fed to step s+1 (rnn.py:88-96)
+            fb = None
             if s + 1 < T:
-                xd = drop.at(STREAM_G_XT + s)
-                xb_next = XHb[s + 1][:, :E] if use_b else None
-                if soft or x_c is None:
-                    embed_gather(E_tok, XH[s + 1][:, :E], ids_a=ids_fb[s], drop=xd, out_b=xb_next)
-                else:
-                    embed_gather(E_tok, XH[s + 1][:, :E], ids_a=ids_fb[s], ids_b=x_c[:, s], ldb=T,
-                                 coin=coins[s:s + 1], drop=xd, out_b=xb_next)
+                fb = dict(table=E_tok, out=XH[s + 1][:, :E], out_b=XHb[s + 1][:, :E] if use_b else None, drop=drop.at(STREAM_G_XT + s))
+                if not (soft or x_c is None):
+                    fb.update(ids_b=x_c[:, s], ldb=T, coin=coins[s:s + 1])
+            if soft:
+                softmax_tau(o_s, inv_tau, o_s, ids_fb[s], gather=fb)
+            else:
+                argmax_rows(o_s, ids_fb[s], gather=fb)
 
         ctx.cfg = (B, Lp, T, V, E, H, Hd, soft, inv_tau, drop, in_drop, inp.dim() == 3, use_b)
         ctx.save_for_backward(*params, emb, ids_in, label_i, label, h0cat, memory, hprev, genc, cenc, c_cat, c0,

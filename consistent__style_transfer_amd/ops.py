@@ -238,17 +238,31 @@ def act_bwd(dy, y, slope, pos_scale=1.0, out=None):
     return out
 
 
-def argmax_rows(x, out=None):
+def argmax_rows(x, out=None, gather=None):
     R, V = x.shape
     if out is None:
         out = torch.empty(R, device=x.device, dtype=torch.int64)
-    call("cst_argmax_rows", x, _ld(x), R, V, out)
+    if gather is None:
+        call("cst_argmax_rows", x, _ld(x), R, V, out)
+    else:
+        call("cst_argmax_rows_gather", x, _ld(x), R, V, out, *_gather_args(gather))
     return out
 
 
-def softmax_tau(logits, inv_tau, p, argmax_out=None):
+def softmax_tau(logits, inv_tau, p, argmax_out=None, gather=None):
+    """gather = dict(table, out, out_b, ids_b, ldb, coin, drop): also embed the token fed to the next step."""
     R, V = logits.shape
-    call("cst_softmax_tau", logits, _ld(logits), float(inv_tau), p, _ld(p), argmax_out, R, V)
+    if gather is None:
+        call("cst_softmax_tau", logits, _ld(logits), float(inv_tau), p, _ld(p), argmax_out, R, V)
+    else:
+        call("cst_softmax_tau_gather", logits, _ld(logits), float(inv_tau), p, _ld(p), argmax_out, R, V, *_gather_args(gather))
+
+
+def _gather_args(g):
+    table, out, out_b = g["table"], g["out"], g.get("out_b")
+    ids_b = g.get("ids_b")
+    return (table, _ld(table), table.shape[1], out, _ld(out), out_b, out_b.stride(0) if out_b is not None else 0,
+            ids_b, g.get("ldb", 1), g.get("coin"), *g.get("drop", NO_DROP).args())     # ids_b: int64 column view, stride ldb
 
 
 def softmax_tau_bwd(p, dp, inv_tau, dx, dx_b=None):

@@ -93,11 +93,25 @@ int cst_token_ce(const float* logits, long ld, const int64_t* target, int R, int
  * rnn.py:83 (softmax(logits / tau)) and the argmax inside hard_sample, rnn.py:52-53. */
 int cst_softmax_tau(const float* logits, long ld, float inv_tau, float* p, long ldp,
                     int64_t* argmax_out, int R, int V, void* stream);
+/* The same, and for each row the embedding fed to the next decode step without a launch of its own:
+ * gout[r, :E] = table[sel(r)] * dropout, sel(r) = (*coin_dev != 0 or ids_b == NULL) ? argmax(r) : ids_b[r*ldb]
+ * (rnn.py:88-96; arguments as cst_embed_gather, dropout index r*E + c). */
+int cst_softmax_tau_gather(const float* logits, long ld, float inv_tau, float* p, long ldp,
+                           int64_t* argmax_out, int R, int V,
+                           const float* table, long ldt, int E, float* out, long ldo, void* out_bf16, long ldob,
+                           const int64_t* ids_b, long ldb, const int* coin_dev,
+                           float drop_p, uint32_t drop_seed, uint32_t drop_stream, const void* drop_seed_dev,
+                           void* stream);
 /* dx = inv_tau * p * (dp - sum(dp * p)); dx may alias dp. */
 int cst_softmax_tau_bwd(const float* p, long ldp, const float* dp, long lddp, float inv_tau,
                         float* dx, long lddx, void* dx_bf16, long lddxb, int R, int V, void* stream);
 /* out[r] = first index of the row maximum (rnn.py:92; main_optimize.py:104,131,162). */
 int cst_argmax_rows(const float* x, long ld, int R, int V, int64_t* out, void* stream);
+int cst_argmax_rows_gather(const float* x, long ld, int R, int V, int64_t* out,
+                           const float* table, long ldt, int E, float* gout, long ldo, void* out_bf16, long ldob,
+                           const int64_t* ids_b, long ldb, const int* coin_dev,
+                           float drop_p, uint32_t drop_seed, uint32_t drop_stream, const void* drop_seed_dev,
+                           void* stream);
 
 /* z = res + dropout(x); y = LayerNorm(z) (eps inside the sqrt, biased variance); z may alias x or
  * be null.  norm1/norm2 of nn.TransformerEncoderLayer with its dropout1/dropout2 and residuals. */
