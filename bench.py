@@ -90,17 +90,22 @@ class GraphedPipeline:
     """The three stage steps captured as hipGraphs (the optimize stage twice: with and without
     the every-4th-batch discriminator update)."""
 
-    def __init__(self, stages_, batches):
+    def __init__(self, stages_, batches, reducer=None):
+        """With a gradient reducer (N > 1) every stage step is captured as graph segments split at its
+        all-reduce points; the collectives run eagerly on the stream between the segments."""
         from consistent__style_transfer_amd.graphs import GraphedStep
         pre, wu, opt = stages_
         bp, bw, bo = batches[0]
         L = bw[1].shape[1]
         dev = bw[1].device
         c0 = coins_tensor(0, L, dev)
-        self.pre = GraphedStep(lambda *b: pre.train_step(b), list(bp), [pre])
-        self.wu = GraphedStep(lambda nx, x, lab, coins: wu.train_step((nx, x, lab), coins=coins), list(bw) + [c0], [wu])
-        self.opt_d = GraphedStep(lambda x, lab, coins: opt.train_step((x, lab), 0, coins=coins), list(bo) + [c0], [opt])
-        self.opt_nd = GraphedStep(lambda x, lab, coins: opt.train_step((x, lab), 1, coins=coins), list(bo) + [c0], [opt])
+        self.pre = GraphedStep(lambda *b, reducer=None: pre.train_step(b, reducer=reducer), list(bp), [pre], reducer=reducer)
+        self.wu = GraphedStep(lambda nx, x, lab, coins, reducer=None: wu.train_step((nx, x, lab), coins=coins, reducer=reducer),
+                              list(bw) + [c0], [wu], reducer=reducer)
+        self.opt_d = GraphedStep(lambda x, lab, coins, reducer=None: opt.train_step((x, lab), 0, coins=coins, reducer=reducer),
+                                 list(bo) + [c0], [opt], reducer=reducer)
+        self.opt_nd = GraphedStep(lambda x, lab, coins, reducer=None: opt.train_step((x, lab), 1, coins=coins, reducer=reducer),
+                                  list(bo) + [c0], [opt], reducer=reducer)
         self.L, self.dev = L, dev
 
     def step(self, batches, it):
@@ -195,9 +200,11 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    use_graph = (not args.no_graph) and world == 1
+    if os.environ.get("CST_FORCE_SEGMENTS") and reducer is None:
+        reducer = lambda groups: None                  # single-GPU rehearsal of the segmented (N > 1) launch path
+    use_graph = not args.no_graph
     if use_graph:
-        pipe = GraphedPipeline(stages_, batches)
+        pipe = GraphedPipeline(stages_, batches, reducer)
         step = lambda it: pipe.step(batches, it)
     else:
         step = lambda it: run_step(stages_, batches, it, reducer)

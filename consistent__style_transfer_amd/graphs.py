@@ -18,9 +18,14 @@ from ._lib import call
 
 
 class GraphedStep:
-    def __init__(self, fn, example_inputs, seed_modules=(), warmup=2):
+    def __init__(self, fn, example_inputs, seed_modules=(), warmup=2, reducer=None):
         """fn(*static_inputs) -> dict of tensors.  `example_inputs`: tensors fixing shapes/dtypes.
-        `seed_modules`: modules whose dropout seed must advance on every replay."""
+        `seed_modules`: modules whose dropout seed must advance on every replay.
+
+        With a `reducer` (data parallelism) fn is called as fn(*static_inputs, reducer=hook): every
+        call of the hook -- the points where the stage all-reduces its flat gradient buffers -- ends the
+        graph being captured and starts the next one, and on replay the collective runs eagerly on the
+        stream between the two segment graphs (forward/backward/gather | all-reduce | clip/Adam ...)."""
         dev = example_inputs[0].device
         self.static_in = [t.clone() for t in example_inputs]
         self.seed_dev = torch.zeros(1, dtype=torch.int32, device=dev)
@@ -30,6 +35,8 @@ class GraphedStep:
                 if st is not None:
                     st.seed_dev = self.seed_dev
         self.fn = fn
+        self.reducer = reducer
+        self._hook = reducer                              # eager passes: the real collective
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):
@@ -37,21 +44,52 @@ class GraphedStep:
                 self.first_out = self._body()
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
-        self.graph = torch.cuda.CUDAGraph()
         ops.capture_scope_reset()
+        self.graphs, self.points = [], []
         try:
-            with torch.cuda.graph(self.graph):
-                self.static_out = self._body()
+            if reducer is None:
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    self.static_out = self._body()
+                self.graphs.append(g)
+            else:
+                self._capture_segments(s)
         finally:
             ops.capture_scope_reset()
+            self._hook = reducer
         torch.cuda.synchronize()
+
+    def _capture_segments(self, side):
+        pool = torch.cuda.graph_pool_handle()
+        cur = [torch.cuda.CUDAGraph()]
+
+        def hook(groups):
+            cur[0].capture_end()
+            self.graphs.append(cur[0])
+            self.points.append(list(groups))              # nothing has run during capture: nothing to reduce yet
+            cur[0] = torch.cuda.CUDAGraph()
+            cur[0].capture_begin(pool=pool)
+
+        self._hook = hook
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            cur[0].capture_begin(pool=pool)
+            self.static_out = self._body()
+            cur[0].capture_end()
+            self.graphs.append(cur[0])
+        torch.cuda.current_stream().wait_stream(side)
 
     def _body(self):
         call("cst_add_i32", self.seed_dev, 7919)          # new dropout masks on every replay
-        return self.fn(*self.static_in)
+        if self.reducer is None:
+            return self.fn(*self.static_in)
+        return self.fn(*self.static_in, reducer=self._hook)
 
     def __call__(self, *inputs):
         for dst, src in zip(self.static_in, inputs):
             dst.copy_(src, non_blocking=True)
-        self.graph.replay()
+        for i, g in enumerate(self.graphs):
+            g.replay()
+            if i < len(self.points):
+                self.reducer(self.points[i])
         return self.static_out

@@ -43,8 +43,8 @@ class OptimizeAdapter(OptimizeStage):
     def train_batch(self, trainer, batch, batch_idx):
         coins = trainer.coins(batch[0].shape[1])
         upd = batch_idx % 4 == 0
-        out = self._steps.run(("o", upd), lambda x, lab, c: self.train_step((x, lab), 0 if upd else 1, coins=c,
-                                                                              reducer=trainer.reducer), list(batch) + [coins])
+        out = self._steps.run(("o", upd), lambda x, lab, c, reducer=None: self.train_step((x, lab), 0 if upd else 1, coins=c,
+                                                                                            reducer=reducer), list(batch) + [coins])
         return {"G": out["G"], "STI": out["STI"], "CP": out["CP_logits"], "BK": out["BK"], "D": out["D"]}
 
     def validation_step(self, trainer, batch):
@@ -94,7 +94,7 @@ def main(argv=None):
     if args.mode == "train":
         stage.train()
         stage.setup_optim()
-        stage._steps = StepCache(trainer.use_graph, [stage])
+        stage._steps = StepCache(trainer.use_graph, [stage], trainer.reducer)
         train_ds = StyleDataset([f"{data_dir}/style.train.0", f"{data_dir}/style.train.1"], vocab, args.max_len, load_s2l)
         val_ds = StyleDataset([f"{data_dir}/style.dev.0", f"{data_dir}/style.dev.1"], vocab, args.max_len, load_s2l)
         trainer.fit(stage, train_ds, val_ds, collate_optimize, args.batch_size)

@@ -34,7 +34,7 @@ class PretrainAdapter(PretrainStage):
 
     def train_batch(self, trainer, batch, batch_idx):
         key = tuple(sorted(k for k, v in self.flags.items() if v))
-        out = self._steps.run(key, lambda *b: self.train_step(b, reducer=trainer.reducer), list(batch))
+        out = self._steps.run(key, lambda *b, reducer=None: self.train_step(b, reducer=reducer), list(batch))
         return {k: out[k] for k in ("s_loss", "c_loss", "dn_loss")}
 
     def validation_step(self, trainer, batch):
@@ -71,7 +71,7 @@ def main(argv=None, label_fn=None):
     stage = PretrainAdapter(args, vocab).to(trainer.device)
     stage.train()
     stage.setup_optim()
-    stage._steps = StepCache(trainer.use_graph, [stage])
+    stage._steps = StepCache(trainer.use_graph, [stage], trainer.reducer)
     data_dir = f"{args.data_dir}/{args.dataset}"
     train_ds = StyleDataset([f"{data_dir}/style.train.0", f"{data_dir}/style.train.1"], vocab, args.max_len, load_s2l)
     val_ds = StyleDataset([f"{data_dir}/style.dev.0", f"{data_dir}/style.dev.1"], vocab, args.max_len, load_s2l)

@@ -29,7 +29,7 @@ class WarmupAdapter(WarmupStage):
 
     def train_batch(self, trainer, batch, batch_idx):
         coins = trainer.coins(batch[1].shape[1])
-        out = self._steps.run("w", lambda nx, x, lab, c: self.train_step((nx, x, lab), coins=c, reducer=trainer.reducer),
+        out = self._steps.run("w", lambda nx, x, lab, c, reducer=None: self.train_step((nx, x, lab), coins=c, reducer=reducer),
                               list(batch) + [coins])
         return {"dn_loss": out["dn_loss"]}
 
@@ -63,7 +63,7 @@ def main(argv=None):
     stage = WarmupAdapter(args, vocab).to(trainer.device)
     stage.train()
     stage.setup_optim()
-    stage._steps = StepCache(trainer.use_graph, [stage])
+    stage._steps = StepCache(trainer.use_graph, [stage], trainer.reducer)
     data_dir = f"{args.data_dir}/{args.dataset}"
     train_ds = StyleDataset([f"{data_dir}/style.train.0", f"{data_dir}/style.train.1"], vocab, args.max_len, load_s2l)
     val_ds = StyleDataset([f"{data_dir}/style.dev.0", f"{data_dir}/style.dev.1"], vocab, args.max_len, load_s2l)

@@ -86,7 +86,7 @@ class Trainer:
         self.early = EarlyStopping(patience)
         self.logger = ScalarLogger(args.log_dir, log_name, args, getattr(args, "restore_version", None), enabled=self.rank == 0)
         self.reducer = GradReducer(self.world) if self.world > 1 else None
-        self.use_graph = self.world == 1 and not getattr(args, "no_graph", False)
+        self.use_graph = not getattr(args, "no_graph", False)      # world > 1: graph segments around the eager all-reduces
         self.sanity_batches = sanity_batches
         self.global_step = 0
         self.current_epoch = 0
@@ -159,16 +159,17 @@ class StepCache:
     """hipGraph replay of a stage's train_step, re-captured whenever the static key changes (batch
     shapes; the pretrain freeze flags; the optimize stage's D-update variant)."""
 
-    def __init__(self, enabled, seed_modules):
-        self.enabled, self.seed_modules, self.graphs = enabled, seed_modules, {}
+    def __init__(self, enabled, seed_modules, reducer=None):
+        """`reducer` (world > 1): fn must accept a `reducer=` keyword; see graphs.GraphedStep."""
+        self.enabled, self.seed_modules, self.graphs, self.reducer = enabled, seed_modules, {}, reducer
 
     def run(self, key, fn, inputs):
         if not self.enabled:
-            return fn(*inputs)
+            return fn(*inputs) if self.reducer is None else fn(*inputs, reducer=self.reducer)
         k = (key,) + tuple((tuple(t.shape), t.dtype) for t in inputs)
         g = self.graphs.get(k)
         if g is None:
             # construction runs the step once eagerly on these inputs (a real training step), then captures
-            g = self.graphs[k] = GraphedStep(fn, list(inputs), self.seed_modules, warmup=1)
+            g = self.graphs[k] = GraphedStep(fn, list(inputs), self.seed_modules, warmup=1, reducer=self.reducer)
             return g.first_out
         return g(*inputs)
