@@ -175,8 +175,8 @@ extern "C" int cst_mha_fwd(const float* qkv, float* out, float* lse, int B, int 
                            float drop_p, uint32_t drop_seed, uint32_t drop_stream, const void* drop_seed_dev,
                            void* stream) {
     CST_REQUIRE(qkv && out && lse, "cst_mha_fwd: null pointer");
-    CST_REQUIRE(((uintptr_t)qkv & 15) == 0, "cst_mha_fwd: qkv must be 16-byte aligned");
     CST_REQUIRE(B > 0 && S > 0 && S <= MHA_SMAX && H > 0, "cst_mha_fwd: S=%d unsupported (max %d)", S, MHA_SMAX);
+    CST_REQUIRE(((uintptr_t)qkv & 15) == 0, "cst_mha_fwd: qkv must be 16-byte aligned");
     CstDrop dr = cst_make_drop(drop_p, drop_seed, drop_stream, drop_seed_dev);
     const float scale = 1.0f / sqrtf((float)hd);
     const size_t lds = sizeof(float) * mha_fwd_lds_floats(S, hd);
@@ -402,8 +402,8 @@ extern "C" int cst_mha_bwd(const float* qkv, const float* dout, const float* lse
                            float drop_p, uint32_t drop_seed, uint32_t drop_stream, const void* drop_seed_dev,
                            void* stream) {
     CST_REQUIRE(qkv && dout && lse && dqkv, "cst_mha_bwd: null pointer");
-    CST_REQUIRE((((uintptr_t)qkv | (uintptr_t)dout) & 15) == 0, "cst_mha_bwd: qkv / dout must be 16-byte aligned");
     CST_REQUIRE(B > 0 && S > 0 && S <= MHA_SMAX && H > 0, "cst_mha_bwd: S=%d unsupported (max %d)", S, MHA_SMAX);
+    CST_REQUIRE((((uintptr_t)qkv | (uintptr_t)dout) & 15) == 0, "cst_mha_bwd: qkv / dout must be 16-byte aligned");
     CstDrop dr = cst_make_drop(drop_p, drop_seed, drop_stream, drop_seed_dev);
     const float scale = 1.0f / sqrtf((float)hd);
     const size_t lds = sizeof(float) * mha_bwd_lds_floats(S, hd);
