@@ -173,6 +173,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-stage-split", action="store_true", help="skip the per-stage timing leg")
     ap.add_argument("--workload", default="yelp_4l_d512_b256", choices=sorted(WORKLOADS))
     ap.add_argument("--precision", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -218,6 +219,37 @@ def main():
     dt = max_over_ranks(time.perf_counter() - t0, device)
     ms_per_step = 1000.0 * dt / args.steps
     value = w["B"] * world * args.steps / dt
+
+    # per-stage split of the step (the metric is reported per stage as well): the same graphs / eager
+    # calls timed one stage at a time, outside the timed region above
+    per_stage = None
+    if not args.no_stage_split:
+        from consistent__style_transfer_amd.flops import stage_gflop_per_sentence
+        gf = stage_gflop_per_sentence(w["n_layer"], w["d_model"], w["L"], w["V"])
+        pre, wu, opt = stages_
+        L, nst = w["L"], max(4, min(args.steps, 8))
+
+        def stage_calls(it):
+            bp, bw, bo = batches[it % len(batches)]
+            if use_graph:
+                return {"pretrain": lambda: pipe.pre(*bp), "warmup": lambda: pipe.wu(*bw, coins_tensor(2 * it, L, device)),
+                        "optimize": lambda: (pipe.opt_d if it % 4 == 0 else pipe.opt_nd)(*bo, coins_tensor(2 * it + 1, L, device))}
+            return {"pretrain": lambda: pre.train_step(bp, seed=3 * it, reducer=reducer),
+                    "warmup": lambda: wu.train_step(bw, coins=coins_tensor(2 * it, L, device), seed=3 * it + 1, reducer=reducer),
+                    "optimize": lambda: opt.train_step(bo, it, coins=coins_tensor(2 * it + 1, L, device), seed=3 * it + 2, reducer=reducer)}
+
+        per_stage = {}
+        base = args.warmup + args.steps
+        for name in ("pretrain", "warmup", "optimize"):
+            barrier()
+            t1 = time.perf_counter()
+            for it in range(nst):
+                stage_calls(base + it)[name]()
+            barrier()
+            ms = 1000.0 * max_over_ranks(time.perf_counter() - t1, device) / nst
+            g = gf[name] if name != "optimize" else gf["optimize_g"] + gf["optimize_d"]
+            per_stage[name] = {"ms_per_step": ms, "sentences_per_s": w["B"] * world / (ms * 1e-3), "algorithmic_gflop_per_sentence": g,
+                               "model_tflops": g * w["B"] * world / (ms * 1e-3) / 1e3}
 
     roofline = None
     if rank == 0 and not args.no_roofline:
@@ -282,8 +314,8 @@ def main():
             "config": {"workload": args.workload, "per_gpu_batch": w["B"], "global_batch": w["B"] * world,
                        "seq_len": w["L"], "vocab": w["V"], "critic_layers": w["n_layer"], "d_model": w["d_model"],
                        "parallelism": f"dp{world}", "stages": "pretrain+warmup+optimize(G+D)", "weights": "random-init",
-                       "launch": "hipGraph replay" if use_graph else "eager"},
-            "roofline": roofline, "cpu_baseline": cpu,
+                       "launch": ("hipGraph replay" if world == 1 else "hipGraph segments + eager all-reduce") if use_graph else "eager"},
+            "roofline": roofline, "cpu_baseline": cpu, "per_stage": per_stage,
         }
         print(json.dumps(line), flush=True)
     if world > 1:

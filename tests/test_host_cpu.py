@@ -86,3 +86,16 @@ def test_cli_contract():
         arguments.fetch_args(["--ver", "1"])                       # --dataset is required
     c = arguments.fetch_args(["--dataset", "yelp", "--ver", "x", "--batch_size", "2048", "--n_layer", "4"])
     assert c.batch_size == 2048 and c.n_layer == 4
+
+
+def test_flop_counter_reproduces_survey_table():
+    """algorithmic GFLOP per sentence per stage (the counter bench.py reports model TFLOP/s with).
+    The survey's optimize-G column also counts the decoder's straight-through `hard_sample(p) @ E` product (46 MFLOP at
+    L=18, rnn.py:84-85), which is a gather of one row here and counts 0: hence the 2 % band on that column."""
+    from consistent__style_transfer_amd.flops import stage_gflop_per_sentence
+    table = {(2, 256, 16): (1.03, 0.75, 2.34, 0.76), (4, 512, 18): (4.70, 0.84, 4.26, 0.82), (6, 512, 18): (6.75, 0.84, 5.18, 0.82),
+             (6, 512, 30): (11.3, 1.40, 8.60, 1.17), (6, 768, 18): (11.6, 0.84, 7.42, 0.82)}
+    for (n_layer, d, L), want in table.items():
+        got = stage_gflop_per_sentence(n_layer, d, L, 10000)
+        for k, w in zip(("pretrain", "warmup", "optimize_g", "optimize_d"), want):
+            assert abs(got[k] - w) <= 0.02 * w + 0.006, (n_layer, d, L, k, got[k], w)
