@@ -154,6 +154,40 @@ extern "C" int cst_embed_scatter_add(const int64_t* ids_a, const int64_t* ids_b,
     return CST_OK;
 }
 
+// The decoder's embedding gradients of ALL steps in one launch (rnn.py:88-96 backward): row r = s*B + b of
+// dout is the gradient of the token fed to step s+1, chosen by coins[s] between the fed-back id ids_a[s*B+b]
+// and the teacher token ids_b[b*ldb + s]; its dropout mask is that of call-site stream drop.stream + s, element
+// b*E + c -- exactly what S separate cst_embed_scatter_add launches (one per step) compute.
+__global__ void embed_scatter_steps_kernel(const int64_t* __restrict__ ids_a, const int64_t* __restrict__ ids_b, long ldb,
+                                           const int* __restrict__ coins, const float* __restrict__ dout, long ldo,
+                                           float* __restrict__ dtable, long ldt, int S, int B, int E, int V, CstDrop drop) {
+    const uint32_t dseed = drop.p > 0.f ? cst_drop_seed(drop) : 0u;
+    const int total = S * B * E;                       // < 2^31 (checked by the host wrapper): 32-bit index arithmetic
+    for (int e = blockIdx.x * EW_THREADS + threadIdx.x; e < total; e += gridDim.x * EW_THREADS) {
+        const int r = e / E, c = e - r * E;
+        const int s = r / B, b = r - s * B;
+        long id = ids_a[r];
+        if (ids_b && !(coins && coins[s])) id = ids_b[(long)b * ldb + s];
+        if (id < 0 || id >= V) continue;
+        float g = dout[(long)r * ldo + c];
+        if (drop.p > 0.f)
+            g *= ((cst_mix32(dseed, drop.stream + (uint32_t)s, (uint32_t)(b * E + c)) >> 8) >= drop.thresh) ? drop.scale : 0.0f;
+        atomicAdd(&dtable[id * ldt + c], g);
+    }
+}
+
+extern "C" int cst_embed_scatter_add_steps(const int64_t* ids_a, const int64_t* ids_b, long ldb, const int* coins_dev,
+                                           const float* dout, long ldo, float* dtable, long ldt, int S, int B, int E, int V,
+                                           float drop_p, uint32_t drop_seed, uint32_t drop_stream, const void* drop_seed_dev, void* stream) {
+    CST_REQUIRE(ids_a && dout && dtable && S > 0 && B > 0 && E > 0 && ldo >= E && ldt >= E, "cst_embed_scatter_add_steps: bad arguments");
+    CST_REQUIRE((long)S * B * E < (1L << 31), "cst_embed_scatter_add_steps: S*B*E too large");
+    CstDrop dr = cst_make_drop(drop_p, drop_seed, drop_stream, drop_seed_dev);
+    hipLaunchKernelGGL(embed_scatter_steps_kernel, ew_grid((long)S * B * E), dim3(EW_THREADS), 0, (hipStream_t)stream,
+                       ids_a, ids_b, ldb, coins_dev, dout, ldo, dtable, ldt, S, B, E, V, dr);
+    CST_LAUNCH_CHECK("cst_embed_scatter_add_steps");
+    return CST_OK;
+}
+
 // token (+pre-multiplied soft) + position + segment embedding into rows [off, off+L) of x [B,S,d]
 __global__ void tps_embed_fwd_kernel(const int64_t* __restrict__ ids, const float* __restrict__ pre,
                                      const float* __restrict__ Etok, const float* __restrict__ Epos, const float* __restrict__ seg,

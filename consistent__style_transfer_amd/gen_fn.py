@@ -267,8 +267,8 @@ class GeneratorFn(torch.autograd.Function):
             # and one through fn_1 instead of T small ones
             dgrad(dout.view(B * T, V), P["fn_2.weight"], out=dpre1.view(B * T, Hd), aux=r1.view(B * T, Hd), act=4)
             dgrad(dpre1.view(B * T, Hd), P["fn_1.weight"], out=diffn_all.view(B * T, W_))
-        dXH = _new(dev, B, E + Hd)
-        dxe = _new(dev, B, E)
+        dXH_all = _new(dev, T, B, E + Hd)              # step s writes [d x_s | d h_{s-1}] into slice s
+        dxe_all = _new(dev, max(T - 1, 1), B, E) if (soft and drop.p > 0) else None
         dc = _new(dev, B, Hd)
         if use_b:
             fn1_t = weight_bf16(P["fn_1.weight"])[1]                # [W_, Hd]
@@ -279,22 +279,17 @@ class GeneratorFn(torch.autograd.Function):
                 dp1b = _i16(dev, B, Hd)
         for s in range(T - 1, -1, -1):
             dl = dout2[:, s * V:(s + 1) * V]
-            if s + 1 < T:
-                # gradient of the embedding that fed step s+1 (dropout STREAM_G_XT+s was applied to it)
+            dXH = dXH_all[s + 1] if s + 1 < T else None        # written by step s+1's dgrad below
+            if s + 1 < T and soft:
+                # gradient of the embedding that fed step s+1 (dropout STREAM_G_XT+s was applied to it);
+                # straight-through: d p_s += dx @ E^T (rnn.py:84-85).  The scatter into dE waits for the end of the loop.
                 xd = drop.at(STREAM_G_XT + s)
-                if soft:
-                    if xd.p > 0:
-                        dropout2d(dXH[:, :E], xd, out=dxe)
-                        g_x = dxe
-                    else:
-                        g_x = dXH[:, :E]
-                    # straight-through: d p_s += dx @ E^T ; dE += onehot(argmax)^T dx   (rnn.py:84-85)
-                    gemm(g_x, True, E_tok, True, dl, B, V, E, accumulate=True)
-                    embed_scatter_add(dE, g_x, ids_a=ids_fb[s])
-                elif x_c is None:
-                    embed_scatter_add(dE, dXH[:, :E], ids_a=ids_fb[s], drop=xd)       # dropout mask applied in the scatter
+                if xd.p > 0:
+                    g_x = dxe_all[s]
+                    dropout2d(dXH[:, :E], xd, out=g_x)
                 else:
-                    embed_scatter_add(dE, dXH[:, :E], ids_a=ids_fb[s], ids_b=x_c[:, s], ldb=T, coin=coins[s:s + 1], drop=xd)
+                    g_x = dXH[:, :E]
+                gemm(g_x, True, E_tok, True, dl, B, V, E, accumulate=True)
             if soft:
                 softmax_tau_bwd(out2[:, s * V:(s + 1) * V], dl, inv_tau, dl, dx_b=dlb if use_b else None)
             diffn = df2[:, s * W_:(s + 1) * W_]
@@ -317,9 +312,21 @@ class GeneratorFn(torch.autograd.Function):
             _cell_bwd(gdec[s], c_prev, cdec[s], diffn[:, :Hd], None if last else dXH[:, E:], None if last else dc,
                       dgd[s], dc, B, Hd, dgb=dgdb if use_b else None)
             if use_b:
-                gemm_bf16(dgdb, wcat_t, B, E + Hd, C=dXH)
+                gemm_bf16(dgdb, wcat_t, B, E + Hd, C=dXH_all[s])
             else:
-                dgrad(dgd[s], wcat, out=dXH)
+                dgrad(dgd[s], wcat, out=dXH_all[s])
+        # embedding gradients of the tokens fed to steps 1..T-1, all steps in one scatter
+        if T > 1:
+            S_ = T - 1
+            if soft:
+                src = dxe_all.view(S_ * B, E) if drop.p > 0 else dXH_all[1:].view(S_ * B, E + Hd)[:, :E]
+                call("cst_embed_scatter_add_steps", ids_fb.view(-1), None, 0, None, src, src.stride(0), dE, E, S_, B, E, V,
+                     *NO_DROP.args())
+            else:
+                src = dXH_all[1:].view(S_ * B, E + Hd)[:, :E]
+                call("cst_embed_scatter_add_steps", ids_fb.view(-1), x_c, T if x_c is not None else 0,
+                     coins if x_c is not None else None, src, E + Hd, dE, E, S_, B, E, V, *drop.at(STREAM_G_XT).args())
+        dXH = dXH_all[0]
         # step 0 input was the start embedding (no dropout), h_{-1} the style embedding
         G["start_embedding.weight"] = colsum(dXH[:, :E]).view(1, E)
         dstyle = torch.zeros_like(P["style_embedding.weight"])

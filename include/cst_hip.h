@@ -195,6 +195,14 @@ int cst_embed_scatter_add(const int64_t* ids_a, const int64_t* ids_b, long ldb, 
                           const float* dout, long ldo, float* dtable, long ldt, int transposed, int R, int E, int V,
                           float drop_p, uint32_t drop_seed, uint32_t drop_stream, const void* drop_seed_dev, void* stream);
 
+/* The decoder's S per-step embedding gradients in one launch (backward of rnn.py:88-96): row s*B + b of dout belongs
+ * to the token fed to step s+1 -- ids_a[s*B+b] if coins_dev[s] != 0 (or ids_b == NULL) else ids_b[b*ldb + s] -- and
+ * carries the dropout mask of call-site stream drop_stream + s, element b*E + c: identical to S launches of
+ * cst_embed_scatter_add with (ids_a + s*B, ids_b + s, coin = coins_dev + s, drop_stream + s). */
+int cst_embed_scatter_add_steps(const int64_t* ids_a, const int64_t* ids_b, long ldb, const int* coins_dev,
+                                const float* dout, long ldo, float* dtable, long ldt, int S, int B, int E, int V,
+                                float drop_p, uint32_t drop_seed, uint32_t drop_stream, const void* drop_seed_dev, void* stream);
+
 /* x[b, off+l, :] = (Etok[ids[b,l]] | pre[b,l,:]) + Epos[l] (+ seg_row)   (mlm.py:27-38; match.py:24-34). */
 int cst_tps_embed_fwd(const int64_t* ids, const float* pre, const float* Etok, const float* Epos, const float* seg_row,
                       float* x, int B, int L, int d, int S, int off, int V, void* stream);
