@@ -592,6 +592,99 @@ __global__ __launch_bounds__(1024) void dot_attn_bwd_kernel(const float* __restr
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Decoder attention backward for ALL T decode steps of a batch row in one workgroup (teacher-forced /
+// free-running decodes, where the FFN gradients of every step are known before the recurrence runs):
+// the memory tile is staged once instead of T times, d memory is accumulated in LDS and written once,
+// and the dropout of the FFN input (rnn.py:78-79, call-site stream drop.stream + s, element b*2D + c)
+// is applied on the way in.  g = diffn[b, s, 0:2D] holds d[h | a] of the FFN input; on return
+// diffn[b, s, 0:D] = dropout(g)[0:D] + dq (the total d h_s that the LSTM cell backward consumes).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void dot_attn_bwd_steps_kernel(float* __restrict__ diffn, long ldrow, long gstep,
+                                                                 const float* __restrict__ q, long ldq, long qstep,
+                                                                 const float* __restrict__ mem, const float* __restrict__ p,
+                                                                 float* __restrict__ dmem, int B, int T, int L, int D, float scale,
+                                                                 CstDrop drop) {
+    extern __shared__ __attribute__((aligned(16))) float dsm[];
+    float* ms = dsm;                 // [L][D] memory tile
+    float* dms = ms + L * D;         // [L][D] d memory accumulated over the steps
+    float* gs = dms + L * D;         // [D]    dropped d a_s
+    float* qs = gs + D;              // [D]    h_s
+    float* ds = qs + D;              // [64]
+    float* ps = ds + 64;             // [64]
+    const int b = blockIdx.x, lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const int tid = threadIdx.x;
+    stage_f4(reinterpret_cast<const float4*>(mem + (long)b * L * D), reinterpret_cast<float4*>(ms), L * D / 4);
+    for (int e = tid; e < L * D; e += blockDim.x) dms[e] = 0.f;
+    const uint32_t dseed = drop.p > 0.f ? cst_drop_seed(drop) : 0u;
+    float* gb = diffn + (long)b * ldrow;
+    const float* qb = q + (long)b * ldq;
+    // step 0 operands; inside the loop the next step's are requested before this step's arithmetic
+    float graw = tid < 2 * D ? gb[tid] : 0.f;
+    float qv = tid < D ? qb[tid] : 0.f;
+    float pv = tid < L ? p[(long)b * L + tid] : 0.f;
+    __syncthreads();
+    for (int s = 0; s < T; ++s) {
+        float gh = 0.f;
+        if (tid < 2 * D) {
+            float gd = graw;
+            if (drop.p > 0.f)
+                gd *= ((cst_mix32(dseed, drop.stream + (uint32_t)s, (uint32_t)((long)b * 2 * D + tid)) >> 8) >= drop.thresh) ? drop.scale : 0.0f;
+            if (tid >= D) gs[tid - D] = gd; else gh = gd;
+        }
+        if (tid < D) qs[tid] = qv;
+        if (tid < L) ps[tid] = pv;
+        if (s + 1 < T) {                                   // prefetch
+            graw = tid < 2 * D ? gb[(long)(s + 1) * gstep + tid] : 0.f;
+            qv = tid < D ? qb[(long)(s + 1) * qstep + tid] : 0.f;
+            pv = tid < L ? p[((long)(s + 1) * B + b) * L + tid] : 0.f;
+        }
+        __syncthreads();
+        for (int j = w; j < L; j += nw) {
+            float a = 0.f;
+            for (int c = lane; c < D; c += 64) a += gs[c] * ms[j * D + c];
+            a = wave_sum(a);
+            if (lane == 0) ds[j] = a;                      // dp_j
+        }
+        __syncthreads();
+        float delta = 0.f;
+        for (int j = 0; j < L; ++j) delta += ds[j] * ps[j];
+        __syncthreads();
+        if (tid < L) ds[tid] = ps[tid] * (ds[tid] - delta) * scale;
+        __syncthreads();
+        if (tid < D) {
+            const float g = gs[tid], qc = qs[tid];
+            float a = 0.f;
+            for (int j = 0; j < L; ++j) {
+                const float dsj = ds[j];
+                a += dsj * ms[j * D + tid];
+                dms[j * D + tid] += ps[j] * g + dsj * qc;
+            }
+            gb[(long)s * gstep + tid] = gh + a;
+        }
+        __syncthreads();
+    }
+    float* dmb = dmem + (long)b * L * D;
+    for (int e = tid; e < L * D; e += blockDim.x) dmb[e] += dms[e];
+}
+
+extern "C" int cst_dot_attn_bwd_steps(float* diffn, long ldrow, long gstep, const float* q, long ldq, long qstep,
+                                      const float* mem, const float* p, float* dmem, int B, int T, int L, int D,
+                                      float drop_p, uint32_t drop_seed, uint32_t drop_stream, const void* drop_seed_dev, void* stream) {
+    CST_REQUIRE(diffn && q && mem && p && dmem, "cst_dot_attn_bwd_steps: null pointer");
+    CST_REQUIRE(B > 0 && T > 0 && L > 0 && L <= MHA_SMAX && D > 0 && D % 4 == 0 && 2 * D <= 1024,
+                "cst_dot_attn_bwd_steps: L=%d (max %d) or D=%d (max 512) unsupported", L, MHA_SMAX, D);
+    CST_REQUIRE(((uintptr_t)mem & 15) == 0, "cst_dot_attn_bwd_steps: mem must be 16-byte aligned");
+    const size_t lds = sizeof(float) * ((size_t)2 * L * D + 2 * D + 128);
+    CST_REQUIRE(lds <= 160 * 1024, "cst_dot_attn_bwd_steps: tiles of %zu bytes exceed the 160 KiB LDS", lds);
+    if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)dot_attn_bwd_steps_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    CstDrop dr = cst_make_drop(drop_p, drop_seed, drop_stream, drop_seed_dev);
+    hipLaunchKernelGGL(dot_attn_bwd_steps_kernel, dim3(B), dim3(1024), lds, (hipStream_t)stream, diffn, ldrow, gstep, q, ldq, qstep, mem, p,
+                       dmem, B, T, L, D, 1.0f / sqrtf((float)D), dr);
+    CST_LAUNCH_CHECK("cst_dot_attn_bwd_steps");
+    return CST_OK;
+}
+
 extern "C" int cst_dot_attn_bwd(const float* dout, long lddo, const float* q, long ldq, const float* mem, const float* p,
                                 float* dq, long lddq, int dq_accumulate, float* dmem, int B, int L, int D, void* stream) {
     CST_REQUIRE(dout && q && mem && p && dq && dmem, "cst_dot_attn_bwd: null pointer");

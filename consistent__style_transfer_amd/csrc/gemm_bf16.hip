@@ -622,20 +622,30 @@ struct LstmBwdEpi {
 };
 struct LstmBwdEpi2 {
     LstmBwdEpi e[2];
+    float* extra[2]; long ldx; int n_extra;           // leading n_extra columns of the product: summed and stored as they are
     const float* slab; int splits; int M, H;
     long ldg, ldcp, ldcn, lddh, lddc, lddg, lddcp, lddgb;
 };
 
 __global__ __launch_bounds__(256) void cst_gemm_bf16_lstm_bwd_reduce(LstmBwdEpi2 q) {
     const LstmBwdEpi& p = q.e[blockIdx.y];
-    const int H4 = q.H >> 2;
-    const int idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx >= q.M * H4) return;
-    const int m = idx / H4, u = (idx - m * H4) * 4;
-    const long MN = (long)q.M * q.H;
+    const int H4 = q.H >> 2, X4 = q.n_extra >> 2;
+    const int N = q.n_extra + q.H;
+    const long MN = (long)q.M * N;
     const float* slab = q.slab + (long)blockIdx.y * q.splits * MN;
+    int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= q.M * H4) {                               // the pass-through columns (decoder: d x_t next to d h_{t-1})
+        idx -= q.M * H4;
+        if (idx >= q.M * X4) return;
+        const int m = idx / X4, c = (idx - m * X4) * 4;
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int s = 0; s < q.splits; ++s) f4_add(v, slab + s * MN + (long)m * N + c);
+        f4_store(q.extra[blockIdx.y] + (long)m * q.ldx + c, v);
+        return;
+    }
+    const int m = idx / H4, u = (idx - m * H4) * 4;
     float dht[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int s = 0; s < q.splits; ++s) f4_add(dht, slab + s * MN + (long)m * q.H + u);
+    for (int s = 0; s < q.splits; ++s) f4_add(dht, slab + s * MN + (long)m * N + q.n_extra + u);
     if (p.dh_extra) f4_add(dht, p.dh_extra + (long)m * q.lddh + u);
     float gi[4] = {0.f, 0.f, 0.f, 0.f}, gf[4] = {0.f, 0.f, 0.f, 0.f}, gg[4] = {0.f, 0.f, 0.f, 0.f}, go[4] = {0.f, 0.f, 0.f, 0.f};
     const float* g = p.gates + (long)m * q.ldg + u;
@@ -670,8 +680,11 @@ extern "C" int cst_gemm_bf16_lstm_bwd(const void* A, long lda, const void* B, lo
                                       float* dgates, long lddg, float* dc_prev, long lddcp, void* dgates_bf16, long lddgb,
                                       const void* A2, const void* B2, const float* gates2, const float* c_prev2, const float* c_new2,
                                       const float* dh_extra2, const float* dc_in2, float* dgates2, float* dc_prev2, void* dgates_bf16_2,
+                                      int n_extra, float* extra_out, float* extra_out2, long ldx,
                                       int splitk, float* workspace, long workspace_floats, void* stream) {
     CST_REQUIRE(gates && c_prev && c_new && dgates && dc_prev, "cst_gemm_bf16_lstm_bwd: null pointer");
+    CST_REQUIRE(n_extra >= 0 && n_extra % 4 == 0 && (n_extra == 0 || (extra_out && ldx >= n_extra && ldx % 4 == 0 && al16(extra_out) && al16(extra_out2))),
+                "cst_gemm_bf16_lstm_bwd: bad pass-through columns (n_extra=%d)", n_extra);
     CST_REQUIRE(H > 0 && H % 4 == 0, "cst_gemm_bf16_lstm_bwd: H=%d must be a positive multiple of 4", H);
     CST_REQUIRE(!A2 || (gates2 && c_prev2 && c_new2 && dgates2 && dc_prev2), "cst_gemm_bf16_lstm_bwd: second problem incomplete");
     const bool al = ((ldg | ldcp | ldcn | lddh | lddc | lddg | lddcp | lddgb) % 4 == 0) &&
@@ -681,13 +694,14 @@ extern "C" int cst_gemm_bf16_lstm_bwd(const void* A, long lda, const void* B, lo
     CST_REQUIRE(al, "cst_gemm_bf16_lstm_bwd: every row pointer must be 16-byte aligned (leading dimensions multiples of 4)");
     hipStream_t st = (hipStream_t)stream;
     BGemmArgs g;
-    if (int rc = lstm_gemm_front("cst_gemm_bf16_lstm_bwd", g, A, B, A2, B2, lda, ldb, M, H, K, splitk, workspace, workspace_floats, st)) return rc;
+    if (int rc = lstm_gemm_front("cst_gemm_bf16_lstm_bwd", g, A, B, A2, B2, lda, ldb, M, n_extra + H, K, splitk, workspace, workspace_floats, st)) return rc;
     LstmBwdEpi2 q;
     q.e[0] = LstmBwdEpi{gates, c_prev, c_new, dh_extra, dc_in, dgates, dc_prev, (bf16_t*)dgates_bf16};
     q.e[1] = LstmBwdEpi{gates2, c_prev2, c_new2, dh_extra2, dc_in2, dgates2, dc_prev2, (bf16_t*)dgates_bf16_2};
+    q.extra[0] = extra_out; q.extra[1] = extra_out2; q.ldx = ldx; q.n_extra = n_extra;
     q.slab = workspace; q.splits = g.splits; q.M = M; q.H = H;
     q.ldg = ldg; q.ldcp = ldcp; q.ldcn = ldcn; q.lddh = lddh; q.lddc = lddc; q.lddg = lddg; q.lddcp = lddcp; q.lddgb = lddgb;
-    const int nthr = M * (H / 4);
+    const int nthr = M * ((H + n_extra) / 4);
     hipLaunchKernelGGL(cst_gemm_bf16_lstm_bwd_reduce, dim3((nthr + 255) / 256, A2 ? 2 : 1), dim3(256), 0, st, q);
     CST_LAUNCH_CHECK("cst_gemm_bf16_lstm_bwd_reduce");
     return CST_OK;

@@ -64,6 +64,7 @@ def _gemm_cell_bwd(probs, B, H):
          p["dgates"], p["dgates"].stride(0), p["dc_prev"], p["dc_prev"].stride(0), g(p, "dgb"), _st(g(p, "dgb")),
          g(q, "Ab"), g(q, "Bb"), g(q, "gates"), g(q, "c_prev"), g(q, "c_new"), g(q, "dh_extra"), g(q, "dc_in"),
          g(q, "dgates"), g(q, "dc_prev"), g(q, "dgb"),
+         p.get("n_extra", 0), g(p, "extra_out"), g(q, "extra_out"), _st(g(p, "extra_out")),
          ops.LSTM_SPLITK, ops._workspace(p["gates"].device), ops.WS_FLOATS)
 
 
@@ -277,7 +278,24 @@ class GeneratorFn(torch.autograd.Function):
             if soft:
                 dlb = torch.zeros(B, (V + 63) // 64 * 64, device=dev, dtype=torch.int16)    # K padding stays zero
                 dp1b = _i16(dev, B, Hd)
-        for s in range(T - 1, -1, -1):
+        # Teacher-forced / free-running decodes on the bf16 path: every step's FFN gradient is already in
+        # diffn_all, so the attention backward of all steps runs as ONE launch (memory tile staged once per
+        # batch row, FFN-input dropout applied on the way in) and each step of the recurrence is one launch
+        # pair: dgates_{s+1} [W_ih | W_hh] with the cell backward of step s inside its split-K reduce.
+        steps_fused = (not soft) and use_b and 2 * Hd <= 1024 and Hd == 2 * H and E % 4 == 0
+        if steps_fused:
+            call("cst_dot_attn_bwd_steps", df2, T * W_, W_, if2, T * W_, W_, memory, patt, dmem, B, T, Lp, Hd,
+                 *drop.at(STREAM_G_FFN).args())
+            for s in range(T - 1, -1, -1):
+                c_prev = c0 if s == 0 else cdec[s - 1]
+                diffn = df2[:, s * W_:(s + 1) * W_]
+                if s == T - 1:
+                    _cell_bwd(gdec[s], c_prev, cdec[s], diffn[:, :Hd], None, None, dgd[s], dc, B, Hd, dgb=dgdb)
+                else:
+                    _gemm_cell_bwd([dict(Ab=dgdb, Bb=wcat_t, gates=gdec[s], c_prev=c_prev, c_new=cdec[s], dh_extra=diffn[:, :Hd],
+                                         dc_in=dc, dgates=dgd[s], dc_prev=dc, dgb=dgdb, n_extra=E, extra_out=dXH_all[s + 1][:, :E])], B, Hd)
+            gemm_bf16(dgdb, wcat_t, B, E + Hd, C=dXH_all[0])
+        for s in (() if steps_fused else range(T - 1, -1, -1)):
             dl = dout2[:, s * V:(s + 1) * V]
             dXH = dXH_all[s + 1] if s + 1 < T else None        # written by step s+1's dgrad below
             if s + 1 < T and soft:

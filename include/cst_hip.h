@@ -142,9 +142,15 @@ int cst_mha_bwd(const float* qkv, const float* dout, const float* lse, float* dq
 int cst_dot_attn_fwd(const float* q, long ldq, const float* mem, float* out, long ldo, float* p,
                      int B, int L, int D, float* dropped, long lddrop, void* dropped_bf16, long lddropb,
                      float drop_p, uint32_t drop_seed, uint32_t drop_stream, const void* drop_seed_dev, void* stream);
-/* dq (+)= ..., dmem += ... (dmem accumulates across decode steps; zero it first). */
+/* dq (+)= ..., dmem += ... (dmem accumulates across decode steps; zero it first).
+ * _steps: all T decode steps of a batch row in one workgroup, for decodes whose FFN gradients are known up front:
+ * diffn [B, T, 2D] holds d[h | a] of the FFN input before its dropout (stream drop_stream + s, element b*2D + c);
+ * on return diffn[b, s, 0:D] = dropout(.)[0:D] + dq.  q [B, T, .]: h_s rows; p [T, B, L]; dmem += sum over steps. */
 int cst_dot_attn_bwd(const float* dout, long lddo, const float* q, long ldq, const float* mem, const float* p,
                      float* dq, long lddq, int dq_accumulate, float* dmem, int B, int L, int D, void* stream);
+int cst_dot_attn_bwd_steps(float* diffn, long ldrow, long gstep, const float* q, long ldq, long qstep,
+                           const float* mem, const float* p, float* dmem, int B, int T, int L, int D,
+                           float drop_p, uint32_t drop_seed, uint32_t drop_stream, const void* drop_seed_dev, void* stream);
 
 /* LSTM cell (gate order i,f,g,o as nn.LSTM, rnn.py:25-33): gates [B,4H] pre-activation in,
  * activations out (kept for backward); h_out2 optional second copy of h; h_bf16 / h_bf16_2 optional
@@ -158,7 +164,9 @@ int cst_lstm_cell_fwd(float* gates, long ldg, const float* c_prev, long ldcp, fl
  *   forward:  gates = A B^T (+ bias) (+ addend) as cst_gemm_bf16 (A [M,K], B [4H,K] bf16, K % 64 == 0), then the
  *             cell of cst_lstm_cell_fwd.
  *   backward: dh = A B^T (A = dgates of the step after [M,4H] bf16, B = W_hh^T [H,4H] bf16, K = 4H) (+ dh_extra),
- *             then the cell backward of cst_lstm_cell_bwd for this step (dc_in NULL = 0).
+ *             then the cell backward of cst_lstm_cell_bwd for this step (dc_in NULL = 0).  n_extra > 0: B has n_extra
+ *             leading rows whose products are stored as they are in extra_out [M, ldx] (the decoder's
+ *             [W_ih | W_hh]^T: d x_t next to d h_{t-1}).
  * The product's split-K partials go to the workspace (>= problems*splits*M*N floats; splitk 0 = heuristic) and ONE
  * second kernel sums them and applies the cell: no pre-activation / dh round trip, no separate reduce and cell
  * launches.  Every fp32 row pointer must be 16-byte aligned (H % 4 == 0, leading dimensions multiples of 4). */
@@ -177,6 +185,7 @@ int cst_gemm_bf16_lstm_bwd(const void* A, long lda, const void* B, long ldb, int
                            float* dgates, long lddg, float* dc_prev, long lddcp, void* dgates_bf16, long lddgb,
                            const void* A2, const void* B2, const float* gates2, const float* c_prev2, const float* c_new2,
                            const float* dh_extra2, const float* dc_in2, float* dgates2, float* dc_prev2, void* dgates_bf16_2,
+                           int n_extra, float* extra_out, float* extra_out2, long ldx,
                            int splitk, float* workspace, long workspace_floats, void* stream);
 int cst_lstm_cell_bwd(const float* gates, long ldg, const float* c_prev, long ldcp, const float* c_new, long ldcn,
                       const float* dh, long lddh, const float* dh2, long lddh2, const float* dc, long lddc,
