@@ -479,3 +479,91 @@ def test_clip_and_adam(ops):
         call("cst_add_i32", step, 1)
         call("cst_adam_step", p, g, m, v, n, 1e-3, 0.9, 0.999, 1e-8, step)
         close(p, pr, 1e-5, 1e-6)
+
+
+# ------------------------------------------------------------- fused recurrent-step entry points
+@pytest.mark.parametrize("B,T,L,D,p", [(3, 4, 5, 32, 0.0), (5, 6, 7, 64, 0.25), (2, 18, 18, 512, 0.1)])
+def test_dot_attn_bwd_steps_equals_per_step_calls(ops, B, T, L, D, p):
+    """All decode steps in one launch == T launches of cst_dropout + cst_dot_attn_bwd (the path it replaces)."""
+    from consistent__style_transfer_amd._lib import call
+    W = 2 * D
+    g = dev(rnd(B, T * W, seed=1))
+    q = dev(rnd(B, T * W, seed=2))                                   # h_s sits in the first D columns of each step's slot
+    mem = dev(rnd(B, L, D, seed=3))
+    pr = torch.softmax(dev(rnd(T, B, L, seed=4)), -1).contiguous()
+    ref_g, ref_dm = g.clone(), torch.zeros(B, L, D, device="cuda")
+    for s in range(T):
+        sl = ref_g[:, s * W:(s + 1) * W]
+        if p > 0:
+            ops.dropout2d(sl, ops.Drop(p, 11, 300 + s), out=sl)
+        call("cst_dot_attn_bwd", sl[:, D:], T * W, q[:, s * W:s * W + D], T * W, mem, pr[s], sl[:, :D], T * W, 1, ref_dm, B, L, D)
+    got_g, got_dm = g.clone(), torch.zeros(B, L, D, device="cuda")
+    call("cst_dot_attn_bwd_steps", got_g, T * W, W, q, T * W, W, mem, pr, got_dm, B, T, L, D, *ops.Drop(p, 11, 300).args())
+    close(got_g.view(B, T, W)[:, :, :D], ref_g.view(B, T, W)[:, :, :D], 2e-5, 2e-6)
+    close(got_dm, ref_dm, 2e-5, 2e-5)
+
+
+@pytest.mark.parametrize("pair", [False, True])
+@pytest.mark.parametrize("B,H,K,splitk", [(5, 16, 64, 0), (256, 256, 256, 2), (256, 512, 640, 0)])
+def test_gemm_bf16_lstm_equals_gemm_plus_cell(ops, B, H, K, splitk, pair):
+    from consistent__style_transfer_amd._lib import call
+    np_ = 2 if pair else 1
+    probs, refs = [], []
+    for i in range(np_):
+        A, Wt = rnd(B, K, seed=10 + i, scale=0.3), rnd(4 * H, K, seed=20 + i, scale=0.3)
+        Ab, Wb = ops.cast_bf16(dev(A), want_t=False)[0], ops.cast_bf16(dev(Wt), want_t=False)[0]
+        bias, add, c_prev = dev(rnd(4 * H, seed=30 + i)), dev(rnd(B, 4 * H + 8, seed=40 + i)), dev(rnd(B, H, seed=50 + i))
+        # reference: the two-kernel path
+        g = torch.empty(B, 4 * H, device="cuda")
+        ops.gemm_bf16(Ab, Wb, B, 4 * H, C=g, bias=bias, addend=add[:, :4 * H])
+        h, c, h2 = (torch.empty(B, H, device="cuda") for _ in range(3))
+        hb = torch.zeros(B, H, device="cuda", dtype=torch.int16)
+        call("cst_lstm_cell_fwd", g, 4 * H, c_prev, H, h, H, c, H, h2, H, hb, H, None, 0, B, H)
+        refs.append((g, h, c, h2, hb))
+        probs.append(dict(Ab=Ab, Bb=Wb, gates=torch.empty(B, 4 * H, device="cuda"), c_prev=c_prev, h_out=torch.empty(B, H, device="cuda"),
+                          c_out=torch.empty(B, H, device="cuda"), h_out2=torch.empty(B, H, device="cuda"), bias=bias, addend=add[:, :4 * H],
+                          hb=torch.zeros(B, H, device="cuda", dtype=torch.int16)))
+    from consistent__style_transfer_amd import gen_fn
+    old = ops.LSTM_SPLITK
+    ops.LSTM_SPLITK = splitk
+    try:
+        gen_fn._gemm_cell_fwd(probs, B, H)
+    finally:
+        ops.LSTM_SPLITK = old
+    for pr, (g, h, c, h2, hb) in zip(probs, refs):
+        close(pr["gates"], g, 1e-5, 1e-5)
+        close(pr["h_out"], h, 1e-5, 1e-5)
+        close(pr["c_out"], c, 1e-5, 1e-5)
+        close(pr["h_out2"], h2, 1e-5, 1e-5)
+        close(pr["hb"].view(torch.bfloat16).float(), hb.view(torch.bfloat16).float(), 1e-2, 1e-2)
+
+
+@pytest.mark.parametrize("B,H,n_extra,pair", [(5, 16, 0, False), (256, 256, 0, True), (256, 512, 128, False)])
+def test_gemm_bf16_lstm_bwd_equals_gemm_plus_cell_bwd(ops, B, H, n_extra, pair):
+    from consistent__style_transfer_amd import gen_fn
+    from consistent__style_transfer_amd._lib import call
+    N, K = n_extra + H, 4 * H
+    probs, refs = [], []
+    for i in range(2 if pair else 1):
+        dgn, Wt = rnd(B, K, seed=60 + i, scale=0.3), rnd(N, K, seed=70 + i, scale=0.3)
+        Ab, Wb = ops.cast_bf16(dev(dgn), want_t=False)[0], ops.cast_bf16(dev(Wt), want_t=False)[0]
+        gates = torch.sigmoid(dev(rnd(B, 4 * H, seed=80 + i)))
+        c_prev, c_new, dh_x, dc_in = (dev(rnd(B, H, seed=90 + 4 * i + j)) for j in range(4))
+        full = torch.empty(B, N, device="cuda")
+        ops.gemm_bf16(Ab, Wb, B, N, C=full)
+        dg, dcp = torch.empty(B, 4 * H, device="cuda"), torch.empty(B, H, device="cuda")
+        dgb = torch.zeros(B, 4 * H, device="cuda", dtype=torch.int16)
+        dh = full[:, n_extra:].contiguous()
+        call("cst_lstm_cell_bwd", gates, 4 * H, c_prev, H, c_new, H, dh_x, H, dh, H, dc_in, H, dg, 4 * H, dcp, H, dgb, 4 * H, B, H)
+        refs.append((full, dg, dcp, dgb))
+        probs.append(dict(Ab=Ab, Bb=Wb, gates=gates, c_prev=c_prev, c_new=c_new, dh_extra=dh_x, dc_in=dc_in,
+                          dgates=torch.empty(B, 4 * H, device="cuda"), dc_prev=torch.empty(B, H, device="cuda"),
+                          dgb=torch.zeros(B, 4 * H, device="cuda", dtype=torch.int16), n_extra=n_extra,
+                          extra_out=torch.empty(B, n_extra + 4, device="cuda")[:, :n_extra] if n_extra else None))
+    gen_fn._gemm_cell_bwd(probs, B, H)
+    for pr, (full, dg, dcp, dgb) in zip(probs, refs):
+        close(pr["dgates"], dg, 2e-5, 2e-5)
+        close(pr["dc_prev"], dcp, 2e-5, 2e-5)
+        close(pr["dgb"].view(torch.bfloat16).float(), dgb.view(torch.bfloat16).float(), 1e-2, 1e-2)
+        if n_extra:
+            close(pr["extra_out"], full[:, :n_extra], 2e-5, 2e-5)
