@@ -75,15 +75,21 @@ def coins_tensor(step, L, device):
     return torch.tensor([int(c) for c in coins_for(step, L)], dtype=torch.int32).to(device, non_blocking=True)
 
 
+ONLY = None        # profiling aid (--only-stage): restrict the eager step to one stage
+
+
 def run_step(stages_, batches, it, reducer):
     """Eager step (used with --no-graph, for N > 1 and for the per-kernel timing leg)."""
     pre, wu, opt = stages_
     bp, bw, bo = batches[it % len(batches)]
     L = bw[1].shape[1]
     dev = bw[1].device
-    pre.train_step(bp, seed=3 * it, reducer=reducer)
-    wu.train_step(bw, coins=coins_tensor(2 * it, L, dev), seed=3 * it + 1, reducer=reducer)
-    opt.train_step(bo, it, coins=coins_tensor(2 * it + 1, L, dev), seed=3 * it + 2, reducer=reducer)
+    if ONLY in (None, "pretrain"):
+        pre.train_step(bp, seed=3 * it, reducer=reducer)
+    if ONLY in (None, "warmup"):
+        wu.train_step(bw, coins=coins_tensor(2 * it, L, dev), seed=3 * it + 1, reducer=reducer)
+    if ONLY in (None, "optimize"):
+        opt.train_step(bo, it, coins=coins_tensor(2 * it + 1, L, dev), seed=3 * it + 2, reducer=reducer)
 
 
 class GraphedPipeline:
@@ -174,6 +180,8 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-stage-split", action="store_true", help="skip the per-stage timing leg")
+    ap.add_argument("--only-stage", choices=["pretrain", "warmup", "optimize"], default=None,
+                    help="profiling aid: with --no-graph run only this stage's step (the JSON line is then NOT the benchmark metric)")
     ap.add_argument("--workload", default="yelp_4l_d512_b256", choices=sorted(WORKLOADS))
     ap.add_argument("--precision", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -190,6 +198,10 @@ def main():
     device = torch.device("cuda", local % torch.cuda.device_count())
     torch.cuda.set_device(device)
     ops.set_precision(args.precision)
+    global ONLY
+    ONLY = args.only_stage
+    if ONLY:
+        args.no_graph, args.no_stage_split, args.no_roofline, args.no_cpu_baseline = True, True, True, True
     w = WORKLOADS[args.workload]
     stages_ = build_stages(w, device)
     batches = make_batches(w, rank, device)

@@ -15,6 +15,7 @@ import bench  # noqa: E402
 from consistent__style_transfer_amd import _lib, ops  # noqa: E402
 
 w = bench.WORKLOADS[sys.argv[1] if len(sys.argv) > 1 else "yelp_4l_d512_b256"]
+bench.ONLY = sys.argv[2] if len(sys.argv) > 2 else None          # optional: one stage only
 dev = torch.device("cuda:0")
 stages_ = bench.build_stages(w, dev)
 batches = bench.make_batches(w, 0, dev)
