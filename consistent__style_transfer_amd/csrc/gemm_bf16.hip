@@ -153,6 +153,15 @@ __device__ __forceinline__ u32x4_t lds_read128(unsigned addr) {
     return v;
 }
 
+typedef __attribute__((ext_vector_type(2))) unsigned u32x2_t;
+__device__ __forceinline__ u32x2_t lds_read64_tr(unsigned addr) {
+    u32x2_t v;
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v) : "v"(addr) : "memory");
+    return v;
+}
+// byte offset of 16-byte chunk ch (0..15) of row `row` in the [64 k][128 x bf16] transposed-read image
+__device__ __forceinline__ int tlds_off(int row, int ch) { return row * 256 + 16 * (ch ^ (((row & 3) << 2) | ((row >> 2) & 3))); }
+
 __device__ __forceinline__ void bgemm_store(const BGemmArgs& g, uint32_t dseed, int m, int n, float acc) {
     float v = g.alpha * acc + (g.bias ? g.bias[n] : 0.f);
     if (g.addend) v += g.addend[(long)m * g.ldadd + n];
@@ -211,12 +220,19 @@ __device__ __forceinline__ void bgemm_store4(const BGemmArgs& g, uint32_t dseed,
     }
 }
 
-template <int BM, int BN, int NSTAGE>
+// TT = false: C = A B^T, A [M,K] and B [N,K] with K contiguous (row reads of the tile: ds_read_b128).
+// TT = true : C = A^T B, A [K,M] and B [K,N] with the CONTRACTION index as the row index (weight gradients
+//             dW = dY^T X straight from the row-major activations, no transposed copies in HBM): a k-tile is
+//             64 rows of 256 bytes and the MFMA fragments come from the hardware transposed read
+//             ds_read_b64_tr_b16 (4 rows x 16 columns per 16-lane group, delivered column-major), on the
+//             XOR image (b) of cdna_hip_programming.md T10.  128x128 tiles only.
+template <int BM, int BN, int NSTAGE, bool TT = false>
 __global__ __launch_bounds__(256) void cst_gemm_bf16_kernel(BGemmArgs g) {
     constexpr int A_BYTES = BM * BROW, B_BYTES = BN * BROW, ST_BYTES = A_BYTES + B_BYTES;
     constexpr int A_CH = BM / 8 / 4, B_CH = BN / 8 / 4;        // 1-KiB chunks (8 rows) per wave per tile
     constexpr int LOADS = A_CH + B_CH;                          // global_load_lds instructions per wave per tile
     constexpr int TM = BM / 32, TN = BN / 32;
+    static_assert(!TT || (BM == 128 && BN == 128), "the transposed-read image assumes 256-byte tile rows");
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tilesM = (g.M + BM - 1) / BM, tilesN = (g.N + BN - 1) / BN;
@@ -243,15 +259,34 @@ __global__ __launch_bounds__(256) void cst_gemm_bf16_kernel(BGemmArgs g) {
     const int lrow = lane >> 3, lps = lane & 7;
     const bf16_t* asrc[A_CH];
     const bf16_t* bsrc[B_CH];
+    if constexpr (!TT) {
 #pragma unroll
-    for (int c = 0; c < A_CH; ++c) {
-        const int r = (wave * A_CH + c) * 8 + lrow;
-        asrc[c] = (blockIdx.z ? g.A2 : g.A) + (long)min(m0 + r, g.M - 1) * g.lda + ((lps ^ (r & 7)) << 3);
-    }
+        for (int c = 0; c < A_CH; ++c) {
+            const int r = (wave * A_CH + c) * 8 + lrow;
+            asrc[c] = (blockIdx.z ? g.A2 : g.A) + (long)min(m0 + r, g.M - 1) * g.lda + ((lps ^ (r & 7)) << 3);
+        }
 #pragma unroll
-    for (int c = 0; c < B_CH; ++c) {
-        const int r = (wave * B_CH + c) * 8 + lrow;
-        bsrc[c] = (blockIdx.z ? g.B2 : g.B) + (long)min(n0 + r, g.N - 1) * g.ldb + ((lps ^ (r & 7)) << 3);
+        for (int c = 0; c < B_CH; ++c) {
+            const int r = (wave * B_CH + c) * 8 + lrow;
+            bsrc[c] = (blockIdx.z ? g.B2 : g.B) + (long)min(n0 + r, g.N - 1) * g.ldb + ((lps ^ (r & 7)) << 3);
+        }
+    } else {
+        // chunk ci = 4 k-rows of 256 bytes; lane l lands at (row 4 ci + l/16, physical 16-byte chunk l%16) and
+        // fetches logical chunk (l%16) ^ f(row), f(row) = ((row & 3) << 2) | ((row >> 2) & 3).  Column chunks
+        // past the matrix edge re-read the last whole chunk (their products are never stored).
+        const int tr = lane >> 4, pc = lane & 15;
+#pragma unroll
+        for (int c = 0; c < A_CH; ++c) {
+            const int r = (wave * A_CH + c) * 4 + tr;
+            const int lc = pc ^ (((r & 3) << 2) | ((r >> 2) & 3));
+            asrc[c] = g.A + (long)r * g.lda + min(m0 + lc * 8, g.M - 8);
+        }
+#pragma unroll
+        for (int c = 0; c < B_CH; ++c) {
+            const int r = (wave * B_CH + c) * 4 + tr;
+            const int lc = pc ^ (((r & 3) << 2) | ((r >> 2) & 3));
+            bsrc[c] = g.B + (long)r * g.ldb + min(n0 + lc * 8, g.N - 8);
+        }
     }
     const int kbeg = blockIdx.y * g.k_per_split;
     const int kend = min(g.K, kbeg + g.k_per_split);
@@ -260,12 +295,13 @@ __global__ __launch_bounds__(256) void cst_gemm_bf16_kernel(BGemmArgs g) {
     auto issue = [&](int t) {
         char* st = smem + (t % NSTAGE) * ST_BYTES;
         const int k = kbeg + t * BBK;
+        const long ka = TT ? (long)k * g.lda : k, kb = TT ? (long)k * g.ldb : k;     // TT: k advances rows
 #pragma unroll
         for (int c = 0; c < A_CH; ++c)
-            __builtin_amdgcn_global_load_lds((gbl_ptr_t)(asrc[c] + k), (lds_ptr_t)(st + (wave * A_CH + c) * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gbl_ptr_t)(asrc[c] + ka), (lds_ptr_t)(st + (wave * A_CH + c) * 1024), 16, 0, 0);
 #pragma unroll
         for (int c = 0; c < B_CH; ++c)
-            __builtin_amdgcn_global_load_lds((gbl_ptr_t)(bsrc[c] + k), (lds_ptr_t)(st + A_BYTES + (wave * B_CH + c) * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gbl_ptr_t)(bsrc[c] + kb), (lds_ptr_t)(st + A_BYTES + (wave * B_CH + c) * 1024), 16, 0, 0);
     };
 
     f32x4_t acc[TM][TN];
@@ -294,17 +330,42 @@ __global__ __launch_bounds__(256) void cst_gemm_bf16_kernel(BGemmArgs g) {
         if (t + NSTAGE - 1 < nk) issue(t + NSTAGE - 1);
         const unsigned As = lds_base + (t % NSTAGE) * ST_BYTES;
         const unsigned Bs = As + A_BYTES;
-        // both 32-wide k halves of the tile are requested before the first MFMA: one LDS round trip per
-        // tile instead of two (the second half's reads retire under the first half's MFMAs)
         u32x4_t af[2][TM], bfr[2][TN];
+        auto read_half = [&](int kk) {
+            if constexpr (!TT) {
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
+                for (int i = 0; i < TM; ++i) af[kk][i] = lds_read128(As + blds_off(wm * (BM / 2) + i * 16 + lr, kk * 4 + lq));
 #pragma unroll
-            for (int i = 0; i < TM; ++i) af[kk][i] = lds_read128(As + blds_off(wm * (BM / 2) + i * 16 + lr, kk * 4 + lq));
+                for (int j = 0; j < TN; ++j) bfr[kk][j] = lds_read128(Bs + blds_off(wn * (BN / 2) + j * 16 + lr, kk * 4 + lq));
+            } else {
+                // 16-lane group lq owns k = 32 kk + 8 lq .. + 7: two transposed 4-row blocks; lane 4q+p of the group
+                // supplies the address of block row q, columns 4p .. 4p+3 and receives column (lane % 16)
+                const int q4 = (lane & 15) >> 2, p4 = lane & 3;
 #pragma unroll
-            for (int j = 0; j < TN; ++j) bfr[kk][j] = lds_read128(Bs + blds_off(wn * (BN / 2) + j * 16 + lr, kk * 4 + lq));
+                for (int i = 0; i < TM; ++i) {
+                    const int c0 = (wm * (BM / 2) + i * 16) / 8 + (p4 >> 1);
+                    const u32x2_t lo = lds_read64_tr(As + tlds_off(kk * 32 + lq * 8 + q4, c0) + 8 * (p4 & 1));
+                    const u32x2_t hi = lds_read64_tr(As + tlds_off(kk * 32 + lq * 8 + 4 + q4, c0) + 8 * (p4 & 1));
+                    af[kk][i] = (u32x4_t){lo.x, lo.y, hi.x, hi.y};
+                }
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const int c0 = (wn * (BN / 2) + j * 16) / 8 + (p4 >> 1);
+                    const u32x2_t lo = lds_read64_tr(Bs + tlds_off(kk * 32 + lq * 8 + q4, c0) + 8 * (p4 & 1));
+                    const u32x2_t hi = lds_read64_tr(Bs + tlds_off(kk * 32 + lq * 8 + 4 + q4, c0) + 8 * (p4 & 1));
+                    bfr[kk][j] = (u32x4_t){lo.x, lo.y, hi.x, hi.y};
+                }
+            }
+        };
+        // NT: both 32-wide k halves are requested before the first MFMA (the second half's reads retire under
+        // the first half's MFMAs); TT issues twice as many (64-bit) reads, more than lgkmcnt can count: half by half
+        read_half(0);
+        if constexpr (!TT) {
+            read_half(1);
+            asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(TM + TN) : "memory");      // first half landed
+        } else {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
-        asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(TM + TN) : "memory");      // first half landed
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int i = 0; i < TM; ++i)
@@ -312,6 +373,7 @@ __global__ __launch_bounds__(256) void cst_gemm_bf16_kernel(BGemmArgs g) {
             for (int j = 0; j < TN; ++j)
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, af[0][i]),
                                                                     __builtin_bit_cast(bf16x8_t, bfr[0][j]), acc[i][j], 0, 0, 0);
+        if constexpr (TT) read_half(1);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -400,12 +462,12 @@ __global__ __launch_bounds__(256) void cst_gemm_bf16_reduce(BGemmArgs g) {
 extern bool cst_prof_on();
 extern void cst_prof_push(hipEvent_t a, hipEvent_t b, double flops, double bytes, int which);
 
-template <int BM, int BN, int NSTAGE>
+template <int BM, int BN, int NSTAGE, bool TT = false>
 static int bgemm_launch(const BGemmArgs& g, hipStream_t st) {
     const size_t lds = (size_t)NSTAGE * (BM + BN) * BROW;
     static bool attr_done = false;
     if (!attr_done && lds > 64 * 1024) {
-        (void)hipFuncSetAttribute((const void*)cst_gemm_bf16_kernel<BM, BN, NSTAGE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)cst_gemm_bf16_kernel<BM, BN, NSTAGE, TT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_done = true;
     }
     dim3 grid(cst_div_up(g.M, BM) * cst_div_up(g.N, BN), g.splits, g.A2 ? 2 : 1), block(256);
@@ -413,9 +475,9 @@ static int bgemm_launch(const BGemmArgs& g, hipStream_t st) {
         hipEvent_t ea, eb;
         (void)hipEventCreate(&ea); (void)hipEventCreate(&eb);
         cst_prof_push(ea, eb, 2.0 * g.M * g.N * g.K, 2.0 * ((double)g.M * g.K + (double)g.N * g.K) + (g.C ? 4.0 : 0.0) * g.M * g.N + (g.Cb ? 2.0 : 0.0) * g.M * g.N, 1);
-        hipExtLaunchKernelGGL((cst_gemm_bf16_kernel<BM, BN, NSTAGE>), grid, block, lds, st, ea, eb, 0, g);
+        hipExtLaunchKernelGGL((cst_gemm_bf16_kernel<BM, BN, NSTAGE, TT>), grid, block, lds, st, ea, eb, 0, g);
     } else {
-        hipLaunchKernelGGL((cst_gemm_bf16_kernel<BM, BN, NSTAGE>), grid, block, lds, st, g);
+        hipLaunchKernelGGL((cst_gemm_bf16_kernel<BM, BN, NSTAGE, TT>), grid, block, lds, st, g);
     }
     return 0;
 }
@@ -473,6 +535,48 @@ extern "C" int cst_gemm_bf16(const void* A, long lda, const void* B, long ldb,
     CST_LAUNCH_CHECK("cst_gemm_bf16");
     if (splits > 1) {
         long mn = ((long)M * N + 3) / 4;          // four columns per thread on the vector path
+        int rb = (int)((mn + 255) / 256); if (rb > 2048) rb = 2048;
+        hipLaunchKernelGGL(cst_gemm_bf16_reduce, dim3(rb), dim3(256), 0, st, g);
+        CST_LAUNCH_CHECK("cst_gemm_bf16_reduce");
+    }
+    return CST_OK;
+}
+
+extern "C" int cst_gemm_bf16_tt(const void* A, long lda, const void* B, long ldb, float* C, long ldc, int M, int N, int K,
+                                int accumulate, int splitk, float* workspace, long workspace_floats, void* stream) {
+    CST_REQUIRE(A && B && C, "cst_gemm_bf16_tt: null operand");
+    CST_REQUIRE(M >= 8 && N >= 8 && M % 8 == 0 && N % 8 == 0 && K > 0 && K % 64 == 0,
+                "cst_gemm_bf16_tt: M=%d, N=%d must be multiples of 8 and K=%d a multiple of 64", M, N, K);
+    CST_REQUIRE(lda >= M && ldb >= N && lda % 8 == 0 && ldb % 8 == 0 && ldc >= N && (((uintptr_t)A | (uintptr_t)B) & 15) == 0,
+                "cst_gemm_bf16_tt: operands must be 16-byte aligned, leading dimensions multiples of 8");
+    BGemmArgs g;
+    g.A = (const bf16_t*)A; g.B = (const bf16_t*)B; g.A2 = nullptr; g.B2 = nullptr; g.C = C; g.Cb = nullptr;
+    g.bias = nullptr; g.addend = nullptr; g.aux = nullptr;
+    g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.ldcb = 0; g.ldadd = 0; g.ldaux = 0;
+    g.M = M; g.N = N; g.K = K; g.act = 0; g.alpha = 1.f; g.gate_scale = 1.f; g.accumulate = accumulate;
+    g.slab_only = 0;
+    g.drop = cst_make_drop(0.f, 0, 0, nullptr);
+    const long tiles = (long)cst_div_up(M, 128) * cst_div_up(N, 128);
+    int splits = 1;
+    if (splitk > 1) splits = splitk;
+    else if (splitk == 0 && workspace && tiles < 192 && K >= 512) {
+        splits = (int)((384 + tiles - 1) / tiles);
+        if (splits > K / 256) splits = K / 256;
+    }
+    int kps = K;
+    if (splits > 1) {
+        kps = cst_div_up(cst_div_up(K, splits), 64) * 64;
+        splits = cst_div_up(K, kps);
+        while (splits > 1 && (long)splits * M * N > workspace_floats) { kps += 64; splits = cst_div_up(K, kps); }
+    }
+    if (splits <= 1) { splits = 1; kps = K; }
+    CST_REQUIRE(splits == 1 || workspace, "cst_gemm_bf16_tt: split-K needs a workspace");
+    g.splits = splits; g.k_per_split = kps; g.slab = workspace;
+    hipStream_t st = (hipStream_t)stream;
+    bgemm_launch<128, 128, 2, true>(g, st);
+    CST_LAUNCH_CHECK("cst_gemm_bf16_tt");
+    if (splits > 1) {
+        long mn = ((long)M * N + 3) / 4;
         int rb = (int)((mn + 255) / 256); if (rb > 2048) rb = 2048;
         hipLaunchKernelGGL(cst_gemm_bf16_reduce, dim3(rb), dim3(256), 0, st, g);
         CST_LAUNCH_CHECK("cst_gemm_bf16_reduce");

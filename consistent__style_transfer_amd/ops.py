@@ -172,6 +172,17 @@ def gemm_bf16(Ab, Bb, M, N, C=None, Cb=None, bias=None, addend=None, aux=None, a
     return C if C is not None else Cb
 
 
+def gemm_bf16_tt(Ab, Bb, M, N, C=None, accumulate=False, splitk=0):
+    """C[M,N] (+)= Ab[K,M]^T Bb[K,N]: bf16 operands whose ROW index is the contraction (token) index."""
+    K = Ab.shape[0]
+    assert Bb.shape[0] == K and Ab.dtype == torch.int16 and Bb.dtype == torch.int16
+    if C is None:
+        C = torch.empty(M, N, device=Ab.device, dtype=torch.float32)
+    call("cst_gemm_bf16_tt", Ab, Ab.stride(0), Bb, Bb.stride(0), C, _ld(C), M, N, K, int(accumulate), splitk,
+         _workspace(Ab.device), WS_FLOATS)
+    return C
+
+
 def colsum_bf16(xb, N):
     out = torch.empty(N, device=xb.device, dtype=torch.float32)
     call("cst_colsum_bf16", xb, xb.stride(0), xb.shape[0], N, out)
@@ -417,11 +428,13 @@ class EncoderLayerFn(torch.autograd.Function):
 
 
 class EncoderLayerBf16Fn(torch.autograd.Function):
-    """The same layer as EncoderLayerFn on the bf16-operand NT GEMM (cst_gemm_bf16, direct-to-LDS
-    ring).  Every GEMM operand is a bf16 copy with K contiguous: activations and weights are cast
-    once (row-major copy for forward / dgrad, transposed copy for dgrad (weights) and wgrad
-    (activations)); the FFN hidden state and its gradient exist ONLY in bf16.  Residual stream,
-    LayerNorm, attention core and all accumulation stay fp32."""
+    """The same layer as EncoderLayerFn on the bf16-operand GEMMs (cst_gemm_bf16 / cst_gemm_bf16_tt, direct-to-LDS
+    ring).  Forward and dgrad products read K-contiguous bf16 copies (activations cast once, weights cached per
+    optimizer version, transposed weight copies for dgrad); the weight gradients dW = dY^T X read the SAME
+    row-major activation copies through the transposed-LDS-read variant, so no activation is ever transposed
+    in HBM (token counts that are not multiples of 64 -- toy shapes -- keep the transposed-copy path).  The FFN
+    hidden state and its gradient exist ONLY in bf16.  Residual stream, LayerNorm, attention core and all
+    accumulation stay fp32."""
 
     @staticmethod
     def forward(ctx, x, in_w, in_b, out_w, out_b, l1_w, l1_b, l2_w, l2_b, n1_w, n1_b, n2_w, n2_b,
@@ -430,62 +443,73 @@ class EncoderLayerBf16Fn(torch.autograd.Function):
         F = l1_w.shape[0]
         dev = x.device
         sb = STREAM_TFM + 10 * layer
-        wg = in_w.requires_grad                       # frozen critics: no transposed activation copies needed
+        wg = in_w.requires_grad                       # frozen critics: no operands kept for weight gradients
+        tt = wg and T % 64 == 0 and d % 8 == 0 and F % 8 == 0
+        want_t = wg and not tt
         new = lambda *s: torch.empty(*s, device=dev, dtype=torch.float32)
-        xb, xt = cast_bf16(x, want_t=wg)
+        xb, xt = cast_bf16(x, want_t=want_t)
         inw_b, inw_t = weight_bf16(in_w)
         qkv = gemm_bf16(xb, inw_b, T, 3 * d, C=new(T, 3 * d), bias=in_b)
         att, lse = new(T, d), new(B * H * S)
         call("cst_mha_fwd", qkv, att, lse, B, S, H, d // H, *drop.at(sb + 0).args())
-        attb, attt = cast_bf16(att, want_t=wg)
+        attb, attt = cast_bf16(att, want_t=want_t)
         outw_b, outw_t = weight_bf16(out_w)
         z1 = gemm_bf16(attb, outw_b, T, d, C=new(T, d), bias=out_b)
         y1, m1, r1 = new(T, d), new(T), new(T)
         _ln_fwd(z1, x, n1_w, n1_b, drop.at(sb + 1), z1, y1, m1, r1)
-        y1b, y1t = cast_bf16(y1, want_t=wg)
+        y1b, y1t = cast_bf16(y1, want_t=want_t)
         l1_b16, l1_t = weight_bf16(l1_w)
         Fp = _up64(F)
         hb = (torch.zeros if Fp != F else torch.empty)(T, Fp, device=dev, dtype=torch.int16)
         gemm_bf16(y1b, l1_b16, T, F, Cb=hb, bias=l1_b, act=1, drop=drop.at(sb + 2))
-        ht = cast_bf16(hb[:, :F], want_rm=False)[1] if wg else None
+        ht = cast_bf16(hb[:, :F], want_rm=False)[1] if want_t else None
         l2_b16, l2_t = weight_bf16(l2_w)
         z2 = gemm_bf16(hb, l2_b16, T, d, C=new(T, d), bias=l2_b)
         y2, m2, r2 = new(T, d), new(T), new(T)
         _ln_fwd(z2, y1, n2_w, n2_b, drop.at(sb + 3), z2, y2, m2, r2)
-        ctx.save_for_backward(xt, attt, y1t, ht, hb, inw_t, outw_t, l1_t, l2_t, n1_w, n2_w, qkv, lse, z1, m1, r1, z2, m2, r2)
-        ctx.cfg = (B, S, H, drop, sb, T, d, F, wg)
+        # operands of the weight gradients: row-major copies (tt) or transposed copies
+        wx, watt, wy1, wh = (xb, attb, y1b, hb) if tt else (xt, attt, y1t, ht)
+        ctx.save_for_backward(wx, watt, wy1, wh, hb, inw_t, outw_t, l1_t, l2_t, n1_w, n2_w, qkv, lse, z1, m1, r1, z2, m2, r2)
+        ctx.cfg = (B, S, H, drop, sb, T, d, F, wg, tt)
         return y2
 
     @staticmethod
     def backward(ctx, dy2):
-        xt, attt, y1t, ht, hb, inw_t, outw_t, l1_t, l2_t, n1_w, n2_w, qkv, lse, z1, m1, r1, z2, m2, r2 = ctx.saved_tensors
-        B, S, H, drop, sb, T, d, F, wg = ctx.cfg
+        wx, watt, wy1, wh, hb, inw_t, outw_t, l1_t, l2_t, n1_w, n2_w, qkv, lse, z1, m1, r1, z2, m2, r2 = ctx.saved_tensors
+        B, S, H, drop, sb, T, d, F, wg, tt = ctx.cfg
         dev = dy2.device
+        want_t = wg and not tt
         new = lambda *s: torch.empty(*s, device=dev, dtype=torch.float32)
         dy2 = dy2.contiguous()
         dz2, dn2w, dn2b = _ln_bwd(dy2, z2, m2, r2, n2_w, wg)
-        dfb, dft = cast_bf16(dz2, want_t=wg, drop=drop.at(sb + 3))                      # dropout2' fused into the cast
+        dfb, dft = cast_bf16(dz2, want_t=want_t, drop=drop.at(sb + 3))                  # dropout2' fused into the cast
         Fp = _up64(F)
         dhb = (torch.zeros if Fp != F else torch.empty)(T, Fp, device=dev, dtype=torch.int16)
         gemm_bf16(dfb, l2_t, T, F, Cb=dhb, aux=hb, act=3, gate_scale=drop.scale)       # relu' and dropout' fused
         dy1 = gemm_bf16(dhb, l1_t, T, d, C=new(T, d), addend=dz2)
         dz1, dn1w, dn1b = _ln_bwd(dy1, z1, m1, r1, n1_w, wg)
-        dob, dot = cast_bf16(dz1, want_t=wg, drop=drop.at(sb + 1))
+        dob, dot = cast_bf16(dz1, want_t=want_t, drop=drop.at(sb + 1))
         datt = gemm_bf16(dob, outw_t, T, d, C=new(T, d))
         dqkv = torch.empty_like(qkv)
         call("cst_mha_bwd", qkv, datt, lse, dqkv, B, S, H, d // H, *drop.at(sb + 0).args())
-        dqb, dqt = cast_bf16(dqkv, want_t=wg)
+        dqb, dqt = cast_bf16(dqkv, want_t=want_t)
         dx = gemm_bf16(dqb, inw_t, T, d, C=new(T, d), addend=dz1) if ctx.needs_input_grad[0] else None
         dinw = dinb = doutw = doutb = dl1w = dl1b = dl2w = dl2b = None
         if wg:
-            dht = cast_bf16(dhb[:, :F], want_rm=False)[1]
-            dl2w = gemm_bf16(dft, ht, d, F, C=new(d, F))
+            if tt:                                        # dW = dY^T X from the row-major copies
+                dl2w = gemm_bf16_tt(dfb, wh, d, F)
+                dl1w = gemm_bf16_tt(dhb, wy1, F, d)
+                doutw = gemm_bf16_tt(dob, watt, d, d)
+                dinw = gemm_bf16_tt(dqb, wx, 3 * d, d)
+            else:
+                dht = cast_bf16(dhb[:, :F], want_rm=False)[1]
+                dl2w = gemm_bf16(dft, wh, d, F, C=new(d, F))
+                dl1w = gemm_bf16(dht, wy1, F, d, C=new(F, d))
+                doutw = gemm_bf16(dot, watt, d, d, C=new(d, d))
+                dinw = gemm_bf16(dqt, wx, 3 * d, d, C=new(3 * d, d))
             dl2b = colsum_bf16(dfb, d) if drop.p > 0 else colsum(dz2)
-            dl1w = gemm_bf16(dht, y1t, F, d, C=new(F, d))
             dl1b = colsum_bf16(dhb, F)
-            doutw = gemm_bf16(dot, attt, d, d, C=new(d, d))
             doutb = colsum_bf16(dob, d) if drop.p > 0 else colsum(dz1)
-            dinw = gemm_bf16(dqt, xt, 3 * d, d, C=new(3 * d, d))
             dinb = colsum(dqkv)
         return (dx, dinw, dinb, doutw, doutb, dl1w, dl1b, dl2w, dl2b, dn1w, dn1b, dn2w, dn2b,
                 None, None, None, None, None)

@@ -158,6 +158,13 @@ int cst_dot_attn_bwd_steps(float* diffn, long ldrow, long gstep, const float* q,
 int cst_lstm_cell_fwd(float* gates, long ldg, const float* c_prev, long ldcp, float* h_out, long ldh,
                       float* c_out, long ldc, float* h_out2, long ldh2,
                       void* h_bf16, long ldhb, void* h_bf16_2, long ldhb2, int B, int H, void* stream);
+/* C[M,N] (+)= A^T B with A [K,M] and B [K,N] bf16, the CONTRACTION index being the row index of both: the weight
+ * gradients dW = dY^T X of every Linear on the path (backward of mlm.py:20-24, match.py:18-22) straight from the
+ * row-major bf16 activations, no transposed copies.  M, N multiples of 8, K a multiple of 64 (token count);
+ * split-K as cst_gemm_bf16. */
+int cst_gemm_bf16_tt(const void* A, long lda, const void* B, long ldb, float* C, long ldc, int M, int N, int K,
+                     int accumulate, int splitk, float* workspace, long workspace_floats, void* stream);
+
 /* One recurrent step of nn.LSTM (rnn.py:25-33, called at rnn.py:57 and :75) in two launches, for one problem
  * or for two independent problems of one shape (the *2 / *_p2 arguments; A2 == NULL: single) -- the two
  * directions of the bidirectional encoder share every dimension and leading dimension.

@@ -567,3 +567,19 @@ def test_gemm_bf16_lstm_bwd_equals_gemm_plus_cell_bwd(ops, B, H, n_extra, pair):
         close(pr["dgb"].view(torch.bfloat16).float(), dgb.view(torch.bfloat16).float(), 1e-2, 1e-2)
         if n_extra:
             close(pr["extra_out"], full[:, :n_extra], 2e-5, 2e-5)
+
+
+@pytest.mark.parametrize("K,M,N,splitk", [(64, 8, 8, 1), (128, 200, 136, 1), (4608, 512, 2048, 0), (9216, 1536, 512, 0),
+                                          (4608, 512, 512, 4), (1024, 2048, 512, 1)])
+def test_gemm_bf16_tt(ops, K, M, N, splitk):
+    """C = A^T B from operands whose row index is the contraction index (hardware transposed LDS reads)."""
+    A, Bm = rnd(K, M, seed=1, scale=0.5), rnd(K, N, seed=2, scale=0.5)
+    Ab, Bb = ops.cast_bf16(dev(A), want_t=False)[0], ops.cast_bf16(dev(Bm), want_t=False)[0]
+    Af = Ab.view(torch.bfloat16).float()[:, :M].cpu().double()
+    Bf = Bb.view(torch.bfloat16).float()[:, :N].cpu().double()
+    ref = (Af.T @ Bf).float()
+    got = ops.gemm_bf16_tt(Ab, Bb, M, N, splitk=splitk)
+    close(got, ref, 2e-4, 2e-4 * math.sqrt(K))
+    acc = torch.ones(M, N, device="cuda")
+    ops.gemm_bf16_tt(Ab, Bb, M, N, C=acc, accumulate=True, splitk=splitk)
+    close(acc, 1 + ref, 2e-4, 2e-4 * math.sqrt(K))
