@@ -583,3 +583,27 @@ def test_gemm_bf16_tt(ops, K, M, N, splitk):
     acc = torch.ones(M, N, device="cuda")
     ops.gemm_bf16_tt(Ab, Bb, M, N, C=acc, accumulate=True, splitk=splitk)
     close(acc, 1 + ref, 2e-4, 2e-4 * math.sqrt(K))
+
+
+def test_encoder_layer_bf16_tt_weight_grads_match_exact_mode(ops):
+    """Token count % 64 == 0 switches the bf16 encoder layer to the transposed-read weight-gradient GEMM; its
+    gradients must agree with the exact-fp32 layer to bf16 accuracy (relative Frobenius error)."""
+    from consistent__style_transfer_amd.model._common import EncoderLayerParams
+    B, S, d, H, F = 4, 16, 64, 4, 128
+    torch.manual_seed(3)
+    lay = EncoderLayerParams(d, F).cuda()
+    x0 = dev(rnd(B * S, d, seed=5))
+    w = dev(rnd(B * S, d, seed=6))
+    res = {}
+    for mode, fn in (("f32", ops.EncoderLayerFn), ("bf16", ops.EncoderLayerBf16Fn)):
+        ops.set_precision(mode)
+        for p in lay.parameters():
+            p.grad = None
+        x = x0.clone().requires_grad_(True)
+        y = fn.apply(x, *lay.flat(), B, S, H, ops.NO_DROP, 0)
+        (y * w).sum().backward()
+        res[mode] = [y.detach(), x.grad] + [p.grad.clone() for p in lay.parameters()]
+    ops.set_precision("bf16")
+    for a, b in zip(res["bf16"], res["f32"]):
+        err = (a - b).norm() / (b.norm() + 1e-12)
+        assert err < 3e-2, float(err)
