@@ -40,7 +40,8 @@ __host__ __device__ inline size_t mha_fwd_lds_floats(int S, int hd) {
 
 template <int HD, int ST>
 __global__ __launch_bounds__(MHA_NW * 64) void mha_fwd_kernel(const float* __restrict__ qkv, float* __restrict__ out,
-                                                             float* __restrict__ lse, int S, int H, float scale, CstDrop drop) {
+                                                             float* __restrict__ lse, int S, int H, float scale, CstDrop drop,
+                                                             unsigned short* __restrict__ outb, long ldob) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int HD4 = HD / 4, HDS = HD + 4, SEG = HD / 4, NT = (HD + 15) / 16;
     constexpr int SP = ST * 16, SS = SP + 4, KSEG = SP / 4, NTHR = MHA_NW * 64;
@@ -165,15 +166,31 @@ __global__ __launch_bounds__(MHA_NW * 64) void mha_fwd_kernel(const float* __res
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int mrow = mt * 16 + lq * 4 + r;
-                if (mrow < S && n < HD) ob[(long)mrow * d + n] = acc[q][r];
+                if (mrow < S && n < HD) {
+                    ob[(long)mrow * d + n] = acc[q][r];
+                    if (outb) {                                   // A operand of the out-projection
+                        __bf16 hh = (__bf16)acc[q][r];
+                        outb[((long)b * S + mrow) * ldob + h * HD + n] = __builtin_bit_cast(unsigned short, hh);
+                    }
+                }
             }
         }
     }
 }
 
+extern "C" int cst_mha_fwd_b(const float* qkv, float* out, float* lse, int B, int S, int H, int hd,
+                             float drop_p, uint32_t drop_seed, uint32_t drop_stream, const void* drop_seed_dev,
+                             void* out_bf16, long ldob, void* stream);
 extern "C" int cst_mha_fwd(const float* qkv, float* out, float* lse, int B, int S, int H, int hd,
                            float drop_p, uint32_t drop_seed, uint32_t drop_stream, const void* drop_seed_dev,
                            void* stream) {
+    return cst_mha_fwd_b(qkv, out, lse, B, S, H, hd, drop_p, drop_seed, drop_stream, drop_seed_dev, nullptr, 0, stream);
+}
+
+extern "C" int cst_mha_fwd_b(const float* qkv, float* out, float* lse, int B, int S, int H, int hd,
+                             float drop_p, uint32_t drop_seed, uint32_t drop_stream, const void* drop_seed_dev,
+                             void* out_bf16, long ldob, void* stream) {
+    CST_REQUIRE(!out_bf16 || ldob >= (long)H * hd, "cst_mha_fwd: bf16 leading dimension < d");
     CST_REQUIRE(qkv && out && lse, "cst_mha_fwd: null pointer");
     CST_REQUIRE(B > 0 && S > 0 && S <= MHA_SMAX && H > 0, "cst_mha_fwd: S=%d unsupported (max %d)", S, MHA_SMAX);
     CST_REQUIRE(((uintptr_t)qkv & 15) == 0, "cst_mha_fwd: qkv must be 16-byte aligned");
@@ -186,7 +203,7 @@ extern "C" int cst_mha_fwd(const float* qkv, float* out, float* lse, int B, int 
 #define MHA_FWD_LAUNCH(HDV, STV)                                                                                  \
     {                                                                                                             \
         if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)mha_fwd_kernel<HDV, STV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-        hipLaunchKernelGGL((mha_fwd_kernel<HDV, STV>), grid, block, lds, st, qkv, out, lse, S, H, scale, dr);     \
+        hipLaunchKernelGGL((mha_fwd_kernel<HDV, STV>), grid, block, lds, st, qkv, out, lse, S, H, scale, dr, (unsigned short*)out_bf16, ldob); \
     }
 #define MHA_FWD_CASE(HDV)                                                                                         \
     case HDV: {                                                                                                   \
@@ -231,7 +248,8 @@ __host__ __device__ inline size_t mha_bwd_lds_floats(int S, int hd) {
 template <int HD, int ST>
 __global__ __launch_bounds__(MHA_NW * 64) void mha_bwd_kernel(const float* __restrict__ qkv, const float* __restrict__ dout,
                                                       const float* __restrict__ lse, float* __restrict__ dqkv,
-                                                      int S, int H, float scale, CstDrop drop) {
+                                                      int S, int H, float scale, CstDrop drop,
+                                                      unsigned short* __restrict__ dqkvb, long lddb) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int HD4 = HD / 4, HDS = HD + 4, SEG = HD / 4, NT = (HD + 15) / 16;
     constexpr int SP = ST * 16, SS = SP + 4, KSEG = SP / 4;     // ST = ceil(S / 16): every loop below unrolls
@@ -391,16 +409,34 @@ __global__ __launch_bounds__(MHA_NW * 64) void mha_bwd_kernel(const float* __res
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int m = mt * 16 + lq * 4 + r;
-                if (m < S && n < HD) dq[(long)m * 3 * d + which * d + n] = acc[q][r];
+                if (m < S && n < HD) {
+                    dq[(long)m * 3 * d + which * d + n] = acc[q][r];
+                    if (dqkvb) {                                  // A operand of the in-projection dgrad / weight gradient
+                        __bf16 hh = (__bf16)acc[q][r];
+                        dqkvb[((long)b * S + m) * lddb + which * d + h * HD + n] = __builtin_bit_cast(unsigned short, hh);
+                    }
+                }
             }
         }
     }
 }
 
+extern "C" int cst_mha_bwd_b(const float* qkv, const float* dout, const float* lse, float* dqkv,
+                             int B, int S, int H, int hd,
+                             float drop_p, uint32_t drop_seed, uint32_t drop_stream, const void* drop_seed_dev,
+                             void* dqkv_bf16, long lddb, void* stream);
 extern "C" int cst_mha_bwd(const float* qkv, const float* dout, const float* lse, float* dqkv,
                            int B, int S, int H, int hd,
                            float drop_p, uint32_t drop_seed, uint32_t drop_stream, const void* drop_seed_dev,
                            void* stream) {
+    return cst_mha_bwd_b(qkv, dout, lse, dqkv, B, S, H, hd, drop_p, drop_seed, drop_stream, drop_seed_dev, nullptr, 0, stream);
+}
+
+extern "C" int cst_mha_bwd_b(const float* qkv, const float* dout, const float* lse, float* dqkv,
+                             int B, int S, int H, int hd,
+                             float drop_p, uint32_t drop_seed, uint32_t drop_stream, const void* drop_seed_dev,
+                             void* dqkv_bf16, long lddb, void* stream) {
+    CST_REQUIRE(!dqkv_bf16 || lddb >= 3L * H * hd, "cst_mha_bwd: bf16 leading dimension < 3d");
     CST_REQUIRE(qkv && dout && lse && dqkv, "cst_mha_bwd: null pointer");
     CST_REQUIRE(B > 0 && S > 0 && S <= MHA_SMAX && H > 0, "cst_mha_bwd: S=%d unsupported (max %d)", S, MHA_SMAX);
     CST_REQUIRE((((uintptr_t)qkv | (uintptr_t)dout) & 15) == 0, "cst_mha_bwd: qkv / dout must be 16-byte aligned");
@@ -413,7 +449,7 @@ extern "C" int cst_mha_bwd(const float* qkv, const float* dout, const float* lse
 #define MHA_BWD_LAUNCH(HDV, STV)                                                                                  \
     {                                                                                                             \
         if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)mha_bwd_kernel<HDV, STV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-        hipLaunchKernelGGL((mha_bwd_kernel<HDV, STV>), grid, block, lds, st, qkv, dout, lse, dqkv, S, H, scale, dr); \
+        hipLaunchKernelGGL((mha_bwd_kernel<HDV, STV>), grid, block, lds, st, qkv, dout, lse, dqkv, S, H, scale, dr, (unsigned short*)dqkv_bf16, lddb); \
     }
 #define MHA_BWD_CASE(HDV)                                                                                         \
     case HDV: {                                                                                                   \

@@ -434,7 +434,8 @@ __global__ __launch_bounds__(256) void add_layernorm_fwd_kernel(const float* __r
                                                                 const float* __restrict__ gamma, const float* __restrict__ beta,
                                                                 float eps, float* z, float* __restrict__ y,
                                                                 float* __restrict__ mean, float* __restrict__ rstd,
-                                                                int T, int d, CstDrop drop) {
+                                                                int T, int d, CstDrop drop,
+                                                                unsigned short* __restrict__ yb, long ldyb) {
     const int lane = threadIdx.x & 63;
     const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= T) return;
@@ -467,23 +468,34 @@ __global__ __launch_bounds__(256) void add_layernorm_fwd_kernel(const float* __r
         const int c = lane + 64 * i;
         if (c < d) {
             if (z) z[row * d + c] = v[i];
-            y[row * d + c] = (v[i] - mu) * rs * gamma[c] + beta[c];
+            const float yv = (v[i] - mu) * rs * gamma[c] + beta[c];
+            y[row * d + c] = yv;
+            if (yb) { __bf16 h = (__bf16)yv; yb[row * ldyb + c] = __builtin_bit_cast(unsigned short, h); }   // next GEMM's A operand
         }
     }
     if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
+}
+
+extern "C" int cst_add_layernorm_fwd_b(const float* x, const float* res, const float* gamma, const float* beta, float eps,
+                                       float* z, float* y, float* mean, float* rstd, int T, int d,
+                                       float drop_p, uint32_t drop_seed, uint32_t drop_stream, const void* drop_seed_dev,
+                                       void* y_bf16, long ldyb, void* stream) {
+    CST_REQUIRE(x && gamma && beta && y && mean && rstd, "cst_add_layernorm_fwd: null pointer");
+    CST_REQUIRE(T > 0 && d > 0 && d <= 64 * LN_MAXE, "cst_add_layernorm_fwd: d=%d unsupported (max %d)", d, 64 * LN_MAXE);
+    CST_REQUIRE(!y_bf16 || ldyb >= d, "cst_add_layernorm_fwd: bf16 leading dimension < d");
+    CstDrop dr = cst_make_drop(drop_p, drop_seed, drop_stream, drop_seed_dev);
+    hipLaunchKernelGGL(add_layernorm_fwd_kernel, dim3(cst_div_up(T, 4)), dim3(256), 0, (hipStream_t)stream,
+                       x, res, gamma, beta, eps, z, y, mean, rstd, T, d, dr, (unsigned short*)y_bf16, ldyb);
+    CST_LAUNCH_CHECK("cst_add_layernorm_fwd");
+    return CST_OK;
 }
 
 extern "C" int cst_add_layernorm_fwd(const float* x, const float* res, const float* gamma, const float* beta, float eps,
                                      float* z, float* y, float* mean, float* rstd, int T, int d,
                                      float drop_p, uint32_t drop_seed, uint32_t drop_stream, const void* drop_seed_dev,
                                      void* stream) {
-    CST_REQUIRE(x && gamma && beta && y && mean && rstd, "cst_add_layernorm_fwd: null pointer");
-    CST_REQUIRE(T > 0 && d > 0 && d <= 64 * LN_MAXE, "cst_add_layernorm_fwd: d=%d unsupported (max %d)", d, 64 * LN_MAXE);
-    CstDrop dr = cst_make_drop(drop_p, drop_seed, drop_stream, drop_seed_dev);
-    hipLaunchKernelGGL(add_layernorm_fwd_kernel, dim3(cst_div_up(T, 4)), dim3(256), 0, (hipStream_t)stream,
-                       x, res, gamma, beta, eps, z, y, mean, rstd, T, d, dr);
-    CST_LAUNCH_CHECK("cst_add_layernorm_fwd");
-    return CST_OK;
+    return cst_add_layernorm_fwd_b(x, res, gamma, beta, eps, z, y, mean, rstd, T, d, drop_p, drop_seed, drop_stream, drop_seed_dev,
+                                   nullptr, 0, stream);
 }
 
 // backward: dz = rstd * (g - mean(g) - xhat * mean(g * xhat)), g = dy * gamma;
@@ -491,13 +503,15 @@ extern "C" int cst_add_layernorm_fwd(const float* x, const float* res, const flo
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ z,
                                                             const float* __restrict__ mean, const float* __restrict__ rstd,
                                                             const float* __restrict__ gamma, float* dz,
-                                                            float* __restrict__ part, int T, int d, int rows_per_block) {
+                                                            float* __restrict__ part, int T, int d, int rows_per_block,
+                                                            unsigned short* __restrict__ dzb, long lddzb, CstDrop bdrop) {
     __shared__ float sh[2][4][64 * LN_MAXE / 4];      // only used for d <= 256 per pass; see loop below
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     float ag[LN_MAXE], ab[LN_MAXE];
 #pragma unroll
     for (int i = 0; i < LN_MAXE; ++i) { ag[i] = 0.f; ab[i] = 0.f; }
     const long r0 = (long)blockIdx.x * rows_per_block;
+    const uint32_t bseed = (dzb && bdrop.p > 0.f) ? cst_drop_seed(bdrop) : 0u;
     for (long row = r0 + w; row < r0 + rows_per_block && row < T; row += 4) {
         const float mu = mean[row], rs = rstd[row];
         float xh[LN_MAXE], g[LN_MAXE];
@@ -517,7 +531,16 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
 #pragma unroll
         for (int i = 0; i < LN_MAXE; ++i) {
             const int c = lane + 64 * i;
-            if (c < d) dz[row * d + c] = rs * (g[i] - s1 - xh[i] * s2);
+            if (c < d) {
+                const float dv = rs * (g[i] - s1 - xh[i] * s2);
+                dz[row * d + c] = dv;
+                if (dzb) {          // dropout'(dz) in bf16: A operand of the dgrad / weight-gradient GEMMs behind this LayerNorm
+                    float t = dv;
+                    if (bdrop.p > 0.f) t *= cst_drop_mask(bdrop, bseed, (uint32_t)(row * d + c));
+                    __bf16 h = (__bf16)t;
+                    dzb[row * lddzb + c] = __builtin_bit_cast(unsigned short, h);
+                }
+            }
         }
     }
     // reduce the 4 waves' partial sums through LDS, 4 column groups (of 64) at a time
@@ -587,16 +610,21 @@ extern "C" long cst_layernorm_bwd_workspace_floats(int T, int d) {
     return 2L * nblk * d;
 }
 
-extern "C" int cst_layernorm_bwd(const float* dy, const float* z, const float* mean, const float* rstd, const float* gamma,
-                                 float* dz, float* dgamma, float* dbeta, int accumulate,
-                                 float* workspace, long workspace_floats, int T, int d, void* stream) {
+extern "C" int cst_layernorm_bwd_b(const float* dy, const float* z, const float* mean, const float* rstd, const float* gamma,
+                                   float* dz, float* dgamma, float* dbeta, int accumulate,
+                                   float* workspace, long workspace_floats, int T, int d,
+                                   void* dz_bf16, long lddzb, float drop_p, uint32_t drop_seed, uint32_t drop_stream, const void* drop_seed_dev,
+                                   void* stream) {
     CST_REQUIRE(dy && z && mean && rstd && gamma && dz && workspace, "cst_layernorm_bwd: null pointer");
     CST_REQUIRE(T > 0 && d > 0 && d <= 64 * LN_MAXE, "cst_layernorm_bwd: d=%d unsupported", d);
+    CST_REQUIRE(!dz_bf16 || lddzb >= d, "cst_layernorm_bwd: bf16 leading dimension < d");
     const int nblk = T < 4096 ? cst_div_up(T, 4) : 1024;      // one row per wave per pass: latency hidden by occupancy
     CST_REQUIRE(workspace_floats >= 2L * nblk * d, "cst_layernorm_bwd: workspace too small (%ld < %ld)", workspace_floats, 2L * nblk * d);
     const int rpb = cst_div_up(T, nblk);
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(nblk), dim3(256), 0, st, dy, z, mean, rstd, gamma, dz, workspace, T, d, rpb);
+    CstDrop bd = cst_make_drop(drop_p, drop_seed, drop_stream, drop_seed_dev);
+    hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(nblk), dim3(256), 0, st, dy, z, mean, rstd, gamma, dz, workspace, T, d, rpb,
+                       (unsigned short*)dz_bf16, lddzb, bd);
     CST_LAUNCH_CHECK("cst_layernorm_bwd");
     if (dgamma) {
         int rc = cst_colsum(workspace, d, nblk, d, dgamma, accumulate, stream);
@@ -607,6 +635,13 @@ extern "C" int cst_layernorm_bwd(const float* dy, const float* z, const float* m
         if (rc) return rc;
     }
     return CST_OK;
+}
+
+extern "C" int cst_layernorm_bwd(const float* dy, const float* z, const float* mean, const float* rstd, const float* gamma,
+                                 float* dz, float* dgamma, float* dbeta, int accumulate,
+                                 float* workspace, long workspace_floats, int T, int d, void* stream) {
+    return cst_layernorm_bwd_b(dy, z, mean, rstd, gamma, dz, dgamma, dbeta, accumulate, workspace, workspace_floats, T, d,
+                               nullptr, 0, 0.f, 0, 0, nullptr, stream);
 }
 
 // ---------------------------------------------------------------------------------------------

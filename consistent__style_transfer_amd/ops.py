@@ -157,6 +157,7 @@ def capture_scope_reset():
     """Called by graphs.GraphedStep right before and right after a capture: copies cached during a
     capture live in that graph's private pool and mean nothing to any other capture or to eager code."""
     _WCACHE_CAPTURE.clear()
+    _SIDE_BF16.clear()
 
 
 def gemm_bf16(Ab, Bb, M, N, C=None, Cb=None, bias=None, addend=None, aux=None, act=0, gate_scale=1.0, alpha=1.0,
@@ -356,14 +357,42 @@ def dropout(x, drop):
 # =============================================================================================
 # transformer encoder layer (post-LN, ReLU) as one autograd node
 # =============================================================================================
-def _ln_fwd(x, res, gamma, beta, drop, z, y, mean, rstd, eps=1e-5):
+def _ln_fwd(x, res, gamma, beta, drop, z, y, mean, rstd, eps=1e-5, yb=None):
     T, d = x.shape
-    call("cst_add_layernorm_fwd", x, res, gamma, beta, eps, z, y, mean, rstd, T, d, *drop.args())
+    if yb is None:
+        call("cst_add_layernorm_fwd", x, res, gamma, beta, eps, z, y, mean, rstd, T, d, *drop.args())
+    else:
+        call("cst_add_layernorm_fwd_b", x, res, gamma, beta, eps, z, y, mean, rstd, T, d, *drop.args(), yb, yb.stride(0))
 
 
-def _ln_bwd(dy, z, mean, rstd, gamma, want_param_grads):
+_SIDE_BF16 = {}
+
+
+def _side_put(t, tb):
+    """bf16 twin of an activation produced by the same kernel, handed to the consumer that would otherwise cast it
+    (the next encoder layer): keyed by storage address + shape, at most a few entries alive."""
+    if len(_SIDE_BF16) >= 4:
+        _SIDE_BF16.pop(next(iter(_SIDE_BF16)))
+    _SIDE_BF16[(t.data_ptr(), tuple(t.shape))] = (weakref.ref(t), tb)
+
+
+def _side_take(t):
+    hit = _SIDE_BF16.pop((t.data_ptr(), tuple(t.shape)), None)
+    return hit[1] if hit is not None and hit[0]() is not None else None
+
+
+def _ln_bwd(dy, z, mean, rstd, gamma, want_param_grads, dzb_drop=None):
+    """dzb_drop: a Drop -> also returns bf16(dropout'(dz)) written by the same kernel (4th result)."""
     T, d = dy.shape
     dz = torch.empty_like(dy)
+    if dzb_drop is not None:
+        nws = call_plain("cst_layernorm_bwd_workspace_floats", T, d)
+        ws = torch.empty(nws, device=dy.device, dtype=torch.float32)
+        dg = torch.empty(d, device=dy.device, dtype=torch.float32) if want_param_grads else None
+        db = torch.empty(d, device=dy.device, dtype=torch.float32) if want_param_grads else None
+        dzb = torch.empty(T, d, device=dy.device, dtype=torch.int16)
+        call("cst_layernorm_bwd_b", dy, z, mean, rstd, gamma, dz, dg, db, 0, ws, nws, T, d, dzb, d, *dzb_drop.args())
+        return dz, dg, db, dzb
     nws = call_plain("cst_layernorm_bwd_workspace_floats", T, d)
     ws = torch.empty(nws, device=dy.device, dtype=torch.float32)
     dg = torch.empty(d, device=dy.device, dtype=torch.float32) if want_param_grads else None
@@ -447,17 +476,30 @@ class EncoderLayerBf16Fn(torch.autograd.Function):
         tt = wg and T % 64 == 0 and d % 8 == 0 and F % 8 == 0
         want_t = wg and not tt
         new = lambda *s: torch.empty(*s, device=dev, dtype=torch.float32)
-        xb, xt = cast_bf16(x, want_t=want_t)
+        fuse_b = (not want_t) and d % 64 == 0          # producers write the bf16 twins themselves (no padding needed)
+        newb = lambda *s: torch.empty(*s, device=dev, dtype=torch.int16)
+        xb = _side_take(x) if fuse_b else None         # written by the previous layer's LayerNorm
+        xt = None
+        if xb is None:
+            xb, xt = cast_bf16(x, want_t=want_t)
         inw_b, inw_t = weight_bf16(in_w)
         qkv = gemm_bf16(xb, inw_b, T, 3 * d, C=new(T, 3 * d), bias=in_b)
         att, lse = new(T, d), new(B * H * S)
-        call("cst_mha_fwd", qkv, att, lse, B, S, H, d // H, *drop.at(sb + 0).args())
-        attb, attt = cast_bf16(att, want_t=want_t)
+        if fuse_b:
+            attb, attt = newb(T, d), None
+            call("cst_mha_fwd_b", qkv, att, lse, B, S, H, d // H, *drop.at(sb + 0).args(), attb, d)
+        else:
+            call("cst_mha_fwd", qkv, att, lse, B, S, H, d // H, *drop.at(sb + 0).args())
+            attb, attt = cast_bf16(att, want_t=want_t)
         outw_b, outw_t = weight_bf16(out_w)
         z1 = gemm_bf16(attb, outw_b, T, d, C=new(T, d), bias=out_b)
         y1, m1, r1 = new(T, d), new(T), new(T)
-        _ln_fwd(z1, x, n1_w, n1_b, drop.at(sb + 1), z1, y1, m1, r1)
-        y1b, y1t = cast_bf16(y1, want_t=want_t)
+        if fuse_b:
+            y1b, y1t = newb(T, d), None
+            _ln_fwd(z1, x, n1_w, n1_b, drop.at(sb + 1), z1, y1, m1, r1, yb=y1b)
+        else:
+            _ln_fwd(z1, x, n1_w, n1_b, drop.at(sb + 1), z1, y1, m1, r1)
+            y1b, y1t = cast_bf16(y1, want_t=want_t)
         l1_b16, l1_t = weight_bf16(l1_w)
         Fp = _up64(F)
         hb = (torch.zeros if Fp != F else torch.empty)(T, Fp, device=dev, dtype=torch.int16)
@@ -466,33 +508,50 @@ class EncoderLayerBf16Fn(torch.autograd.Function):
         l2_b16, l2_t = weight_bf16(l2_w)
         z2 = gemm_bf16(hb, l2_b16, T, d, C=new(T, d), bias=l2_b)
         y2, m2, r2 = new(T, d), new(T), new(T)
-        _ln_fwd(z2, y1, n2_w, n2_b, drop.at(sb + 3), z2, y2, m2, r2)
+        if fuse_b:
+            y2b = newb(T, d)
+            _ln_fwd(z2, y1, n2_w, n2_b, drop.at(sb + 3), z2, y2, m2, r2, yb=y2b)
+            _side_put(y2, y2b)                         # the next layer's xb
+        else:
+            _ln_fwd(z2, y1, n2_w, n2_b, drop.at(sb + 3), z2, y2, m2, r2)
         # operands of the weight gradients: row-major copies (tt) or transposed copies
         wx, watt, wy1, wh = (xb, attb, y1b, hb) if tt else (xt, attt, y1t, ht)
         ctx.save_for_backward(wx, watt, wy1, wh, hb, inw_t, outw_t, l1_t, l2_t, n1_w, n2_w, qkv, lse, z1, m1, r1, z2, m2, r2)
-        ctx.cfg = (B, S, H, drop, sb, T, d, F, wg, tt)
+        ctx.cfg = (B, S, H, drop, sb, T, d, F, wg, tt, fuse_b)
         return y2
 
     @staticmethod
     def backward(ctx, dy2):
         wx, watt, wy1, wh, hb, inw_t, outw_t, l1_t, l2_t, n1_w, n2_w, qkv, lse, z1, m1, r1, z2, m2, r2 = ctx.saved_tensors
-        B, S, H, drop, sb, T, d, F, wg, tt = ctx.cfg
+        B, S, H, drop, sb, T, d, F, wg, tt, fuse_b = ctx.cfg
         dev = dy2.device
         want_t = wg and not tt
         new = lambda *s: torch.empty(*s, device=dev, dtype=torch.float32)
         dy2 = dy2.contiguous()
-        dz2, dn2w, dn2b = _ln_bwd(dy2, z2, m2, r2, n2_w, wg)
-        dfb, dft = cast_bf16(dz2, want_t=want_t, drop=drop.at(sb + 3))                  # dropout2' fused into the cast
+        if fuse_b:
+            dz2, dn2w, dn2b, dfb = _ln_bwd(dy2, z2, m2, r2, n2_w, wg, dzb_drop=drop.at(sb + 3))   # bf16(dropout2'(dz2)) from the LN kernel
+            dft = None
+        else:
+            dz2, dn2w, dn2b = _ln_bwd(dy2, z2, m2, r2, n2_w, wg)
+            dfb, dft = cast_bf16(dz2, want_t=want_t, drop=drop.at(sb + 3))              # dropout2' fused into the cast
         Fp = _up64(F)
         dhb = (torch.zeros if Fp != F else torch.empty)(T, Fp, device=dev, dtype=torch.int16)
         gemm_bf16(dfb, l2_t, T, F, Cb=dhb, aux=hb, act=3, gate_scale=drop.scale)       # relu' and dropout' fused
         dy1 = gemm_bf16(dhb, l1_t, T, d, C=new(T, d), addend=dz2)
-        dz1, dn1w, dn1b = _ln_bwd(dy1, z1, m1, r1, n1_w, wg)
-        dob, dot = cast_bf16(dz1, want_t=want_t, drop=drop.at(sb + 1))
+        if fuse_b:
+            dz1, dn1w, dn1b, dob = _ln_bwd(dy1, z1, m1, r1, n1_w, wg, dzb_drop=drop.at(sb + 1))
+            dot = None
+        else:
+            dz1, dn1w, dn1b = _ln_bwd(dy1, z1, m1, r1, n1_w, wg)
+            dob, dot = cast_bf16(dz1, want_t=want_t, drop=drop.at(sb + 1))
         datt = gemm_bf16(dob, outw_t, T, d, C=new(T, d))
         dqkv = torch.empty_like(qkv)
-        call("cst_mha_bwd", qkv, datt, lse, dqkv, B, S, H, d // H, *drop.at(sb + 0).args())
-        dqb, dqt = cast_bf16(dqkv, want_t=want_t)
+        if fuse_b:
+            dqb, dqt = torch.empty(T, 3 * d, device=dev, dtype=torch.int16), None
+            call("cst_mha_bwd_b", qkv, datt, lse, dqkv, B, S, H, d // H, *drop.at(sb + 0).args(), dqb, 3 * d)
+        else:
+            call("cst_mha_bwd", qkv, datt, lse, dqkv, B, S, H, d // H, *drop.at(sb + 0).args())
+            dqb, dqt = cast_bf16(dqkv, want_t=want_t)
         dx = gemm_bf16(dqb, inw_t, T, d, C=new(T, d), addend=dz1) if ctx.needs_input_grad[0] else None
         dinw = dinb = doutw = doutb = dl1w = dl1b = dl2w = dl2b = None
         if wg:

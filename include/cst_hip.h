@@ -119,10 +119,22 @@ int cst_add_layernorm_fwd(const float* x, const float* res, const float* gamma, 
                           float* z, float* y, float* mean, float* rstd, int T, int d,
                           float drop_p, uint32_t drop_seed, uint32_t drop_stream, const void* drop_seed_dev,
                           void* stream);
+/* _b: y also in bf16 (leading dimension ldyb): the A operand of the next projection. */
+int cst_add_layernorm_fwd_b(const float* x, const float* res, const float* gamma, const float* beta, float eps,
+                            float* z, float* y, float* mean, float* rstd, int T, int d,
+                            float drop_p, uint32_t drop_seed, uint32_t drop_stream, const void* drop_seed_dev,
+                            void* y_bf16, long ldyb, void* stream);
 long cst_layernorm_bwd_workspace_floats(int T, int d);
 int cst_layernorm_bwd(const float* dy, const float* z, const float* mean, const float* rstd, const float* gamma,
                       float* dz, float* dgamma, float* dbeta, int accumulate,
                       float* workspace, long workspace_floats, int T, int d, void* stream);
+/* _b: also dz_bf16 = bf16(dropout'(dz)) with the given dropout descriptor (element index row*d + c): the gradient that
+ * flows through the dropout in front of the residual add, as the GEMMs behind this LayerNorm consume it. */
+int cst_layernorm_bwd_b(const float* dy, const float* z, const float* mean, const float* rstd, const float* gamma,
+                        float* dz, float* dgamma, float* dbeta, int accumulate,
+                        float* workspace, long workspace_floats, int T, int d,
+                        void* dz_bf16, long lddzb, float drop_p, uint32_t drop_seed, uint32_t drop_stream, const void* drop_seed_dev,
+                        void* stream);
 /* out[c] (+)= sum_r X[r,c]  (bias gradients). */
 int cst_colsum(const float* X, long ld, int M, int N, float* out, int accumulate, void* stream);
 /* out[0] (+)= scale * sum(in[0..n)), one block, deterministic. */
@@ -133,8 +145,16 @@ int cst_reduce_sum(const float* in, long n, float scale, float* out, int accumul
  * nn.MultiheadAttention inside nn.TransformerEncoderLayer (mlm.py:20-22,43; match.py:18-20,39). */
 int cst_mha_fwd(const float* qkv, float* out, float* lse, int B, int S, int H, int hd,
                 float drop_p, uint32_t drop_seed, uint32_t drop_stream, const void* drop_seed_dev, void* stream);
+/* _b: also writes the result in bf16 (row-major, leading dimension ldob / lddb elements) -- the A operand of the
+ * projection GEMM that consumes it, saving a separate cast pass. */
+int cst_mha_fwd_b(const float* qkv, float* out, float* lse, int B, int S, int H, int hd,
+                  float drop_p, uint32_t drop_seed, uint32_t drop_stream, const void* drop_seed_dev,
+                  void* out_bf16, long ldob, void* stream);
 int cst_mha_bwd(const float* qkv, const float* dout, const float* lse, float* dqkv, int B, int S, int H, int hd,
                 float drop_p, uint32_t drop_seed, uint32_t drop_stream, const void* drop_seed_dev, void* stream);
+int cst_mha_bwd_b(const float* qkv, const float* dout, const float* lse, float* dqkv, int B, int S, int H, int hd,
+                  float drop_p, uint32_t drop_seed, uint32_t drop_stream, const void* drop_seed_dev,
+                  void* dqkv_bf16, long lddb, void* stream);
 
 /* Single-query dot attention (rnn.py:46-50,76): out = softmax(q mem^T / sqrt(D)) mem; p [B,L] kept.
  * `dropped` (optional, [B, lddrop]): also writes dropout([q | out]) -- the decoder's i_ffn of
