@@ -810,3 +810,133 @@ extern "C" int cst_gemm_bf16_lstm_bwd(const void* A, long lda, const void* B, lo
     CST_LAUNCH_CHECK("cst_gemm_bf16_lstm_bwd_reduce");
     return CST_OK;
 }
+
+// =============================================================================================
+// Decoder step front half in two launches (rnn.py:75-79): gates = [x_t | h_{t-1}] [W_ih | W_hh]^T + b, LSTM cell,
+// single-query attention of h_t over the encoder states, dropout of the FFN input [h_t | a_t].  One workgroup per
+// batch row sums that row's split-K partials, applies the cell (one thread per hidden unit), keeps h_t in LDS as the
+// attention query and finishes with the attention of cst_dot_attn_fwd: the h_t round trip and one dependent launch
+// per decode step disappear.
+// =============================================================================================
+struct LstmAttnEpi {
+    const float* slab; int splits; int M, H;
+    const float* bias; float* gates; long ldg; const float* c_prev; long ldcp;
+    float* h_out; long ldh; float* c_out; long ldc; float* h_out2; long ldh2; bf16_t* hb2; long ldhb2;
+    const float* mem; float* att; long ldo; float* p; int L; float scale;
+    float* dropped; long lddrop; bf16_t* dropped_b; long lddropb; CstDrop drop;
+};
+
+__global__ __launch_bounds__(1024) void cst_gemm_bf16_lstm_attn_kernel(LstmAttnEpi q) {
+    extern __shared__ __attribute__((aligned(16))) float dsm[];
+    const int D = q.H, L = q.L;
+    float* ms = dsm;                 // [L][D] encoder states of this batch row
+    float* qs = ms + L * D;          // [D]    h_t
+    float* sc = qs + D;              // [64]
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    // memory tile: four 16-byte loads in flight per thread, then the cell's operands on top of them
+    {
+        const float4* src = reinterpret_cast<const float4*>(q.mem + (long)b * L * D);
+        float4* dst = reinterpret_cast<float4*>(ms);
+        const int n4 = L * D / 4, bd = blockDim.x;
+        for (int base = 0; base < n4; base += 4 * bd) {
+            float4 t[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) t[u] = src[min(base + u * bd + tid, n4 - 1)];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int e = base + u * bd + tid;
+                if (e < n4) dst[e] = t[u];
+            }
+        }
+    }
+    if (tid < D) {
+        const int u = tid;
+        const long MN = (long)q.M * 4 * D;
+        float pre[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const long off = (long)b * 4 * D + (long)g * D + u;
+            float a = q.bias ? q.bias[g * D + u] : 0.f;
+            for (int s = 0; s < q.splits; ++s) a += q.slab[s * MN + off];
+            pre[g] = a;
+        }
+        const float gi = lstm_sigmoid(pre[0]), gf = lstm_sigmoid(pre[1]), gg = tanhf(pre[2]), go = lstm_sigmoid(pre[3]);
+        const float c = gf * q.c_prev[(long)b * q.ldcp + u] + gi * gg;
+        const float h = go * tanhf(c);
+        float* g = q.gates + (long)b * q.ldg + u;
+        g[0] = gi; g[D] = gf; g[2 * D] = gg; g[3 * D] = go;
+        q.c_out[(long)b * q.ldc + u] = c;
+        q.h_out[(long)b * q.ldh + u] = h;
+        if (q.h_out2) q.h_out2[(long)b * q.ldh2 + u] = h;
+        if (q.hb2) q.hb2[(long)b * q.ldhb2 + u] = f2bf16(h);
+        qs[u] = h;
+    }
+    __syncthreads();
+    for (int j = w; j < L; j += (int)(blockDim.x >> 6)) {
+        float s = 0.f;
+        for (int c = lane; c < D; c += 64) s += qs[c] * ms[j * D + c];
+        s = wave_sum(s);
+        if (lane == 0) sc[j] = s * q.scale;
+    }
+    __syncthreads();
+    float m = -INFINITY;
+    for (int j = 0; j < L; ++j) m = fmaxf(m, sc[j]);
+    float sum = 0.f;
+    for (int j = 0; j < L; ++j) sum += expf(sc[j] - m);
+    __syncthreads();
+    if (tid < L) {
+        const float pj = expf(sc[tid] - m) / sum;
+        sc[tid] = pj;
+        q.p[(long)b * L + tid] = pj;
+    }
+    __syncthreads();
+    const uint32_t dseed = q.drop.p > 0.f ? cst_drop_seed(q.drop) : 0u;
+    if (tid < D) {
+        const int c = tid;
+        float o = 0.f;
+        for (int j = 0; j < L; ++j) o += sc[j] * ms[j * D + c];
+        q.att[(long)b * q.ldo + c] = o;
+        if (q.dropped || q.dropped_b) {                 // dropout index space is the (B, 2D) matrix [h | a]
+            const float mq = q.drop.p > 0.f ? cst_drop_mask(q.drop, dseed, (uint32_t)((long)b * 2 * D + c)) : 1.f;
+            const float mo = q.drop.p > 0.f ? cst_drop_mask(q.drop, dseed, (uint32_t)((long)b * 2 * D + D + c)) : 1.f;
+            if (q.dropped) {
+                float* dr = q.dropped + (long)b * q.lddrop;
+                dr[c] = qs[c] * mq;
+                dr[D + c] = o * mo;
+            }
+            if (q.dropped_b) {
+                bf16_t* db = q.dropped_b + (long)b * q.lddropb;
+                db[c] = f2bf16(qs[c] * mq);
+                db[D + c] = f2bf16(o * mo);
+            }
+        }
+    }
+}
+
+extern "C" int cst_gemm_bf16_lstm_attn(const void* A, long lda, const void* B, long ldb, int M, int H, int K,
+                                       const float* bias, float* gates, long ldg, const float* c_prev, long ldcp,
+                                       float* h_out, long ldh, float* c_out, long ldc, float* h_out2, long ldh2, void* h_bf16_2, long ldhb2,
+                                       const float* mem, int L, float* att_out, long ldo, float* p,
+                                       float* dropped, long lddrop, void* dropped_bf16, long lddropb,
+                                       float drop_p, uint32_t drop_seed, uint32_t drop_stream, const void* drop_seed_dev,
+                                       int splitk, float* workspace, long workspace_floats, void* stream) {
+    CST_REQUIRE(gates && c_prev && h_out && c_out && mem && att_out && p, "cst_gemm_bf16_lstm_attn: null pointer");
+    CST_REQUIRE(H > 0 && H % 4 == 0 && H <= 1024 && L > 0 && L <= 64, "cst_gemm_bf16_lstm_attn: H=%d (multiple of 4, <= 1024) or L=%d (<= 64) unsupported", H, L);
+    CST_REQUIRE(((uintptr_t)mem & 15) == 0, "cst_gemm_bf16_lstm_attn: mem must be 16-byte aligned");
+    const size_t lds = sizeof(float) * ((size_t)L * H + H + 64);
+    CST_REQUIRE(lds <= 160 * 1024, "cst_gemm_bf16_lstm_attn: memory tile of %zu bytes exceeds the 160 KiB LDS", lds);
+    hipStream_t st = (hipStream_t)stream;
+    BGemmArgs g;
+    if (int rc = lstm_gemm_front("cst_gemm_bf16_lstm_attn", g, A, B, nullptr, nullptr, lda, ldb, M, 4 * H, K, splitk, workspace, workspace_floats, st)) return rc;
+    LstmAttnEpi q;
+    q.slab = workspace; q.splits = g.splits; q.M = M; q.H = H;
+    q.bias = bias; q.gates = gates; q.ldg = ldg; q.c_prev = c_prev; q.ldcp = ldcp;
+    q.h_out = h_out; q.ldh = ldh; q.c_out = c_out; q.ldc = ldc; q.h_out2 = h_out2; q.ldh2 = ldh2; q.hb2 = (bf16_t*)h_bf16_2; q.ldhb2 = ldhb2;
+    q.mem = mem; q.att = att_out; q.ldo = ldo; q.p = p; q.L = L; q.scale = 1.0f / sqrtf((float)H);
+    q.dropped = dropped; q.lddrop = lddrop; q.dropped_b = (bf16_t*)dropped_bf16; q.lddropb = lddropb;
+    q.drop = cst_make_drop(drop_p, drop_seed, drop_stream, drop_seed_dev);
+    if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)cst_gemm_bf16_lstm_attn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(cst_gemm_bf16_lstm_attn_kernel, dim3(M), dim3(1024), lds, st, q);
+    CST_LAUNCH_CHECK("cst_gemm_bf16_lstm_attn_kernel");
+    return CST_OK;
+}

@@ -201,17 +201,26 @@ class GeneratorFn(torch.autograd.Function):
             c_in = c0 if s == 0 else cdec[s - 1]
             h_next = XH[s + 1][:, E:] if s + 1 < T else None
             i_s = if2[:, s * W_:(s + 1) * W_]
-            if use_b:
-                _gemm_cell_fwd([dict(Ab=XHb[s], Bb=wcat_b, gates=gdec[s], c_prev=c_in, h_out=i_s[:, :Hd], c_out=cdec[s], h_out2=h_next,
-                                     bias=bdec, hb2=XHb[s + 1][:, E:] if s + 1 < T else None)], B, Hd)
-            else:
-                gemm(XH[s], True, wcat, True, gdec[s], B, 4 * Hd, E + Hd, bias=bdec)
-                _cell_fwd(gdec[s], c_in, i_s[:, :Hd], cdec[s], h_next, B, Hd)
             id_s = ifd2[:, s * W_:(s + 1) * W_]
             fd = drop.at(STREAM_G_FFN + s)
             idb_s = ifdb[:, s * W_:(s + 1) * W_] if use_b else None
-            call("cst_dot_attn_fwd", i_s[:, :Hd], T * W_, memory, i_s[:, Hd:], T * W_, patt[s], B, Lp, Hd,
-                 id_s if drop.p > 0 else None, T * W_, idb_s, T * W_, *fd.args())   # also writes dropout(i_ffn) (+ bf16)
+            if use_b and Hd == 2 * H and Hd <= 1024:
+                # gates product, then ONE kernel: split-K sum + cell + attention over the encoder states + dropout(i_ffn)
+                hb2 = XHb[s + 1][:, E:] if s + 1 < T else None
+                call("cst_gemm_bf16_lstm_attn", XHb[s], XHb[s].stride(0), wcat_b, wcat_b.stride(0), B, Hd, XHb[s].shape[1],
+                     bdec, gdec[s], gdec[s].stride(0), c_in, c_in.stride(0), i_s[:, :Hd], T * W_, cdec[s], cdec[s].stride(0),
+                     h_next, _st(h_next), hb2, _st(hb2), memory, Lp, i_s[:, Hd:], T * W_, patt[s],
+                     id_s if drop.p > 0 else None, T * W_, idb_s, T * W_, *fd.args(),
+                     ops.LSTM_SPLITK, ops._workspace(dev), ops.WS_FLOATS)
+            else:
+                if use_b:
+                    _gemm_cell_fwd([dict(Ab=XHb[s], Bb=wcat_b, gates=gdec[s], c_prev=c_in, h_out=i_s[:, :Hd], c_out=cdec[s], h_out2=h_next,
+                                         bias=bdec, hb2=XHb[s + 1][:, E:] if s + 1 < T else None)], B, Hd)
+                else:
+                    gemm(XH[s], True, wcat, True, gdec[s], B, 4 * Hd, E + Hd, bias=bdec)
+                    _cell_fwd(gdec[s], c_in, i_s[:, :Hd], cdec[s], h_next, B, Hd)
+                call("cst_dot_attn_fwd", i_s[:, :Hd], T * W_, memory, i_s[:, Hd:], T * W_, patt[s], B, Lp, Hd,
+                     id_s if drop.p > 0 else None, T * W_, idb_s, T * W_, *fd.args())   # also writes dropout(i_ffn) (+ bf16)
             r1s = r12[:, s * Hd:(s + 1) * Hd]
             o_s = out2[:, s * V:(s + 1) * V]
             if use_b:

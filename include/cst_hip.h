@@ -206,6 +206,16 @@ int cst_gemm_bf16_lstm(const void* A, long lda, const void* B, long ldb, int M, 
                        float* gates2, const float* c_prev2, float* h_out_2, float* c_out2, float* h_out2_2,
                        void* h_bf16_p2, void* h_bf16_2_p2,
                        int splitk, float* workspace, long workspace_floats, void* stream);
+/* The decoder's variant of the forward step (rnn.py:75-79): gates product (bias only), cell, then the single-query
+ * attention of cst_dot_attn_fwd with h_t as the query (D = H) and the FFN-input dropout, all in the second launch
+ * (one workgroup per batch row).  Arguments as cst_gemm_bf16_lstm / cst_dot_attn_fwd. */
+int cst_gemm_bf16_lstm_attn(const void* A, long lda, const void* B, long ldb, int M, int H, int K,
+                            const float* bias, float* gates, long ldg, const float* c_prev, long ldcp,
+                            float* h_out, long ldh, float* c_out, long ldc, float* h_out2, long ldh2, void* h_bf16_2, long ldhb2,
+                            const float* mem, int L, float* att_out, long ldo, float* p,
+                            float* dropped, long lddrop, void* dropped_bf16, long lddropb,
+                            float drop_p, uint32_t drop_seed, uint32_t drop_stream, const void* drop_seed_dev,
+                            int splitk, float* workspace, long workspace_floats, void* stream);
 int cst_gemm_bf16_lstm_bwd(const void* A, long lda, const void* B, long ldb, int M, int H, int K,
                            const float* gates, long ldg, const float* c_prev, long ldcp, const float* c_new, long ldcn,
                            const float* dh_extra, long lddh, const float* dc_in, long lddc,

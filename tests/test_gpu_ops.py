@@ -607,3 +607,32 @@ def test_encoder_layer_bf16_tt_weight_grads_match_exact_mode(ops):
     for a, b in zip(res["bf16"], res["f32"]):
         err = (a - b).norm() / (b.norm() + 1e-12)
         assert err < 3e-2, float(err)
+
+
+@pytest.mark.parametrize("B,H,K,L,p", [(5, 64, 128, 7, 0.0), (256, 512, 640, 18, 0.1)])
+def test_gemm_bf16_lstm_attn_equals_cell_then_attention(ops, B, H, K, L, p):
+    """Decoder step front half: one fused second launch == cst_gemm_bf16_lstm + cst_dot_attn_fwd."""
+    from consistent__style_transfer_amd import gen_fn
+    from consistent__style_transfer_amd._lib import call
+    A, Wt = rnd(B, K, seed=1, scale=0.3), rnd(4 * H, K, seed=2, scale=0.3)
+    Ab, Wb = ops.cast_bf16(dev(A), want_t=False)[0], ops.cast_bf16(dev(Wt), want_t=False)[0]
+    bias, c_prev, mem = dev(rnd(4 * H, seed=3)), dev(rnd(B, H, seed=4)), dev(rnd(B, L, H, seed=5))
+    drop = ops.Drop(p, 21, 407)
+
+    def bufs():
+        return dict(gates=torch.empty(B, 4 * H, device="cuda"), h=torch.empty(B, 2 * H + 4, device="cuda"), c=torch.empty(B, H, device="cuda"),
+                    h2=torch.empty(B, H, device="cuda"), hb2=torch.zeros(B, H, device="cuda", dtype=torch.int16),
+                    pr=torch.empty(B, L, device="cuda"), dr=torch.empty(B, 2 * H, device="cuda"),
+                    db=torch.zeros(B, 2 * H, device="cuda", dtype=torch.int16))
+    r, f = bufs(), bufs()
+    gen_fn._gemm_cell_fwd([dict(Ab=Ab, Bb=Wb, gates=r["gates"], c_prev=c_prev, h_out=r["h"][:, :H], c_out=r["c"], h_out2=r["h2"], bias=bias,
+                                hb2=r["hb2"])], B, H)
+    call("cst_dot_attn_fwd", r["h"][:, :H], 2 * H + 4, mem, r["h"][:, H:2 * H], 2 * H + 4, r["pr"], B, L, H, r["dr"], 2 * H, r["db"], 2 * H, *drop.args())
+    call("cst_gemm_bf16_lstm_attn", Ab, Ab.stride(0), Wb, Wb.stride(0), B, H, Ab.shape[1], bias, f["gates"], 4 * H, c_prev, H,
+         f["h"][:, :H], 2 * H + 4, f["c"], H, f["h2"], H, f["hb2"], H, mem, L, f["h"][:, H:2 * H], 2 * H + 4, f["pr"],
+         f["dr"], 2 * H, f["db"], 2 * H, *drop.args(), ops.LSTM_SPLITK, ops._workspace(Ab.device), ops.WS_FLOATS)
+    for k in ("gates", "c", "h2", "pr", "dr"):
+        close(f[k], r[k], 2e-5, 2e-5, k)
+    close(f["h"][:, :2 * H], r["h"][:, :2 * H], 2e-5, 2e-5)
+    for k in ("hb2", "db"):
+        close(f[k].view(torch.bfloat16).float(), r[k].view(torch.bfloat16).float(), 1e-2, 1e-2, k)
