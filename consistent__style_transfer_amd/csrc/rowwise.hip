@@ -43,7 +43,8 @@ template <int NV4>
 __global__ __launch_bounds__(ROW_THREADS) void ce_vec_kernel(const float* __restrict__ logits, long ld,
                                                              const int64_t* __restrict__ target, int V,
                                                              float* __restrict__ row_loss,
-                                                             float* dlogits, long ldd, float gscale) {
+                                                             float* dlogits, long ldd, float gscale,
+                                                             unsigned short* __restrict__ dlb, long lddb) {
     __shared__ float red[16];
     const long r = blockIdx.x;
     const float* row = logits + r * ld;
@@ -76,6 +77,15 @@ __global__ __launch_bounds__(ROW_THREADS) void ce_vec_kernel(const float* __rest
                 else if (t == c + 2) g.z -= gscale; else g.w -= gscale;
             }
             x.v[i] = g;
+            if (dlb && c < lddb) {                // bf16 twin, zero in the K padding: operand of the vocabulary dgrad / wgrad
+                uint2 u = make_uint2(0u, 0u);
+                if (c < V) {
+                    __bf16 h0 = (__bf16)g.x, h1 = (__bf16)g.y, h2 = (__bf16)g.z, h3 = (__bf16)g.w;
+                    u.x = (uint32_t)__builtin_bit_cast(unsigned short, h0) | ((uint32_t)__builtin_bit_cast(unsigned short, h1) << 16);
+                    u.y = (uint32_t)__builtin_bit_cast(unsigned short, h2) | ((uint32_t)__builtin_bit_cast(unsigned short, h3) << 16);
+                }
+                *reinterpret_cast<uint2*>(dlb + r * lddb + c) = u;
+            }
         }
         x.store(dlogits + r * ldd, V);
     }
@@ -126,19 +136,29 @@ static bool row_vec_ok(const void* p, long ld, int V) {
         else hipLaunchKernelGGL((KERNEL<32>), __VA_ARGS__);                              \
     } while (0)
 
-extern "C" int cst_token_ce(const float* logits, long ld, const int64_t* target, int R, int V,
-                            float* row_loss, float* dlogits, long ldd, float grad_scale, void* stream) {
+extern "C" int cst_token_ce_b(const float* logits, long ld, const int64_t* target, int R, int V,
+                              float* row_loss, float* dlogits, long ldd, float grad_scale,
+                              void* dlogits_bf16, long lddb, void* stream) {
     CST_REQUIRE(logits && target && row_loss, "cst_token_ce: null pointer");
     CST_REQUIRE(R > 0 && V > 0 && ld >= V, "cst_token_ce: bad shape R=%d V=%d ld=%ld", R, V, ld);
     CST_REQUIRE(!dlogits || ldd >= V, "cst_token_ce: ldd too small");
     hipStream_t st = (hipStream_t)stream;
-    if (row_vec_ok(logits, ld, V) && (!dlogits || row_vec_ok(dlogits, ldd, V))) {
-        ROW_DISPATCH(V, ce_vec_kernel, dim3(R), dim3(ROW_THREADS), 0, st, logits, ld, target, V, row_loss, dlogits, ldd, grad_scale);
+    unsigned short* dlb = (unsigned short*)dlogits_bf16;
+    const bool vec = row_vec_ok(logits, ld, V) && (!dlogits || row_vec_ok(dlogits, ldd, V));
+    CST_REQUIRE(!dlb || (dlogits && vec && V % 4 == 0 && lddb >= V && lddb % 4 == 0 && lddb <= ((V + 1023) / 1024) * 1024 && (((uintptr_t)dlb) & 7) == 0),
+                "cst_token_ce: the bf16 gradient needs the vector path (V %% 4 == 0, 16-byte aligned rows) and V <= lddb <= V rounded up to 1024");
+    if (vec) {
+        ROW_DISPATCH(V, ce_vec_kernel, dim3(R), dim3(ROW_THREADS), 0, st, logits, ld, target, V, row_loss, dlogits, ldd, grad_scale, dlb, lddb);
     } else {
         hipLaunchKernelGGL(ce_generic_kernel, dim3(R), dim3(ROW_THREADS), 0, st, logits, ld, target, V, row_loss, dlogits, ldd, grad_scale);
     }
     CST_LAUNCH_CHECK("cst_token_ce");
     return CST_OK;
+}
+
+extern "C" int cst_token_ce(const float* logits, long ld, const int64_t* target, int R, int V,
+                            float* row_loss, float* dlogits, long ldd, float grad_scale, void* stream) {
+    return cst_token_ce_b(logits, ld, target, R, V, row_loss, dlogits, ldd, grad_scale, nullptr, 0, stream);
 }
 
 // ---------------------------------------------------------------------------------------------

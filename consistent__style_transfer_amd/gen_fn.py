@@ -272,21 +272,36 @@ class GeneratorFn(torch.autograd.Function):
         dgd = _new(dev, T, B, 4 * Hd)
         diffn_all = _new(dev, B, T, W_)
         df2 = diffn_all.view(B, T * W_)
-        if not soft:
-            # all dlogits are known up front (token CE): one large dgrad through fn_2 (+LeakyReLU gate)
-            # and one through fn_1 instead of T small ones
-            dgrad(dout.view(B * T, V), P["fn_2.weight"], out=dpre1.view(B * T, Hd), aux=r1.view(B * T, Hd), act=4)
-            dgrad(dpre1.view(B * T, Hd), P["fn_1.weight"], out=diffn_all.view(B * T, W_))
-        dXH_all = _new(dev, T, B, E + Hd)              # step s writes [d x_s | d h_{s-1}] into slice s
-        dxe_all = _new(dev, max(T - 1, 1), B, E) if (soft and drop.p > 0) else None
-        dc = _new(dev, B, Hd)
+        Vp = (V + 63) // 64 * 64
+        fn1_t = fn2_t = dgdb = dlb_all = None
         if use_b:
             fn1_t = weight_bf16(P["fn_1.weight"])[1]                # [W_, Hd]
             fn2_t = weight_bf16(P["fn_2.weight"])[1]                # [Hd, up64(V)]
             dgdb = _i16(dev, B, 4 * Hd)
             if soft:
-                dlb = torch.zeros(B, (V + 63) // 64 * 64, device=dev, dtype=torch.int16)    # K padding stays zero
+                # bf16 dlogits of ALL steps (softmax backward writes slice s): per-step dgrad operand now, operand of
+                # the fn_2 weight gradient after the loop; only the K-padding columns need zeroing
+                dlb_all = _i16(dev, B, T * Vp)
+                if Vp != V:
+                    dlb_all.view(B, T, Vp)[:, :, V:].zero_()
                 dp1b = _i16(dev, B, Hd)
+            else:
+                dlb_all = ops._side_take(dout)                       # written by the token-CE kernel next to dlogits
+                if dlb_all is not None:
+                    dlb_all = dlb_all.view(B, T * Vp)
+        if not soft:
+            # all dlogits are known up front (token CE): one large dgrad through fn_2 (+LeakyReLU gate)
+            # and one through fn_1 instead of T small ones
+            if dlb_all is not None:
+                dp1b_all = _i16(dev, B * T, Hd)
+                gemm_bf16(dlb_all.view(B * T, Vp), fn2_t, B * T, Hd, C=dpre1.view(B * T, Hd), Cb=dp1b_all, aux=r1b.view(B * T, Hd), act=4)
+                gemm_bf16(dp1b_all, fn1_t, B * T, W_, C=diffn_all.view(B * T, W_))
+            else:
+                dgrad(dout.view(B * T, V), P["fn_2.weight"], out=dpre1.view(B * T, Hd), aux=r1.view(B * T, Hd), act=4)
+                dgrad(dpre1.view(B * T, Hd), P["fn_1.weight"], out=diffn_all.view(B * T, W_))
+        dXH_all = _new(dev, T, B, E + Hd)              # step s writes [d x_s | d h_{s-1}] into slice s
+        dxe_all = _new(dev, max(T - 1, 1), B, E) if (soft and drop.p > 0) else None
+        dc = _new(dev, B, Hd)
         # Teacher-forced / free-running decodes on the bf16 path: every step's FFN gradient is already in
         # diffn_all, so the attention backward of all steps runs as ONE launch (memory tile staged once per
         # batch row, FFN-input dropout applied on the way in) and each step of the recurrence is one launch
@@ -318,7 +333,8 @@ class GeneratorFn(torch.autograd.Function):
                     g_x = dXH[:, :E]
                 gemm(g_x, True, E_tok, True, dl, B, V, E, accumulate=True)
             if soft:
-                softmax_tau_bwd(out2[:, s * V:(s + 1) * V], dl, inv_tau, dl, dx_b=dlb if use_b else None)
+                dlb = dlb_all[:, s * Vp:(s + 1) * Vp] if use_b else None
+                softmax_tau_bwd(out2[:, s * V:(s + 1) * V], dl, inv_tau, dl, dx_b=dlb)
             diffn = df2[:, s * W_:(s + 1) * W_]
             fd = drop.at(STREAM_G_FFN + s)
             if soft:
@@ -364,7 +380,10 @@ class GeneratorFn(torch.autograd.Function):
         G["transfer.weight"] = wgrad(dpre_t, c_cat)
         dc_cat = dgrad(dpre_t, P["transfer.weight"])
         # batched weight gradients of the decoder
-        G["fn_2.weight"] = wgrad(dout.view(B * T, V), r1.view(B * T, Hd))
+        if dlb_all is not None and (B * T) % 64 == 0 and V % 8 == 0 and Hd % 8 == 0:
+            G["fn_2.weight"] = ops.gemm_bf16_tt(dlb_all.view(B * T, Vp), r1b.view(B * T, Hd), V, Hd)   # dlogits^T r1, no transposes
+        else:
+            G["fn_2.weight"] = wgrad(dout.view(B * T, V), r1.view(B * T, Hd))
         dp1 = dpre1.view(B * T, Hd)
         G["fn_1.weight"] = wgrad(dp1, iffn_d.view(B * T, W_))
         G["fn_1.bias"] = colsum(dp1)

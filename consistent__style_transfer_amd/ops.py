@@ -373,11 +373,12 @@ def _side_put(t, tb):
     (the next encoder layer): keyed by storage address + shape, at most a few entries alive."""
     if len(_SIDE_BF16) >= 4:
         _SIDE_BF16.pop(next(iter(_SIDE_BF16)))
-    _SIDE_BF16[(t.data_ptr(), tuple(t.shape))] = (weakref.ref(t), tb)
+    _SIDE_BF16[(t.data_ptr(), t.numel())] = (weakref.ref(t), tb)
 
 
 def _side_take(t):
-    hit = _SIDE_BF16.pop((t.data_ptr(), tuple(t.shape)), None)
+    """Keyed by storage address and element count (views of the producer's tensor qualify)."""
+    hit = _SIDE_BF16.pop((t.data_ptr(), t.numel()), None)
     return hit[1] if hit is not None and hit[0]() is not None else None
 
 
@@ -677,7 +678,14 @@ class TokenCEFn(torch.autograd.Function):
         row = torch.empty(R, device=logits.device, dtype=torch.float32)
         loss = torch.empty(1, device=logits.device, dtype=torch.float32)
         dl = torch.empty(R, V, device=logits.device, dtype=torch.float32) if logits.requires_grad else None
-        call("cst_token_ce", logits, _ld(logits), _i64(target), R, V, row, dl, V, float(weight) / R)
+        if dl is not None and unit_grad and not _STATE["f32"] and V % 4 == 0 and _ld(logits) % 4 == 0 and V <= 16384:
+            # bf16 twin of the gradient (zero K padding) for the vocabulary projection's dgrad / wgrad GEMMs;
+            # valid only when the gradient reaches the producer unscaled (unit_grad)
+            dlb = torch.empty(R, _up64(V), device=logits.device, dtype=torch.int16)
+            call("cst_token_ce_b", logits, _ld(logits), _i64(target), R, V, row, dl, V, float(weight) / R, dlb, dlb.stride(0))
+            _side_put(dl, dlb)
+        else:
+            call("cst_token_ce", logits, _ld(logits), _i64(target), R, V, row, dl, V, float(weight) / R)
         call("cst_reduce_sum", row, R, float(weight) / R, loss, 0)
         ctx.save_for_backward(dl)
         ctx.unit = unit_grad

@@ -88,6 +88,11 @@ int cst_colsum_bf16(const void* X, long ld, int M, int N, float* out, void* stre
  * cst_reduce_sum with scale 1/R -- PAD rows count, ignore_index stays at its default). */
 int cst_token_ce(const float* logits, long ld, const int64_t* target, int R, int V,
                  float* row_loss, float* dlogits, long ldd, float grad_scale, void* stream);
+/* _b: dlogits also in bf16 [R, lddb] with zeros in columns V..lddb-1 (K padding): the operand of the vocabulary
+ * projection's dgrad and weight-gradient GEMMs. */
+int cst_token_ce_b(const float* logits, long ld, const int64_t* target, int R, int V,
+                   float* row_loss, float* dlogits, long ldd, float grad_scale,
+                   void* dlogits_bf16, long lddb, void* stream);
 
 /* p = softmax(logits * inv_tau) over V, argmax_out[r] = first index of max(p) (may be null).
  * rnn.py:83 (softmax(logits / tau)) and the argmax inside hard_sample, rnn.py:52-53. */
