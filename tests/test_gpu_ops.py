@@ -636,3 +636,48 @@ def test_gemm_bf16_lstm_attn_equals_cell_then_attention(ops, B, H, K, L, p):
     close(f["h"][:, :2 * H], r["h"][:, :2 * H], 2e-5, 2e-5)
     for k in ("hb2", "db"):
         close(f[k].view(torch.bfloat16).float(), r[k].view(torch.bfloat16).float(), 1e-2, 1e-2, k)
+
+
+def test_token_ce_bf16_twin(ops):
+    """cst_token_ce_b: the bf16 gradient equals bf16(dlogits) and its K padding is zero."""
+    from consistent__style_transfer_amd._lib import call
+    R, V = 37, 10000
+    Vp = (V + 63) // 64 * 64
+    logits = dev(rnd(R, V, seed=1, scale=2.0))
+    tgt = torch.randint(0, V, (R,), device="cuda")
+    row, dl = torch.empty(R, device="cuda"), torch.empty(R, V, device="cuda")
+    dlb = torch.full((R, Vp), 0x7fc0, device="cuda", dtype=torch.int16)          # NaN pattern: every element must be overwritten
+    call("cst_token_ce_b", logits, V, tgt, R, V, row, dl, V, 1.0 / R, dlb, Vp)
+    ref_row, ref_dl = torch.empty(R, device="cuda"), torch.empty(R, V, device="cuda")
+    call("cst_token_ce", logits, V, tgt, R, V, ref_row, ref_dl, V, 1.0 / R)
+    assert torch.equal(dl, ref_dl) and torch.equal(row, ref_row)
+    twin = dlb.view(torch.bfloat16)
+    assert torch.equal(twin[:, :V], dl.to(torch.bfloat16))
+    assert (dlb[:, V:] == 0).all()
+
+
+def test_generator_teacher_forced_grads_with_and_without_bf16_twin(ops):
+    """The vocabulary dgrad / fn_2 weight gradient through the bf16 twin of dlogits agree with the fp32-operand path."""
+    from consistent__style_transfer_amd import model, synthetic as syn
+    from helpers import CONFIGS
+    from test_gpu_modules import set_constants
+    set_constants(model, CONFIGS["ref"])
+    ops.set_precision("bf16")
+    B, L, V = 64, 8, 1000
+    torch.manual_seed(0)
+    g = model.DenoiseLSTM(V, 2, L).cuda().eval()
+    x, lab = (t.cuda() for t in syn.optimize_batch(B, L, V, 3))
+    coins = torch.ones(L, dtype=torch.int32, device="cuda")
+    grads = []
+    for use_twin in (True, False):
+        g.zero_grad()
+        lg = g(x, lab, x, lab, coins=coins)
+        loss = ops.token_ce(lg.view(-1, V), x.reshape(-1), unit_grad=True)
+        if not use_twin:
+            ops._SIDE_BF16.clear()
+        loss.backward()
+        grads.append({k: p.grad.clone() for k, p in g.named_parameters()})
+    for k in grads[0]:
+        a, b = grads[0][k], grads[1][k]
+        err = (a - b).norm() / (b.norm() + 1e-12)
+        assert err < 3e-2, (k, float(err))
