@@ -30,5 +30,5 @@ class MLM(nn.Module):
         B, L, d = x.shape
         drop = make_drop(self, p_drop, seed)
         x = self.lm.run(x.view(B * L, d), B, L, drop)
-        logits = ops.linear(x, self.fwd.weight, self.fwd.bias)
+        logits = ops.vocab_proj(x, self.fwd.weight, self.fwd.bias)
         return logits.view(B, L, -1)

@@ -333,6 +333,48 @@ class LinearFn(torch.autograd.Function):
         return dx, dW, db, None, None
 
 
+class VocabProjFn(torch.autograd.Function):
+    """logits = x W^T + b for the V-sized output head (mlm.py:24, :46) on the bf16-operand GEMMs: forward reads the
+    bf16 twin of x written by the last LayerNorm and the cached weight copy; backward reads the bf16 twin of dlogits
+    written by the token-CE kernel (a cast pass otherwise): dx on the NT kernel, dW = dlogits^T x on the transposed-
+    read kernel -- the 184 MB fp32 logits gradient is never re-read as a GEMM operand."""
+
+    @staticmethod
+    def forward(ctx, x, W, b):
+        T, d = x.shape
+        V = W.shape[0]
+        xb = _side_take(x)
+        if xb is None:
+            xb = cast_bf16(x, want_t=False)[0]
+        Wb, Wt = weight_bf16(W)
+        logits = gemm_bf16(xb, Wb, T, V, C=torch.empty(T, V, device=x.device, dtype=torch.float32), bias=b)
+        ctx.save_for_backward(xb, Wt)
+        ctx.cfg = (T, d, V, b is not None)
+        return logits
+
+    @staticmethod
+    def backward(ctx, dl):
+        xb, Wt = ctx.saved_tensors
+        T, d, V, has_b = ctx.cfg
+        dl = dl.contiguous()
+        dlb = _side_take(dl)
+        if dlb is None:
+            dlb = cast_bf16(dl, want_t=False)[0]
+        dx = gemm_bf16(dlb, Wt, T, d, C=torch.empty(T, d, device=dl.device, dtype=torch.float32)) if ctx.needs_input_grad[0] else None
+        dW = gemm_bf16_tt(dlb, xb, V, d) if ctx.needs_input_grad[1] else None
+        db = colsum(dl) if (has_b and ctx.needs_input_grad[2]) else None
+        return dx, dW, db
+
+
+def vocab_proj(x, W, b=None):
+    """The MLM output head; bf16 mode with GEMM-friendly shapes only, the generic linear otherwise."""
+    T, d = x.shape
+    V = W.shape[0]
+    if not _STATE["f32"] and T % 64 == 0 and d % 64 == 0 and V % 8 == 0:
+        return VocabProjFn.apply(x, W, b)
+    return linear(x, W, b)
+
+
 def linear(x, W, b=None, act=0, drop=NO_DROP):
     return LinearFn.apply(x, W, b, act, drop)
 
