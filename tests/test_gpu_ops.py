@@ -681,3 +681,31 @@ def test_generator_teacher_forced_grads_with_and_without_bf16_twin(ops):
         a, b = grads[0][k], grads[1][k]
         err = (a - b).norm() / (b.norm() + 1e-12)
         assert err < 3e-2, (k, float(err))
+
+
+def test_vocab_proj_bf16_matches_linear(ops):
+    """The bf16 output head (with and without the producer-written twins) against the fp32-operand linear."""
+    T, d, V = 128, 64, 1000
+    x0, W0, b0, w = dev(rnd(T, d, seed=1)), dev(rnd(V, d, seed=2, scale=0.2)), dev(rnd(V, seed=3)), dev(rnd(T, V, seed=4))
+    res = []
+    for fn in (ops.linear, ops.vocab_proj):
+        ops.set_precision("f32" if fn is ops.linear else "bf16")
+        x, W, b = (t.clone().requires_grad_(True) for t in (x0, W0, b0))
+        y = fn(x, W, b)
+        (y * w).sum().backward()
+        res.append([y.detach(), x.grad, W.grad, b.grad])
+    ops.set_precision("bf16")
+    for a, r in zip(res[1], res[0]):
+        assert (a - r).norm() / r.norm() < 2e-2
+    # and through the token-CE twin: same gradients as without it
+    tgt = torch.randint(0, V, (T,), device="cuda")
+    grads = []
+    for use_twin in (True, False):
+        x, W, b = (t.clone().requires_grad_(True) for t in (x0, W0, b0))
+        loss = ops.token_ce(ops.vocab_proj(x, W, b), tgt, unit_grad=True)
+        if not use_twin:
+            ops._SIDE_BF16.clear()
+        loss.backward()
+        grads.append([x.grad, W.grad, b.grad])
+    for a, r in zip(*grads):
+        assert (a - r).norm() / (r.norm() + 1e-12) < 1e-2
