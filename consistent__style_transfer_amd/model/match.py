@@ -29,8 +29,9 @@ class Matcher(nn.Module):
         return ops.TpsEmbedFn.apply(tensor, None, self.token_embedding.weight, self.posit_embedding.weight, seg)
 
     def forward(self, x1, x2, seed=None):
+        pre1 = ops.shared_lookup(x1, self.token_embedding.weight) if x1.dim() == 3 else None
         x = ops.TpsEmbedFn.apply(x1, x2, self.token_embedding.weight, self.posit_embedding.weight,
-                                 self.segment_embedding.weight)
+                                 self.segment_embedding.weight, pre1)
         B, S, d = x.shape
         drop = make_drop(self, p_drop, seed)
         x = self.matcher.run(x.view(B * S, d), B, S, drop)

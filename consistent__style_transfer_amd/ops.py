@@ -625,7 +625,8 @@ class TpsEmbedFn(torch.autograd.Function):
     side by side on the sequence axis (mlm.py:27-38; match.py:24-39)."""
 
     @staticmethod
-    def forward(ctx, s1, s2, Etok, Epos, Eseg):
+    def forward(ctx, s1, s2, Etok, Epos, Eseg, pre1=None):
+        """pre1: probs(s1) @ Etok computed elsewhere (ops.shared_soft_embed); its gradient goes back to that node."""
         segs = [s for s in (s1, s2) if s is not None]
         B = segs[0].shape[0]
         V, d = Etok.shape
@@ -638,14 +639,18 @@ class TpsEmbedFn(torch.autograd.Function):
             if s.dim() == 2:
                 call("cst_tps_embed_fwd", _i64(s), None, Etok, Epos, seg_row, x, B, L, d, S, off, V)
             elif s.dim() == 3:
-                pre = torch.empty(B * L, d, device=Etok.device, dtype=torch.float32)
-                gemm(s.reshape(B * L, V), True, Etok, False, pre, B * L, d, V)
+                if i == 0 and pre1 is not None:
+                    pre = pre1.contiguous()
+                else:
+                    pre = torch.empty(B * L, d, device=Etok.device, dtype=torch.float32)
+                    gemm(s.reshape(B * L, V), True, Etok, False, pre, B * L, d, V)
                 call("cst_tps_embed_fwd", None, pre, Etok, Epos, seg_row, x, B, L, d, S, off, V)
             else:
                 raise Exception          # the reference's bare `raise Exception` (mlm.py:33, match.py:30)
             off += L
         ctx.save_for_backward(s1, s2, Etok)
         ctx.shape = (B, S, d, V, Epos.shape[0], Eseg is not None)
+        ctx.shared1 = pre1 is not None
         return x
 
     @staticmethod
@@ -659,6 +664,7 @@ class TpsEmbedFn(torch.autograd.Function):
         dEpos = torch.zeros(npos, d, device=dev, dtype=torch.float32) if wg else None
         dEseg = torch.zeros(2, d, device=dev, dtype=torch.float32) if (wg and has_seg) else None
         grads = [None, None]
+        dpre1 = None
         off = 0
         for i, s in enumerate((s1, s2)):
             if s is None:
@@ -671,6 +677,10 @@ class TpsEmbedFn(torch.autograd.Function):
             else:
                 dpre = torch.empty(B * L, d, device=dev, dtype=torch.float32)
                 call("cst_tps_embed_bwd", dx, None, dpre, None, dEpos, dseg_row, B, L, d, S, off, V)
+                if i == 0 and ctx.shared1:
+                    dpre1 = dpre                       # the shared soft-embedding node turns it into d probs (and d Etok)
+                    off += L
+                    continue
                 p2 = s.reshape(B * L, V)
                 if ctx.needs_input_grad[i]:
                     dp = torch.empty(B * L, V, device=dev, dtype=torch.float32)
@@ -679,7 +689,7 @@ class TpsEmbedFn(torch.autograd.Function):
                 if wg:
                     gemm(p2, False, dpre, False, dEtok, V, d, B * L, accumulate=True)
             off += L
-        return grads[0], grads[1], dEtok, dEpos, dEseg
+        return grads[0], grads[1], dEtok, dEpos, dEseg, dpre1
 
 
 class SeqMaxFn(torch.autograd.Function):
@@ -942,5 +952,93 @@ class SoftEmbedFn(torch.autograd.Function):
         return dp, dt, None
 
 
+class SharedSoftEmbedFn(torch.autograd.Function):
+    """One soft-embedding product for several consumers of the same probabilities (main_optimize.py:96-111: the
+    matcher, the classifier and the discriminator all embed sample_p): out_i = p @ table_i computed as ONE GEMM
+    against the column-concatenated tables -- the 184 MB distribution is read once instead of once per consumer --
+    and, backward, ONE product dp = [dout_1 | dout_2 | ...] @ [table_1 | table_2 | ...]^T instead of one V-wide
+    product per consumer plus autograd's pairwise adds of their (R, V) results."""
+
+    @staticmethod
+    def forward(ctx, p, evs, *tables):
+        R, V = p.shape
+        cols = [t.t() if ev else t for t, ev in zip(tables, evs)]          # each [V, E_i]
+        widths = [c.shape[1] for c in cols]
+        tcat = torch.cat(cols, dim=1)                                      # [V, sum E_i], contiguous
+        S = tcat.shape[1]
+        out = torch.empty(R, S, device=p.device, dtype=torch.float32)
+        gemm(p, True, tcat, False, out, R, S, V)
+        ctx.save_for_backward(p, tcat)
+        ctx.cfg = (widths, evs)
+        offs, o = [], 0
+        for w in widths:
+            offs.append(o)
+            o += w
+        return tuple(out[:, o:o + w] for o, w in zip(offs, widths))
+
+    @staticmethod
+    def backward(ctx, *douts):
+        p, tcat = ctx.saved_tensors
+        widths, evs = ctx.cfg
+        R, V = p.shape
+        S = tcat.shape[1]
+        dcat = torch.empty(R, S, device=p.device, dtype=torch.float32)
+        o = 0
+        for w, d in zip(widths, douts):
+            if d is None:
+                dcat[:, o:o + w].zero_()
+            else:
+                dcat[:, o:o + w].copy_(d)
+            o += w
+        dp = None
+        if ctx.needs_input_grad[0]:
+            dp = torch.empty(R, V, device=p.device, dtype=torch.float32)
+            gemm(dcat, True, tcat, True, dp, R, V, S)
+        dts = [None] * len(widths)
+        if any(ctx.needs_input_grad[2:]):
+            dt = torch.empty(V, S, device=p.device, dtype=torch.float32)
+            gemm(p, False, dcat, False, dt, V, S, R)
+            o = 0
+            for i, (w, ev) in enumerate(zip(widths, evs)):
+                if ctx.needs_input_grad[2 + i]:
+                    blk = dt[:, o:o + w]
+                    dts[i] = blk.t().contiguous() if ev else blk.contiguous()
+                o += w
+        return (dp, None, *dts)
+
+
+_SHARED_SOFT = {}
+
+
+class shared_soft_embed:
+    """with shared_soft_embed(p3d, [(table, table_is_ev), ...]): every soft_embed / token-position embedding of these
+    probabilities with one of these tables inside the block returns its slice of the one shared product."""
+
+    def __init__(self, p3d, specs):
+        self.p2d = p3d.reshape(-1, p3d.shape[-1])
+        self.specs = specs
+
+    def __enter__(self):
+        tables = [t for t, _ in self.specs]
+        outs = SharedSoftEmbedFn.apply(self.p2d, tuple(bool(ev) for _, ev in self.specs), *tables)
+        for t, o in zip(tables, outs):
+            _SHARED_SOFT[(self.p2d.data_ptr(), id(t))] = o
+        return self
+
+    def __exit__(self, *exc):
+        _SHARED_SOFT.clear()
+        return False
+
+
+def shared_lookup(p, table):
+    """The shared product's slice for probabilities `p` (any view of the registered tensor) and `table`, or None."""
+    if not _SHARED_SOFT or p is None or p.dim() < 2:
+        return None
+    return _SHARED_SOFT.get((p.data_ptr(), id(table)))
+
+
 def soft_embed(p2d, table, table_is_ev=False):
+    hit = shared_lookup(p2d, table)
+    if hit is not None:
+        return hit
     return SoftEmbedFn.apply(p2d, table, table_is_ev)

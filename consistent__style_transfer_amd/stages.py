@@ -207,7 +207,10 @@ class OptimizeStage(nn.Module):
 
         if not hasattr(self, "_fork"):
             self._fork = Fork(4)
-        bk_loss, (c_logits, c_loss), s_loss, g_loss = self._fork.run([f_bk, f_mat, f_cls, f_adv])
+        # the three critics embed the same sample_p: one shared product (and one shared d sample_p) instead of three
+        with ops.shared_soft_embed(sample_p, [(self.matcher.token_embedding.weight, False), (self.classifier.embedding.weight, False),
+                                              (self.disc.embeddings.weight, True)]):
+            bk_loss, (c_logits, c_loss), s_loss, g_loss = self._fork.run([f_bk, f_mat, f_cls, f_adv])
         self.disc.train(was_training)
         loss = bk_loss + self.wc * c_loss + self.w_adv * g_loss + self.ws * s_loss
         return {"loss": loss, "G": g_loss, "STI": s_loss, "CP_logits": c_logits, "BK": bk_loss / self.w_bt if self.w_bt else bk_loss,
