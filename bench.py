@@ -214,7 +214,7 @@ def main():
         torch.cuda.synchronize()
 
     if os.environ.get("CST_FORCE_SEGMENTS") and reducer is None:
-        reducer = lambda groups: None                  # single-GPU rehearsal of the segmented (N > 1) launch path
+        reducer = lambda groups, defer=False: None     # single-GPU rehearsal of the segmented (N > 1) launch path
     use_graph = not args.no_graph
     if use_graph:
         pipe = GraphedPipeline(stages_, batches, reducer)

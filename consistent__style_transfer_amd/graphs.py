@@ -63,10 +63,10 @@ class GraphedStep:
         pool = torch.cuda.graph_pool_handle()
         cur = [torch.cuda.CUDAGraph()]
 
-        def hook(groups):
+        def hook(groups, defer=False):
             cur[0].capture_end()
             self.graphs.append(cur[0])
-            self.points.append(list(groups))              # nothing has run during capture: nothing to reduce yet
+            self.points.append((list(groups), defer))     # nothing has run during capture: nothing to reduce yet
             cur[0] = torch.cuda.CUDAGraph()
             cur[0].capture_begin(pool=pool)
 
@@ -91,5 +91,6 @@ class GraphedStep:
         for i, g in enumerate(self.graphs):
             g.replay()
             if i < len(self.points):
-                self.reducer(self.points[i])
+                groups, defer = self.points[i]
+                self.reducer(groups, defer) if defer else self.reducer(groups)
         return self.static_out

@@ -53,18 +53,21 @@ class GradReducer:
         self.world = world
         self.bucket = bucket_elems
         self.avg = dist.is_initialized() and dist.get_backend() == "nccl"
+        self._pending = []
 
-    def __call__(self, groups):
+    def __call__(self, groups, defer=False):
+        """defer=True (RCCL only): start the collectives and return -- they run on RCCL's stream next to whatever the
+        caller launches next (the next critic's forward/backward); the next non-deferred call, or wait(), makes the
+        current stream wait for everything outstanding."""
         if self.world == 1:
             return
         if self.avg:
-            works = []
             for g in groups:
                 flat = g.flat_g
                 for s in range(0, flat.numel(), self.bucket):
-                    works.append(dist.all_reduce(flat[s:s + self.bucket], op=dist.ReduceOp.AVG, async_op=True))
-            for w in works:
-                w.wait()
+                    self._pending.append(dist.all_reduce(flat[s:s + self.bucket], op=dist.ReduceOp.AVG, async_op=True))
+            if not defer:
+                self.wait()
             return
         # gloo (CPU tests, single-GPU rehearsals): no AVG and no device tensors -> stage through the host
         for g in groups:
@@ -77,6 +80,11 @@ class GradReducer:
             host.div_(self.world)
             if flat.is_cuda:
                 flat.copy_(host)
+
+    def wait(self):
+        for w in self._pending:
+            w.wait()
+        self._pending = []
 
 
 def max_over_ranks(value, device):

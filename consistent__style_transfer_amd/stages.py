@@ -105,22 +105,38 @@ class PretrainStage(nn.Module):
         return s, c, dn
 
     def train_step(self, batch, seed=None, reducer=None):
-        s, c, dn = self.losses(batch, seed)
-        terms = [t for t in (s, c, dn) if t is not None]
-        total = terms[0]
-        for t in terms[1:]:
-            total = total + t
-        total.backward()
+        """The three critics share nothing, so each runs forward + backward + gradient gather on its own and, under data
+        parallelism, its all-reduce is started right away (deferred) while the next critic computes; only the last
+        reducer call waits for all of them before the global-norm clip."""
+        x, nx_1, nx_2, nx, label, c_label = batch
+        order = [k for k in ("dn", "mat", "cls") if self.flags[k]]            # largest gradient buffers first
+        vals = {"dn": None, "mat": None, "cls": None}
+        for i, k in enumerate(order):
+            if k == "dn":
+                lg = self.denoiser(nx, seed=seed)
+                loss = ops.token_ce(lg.view(-1, lg.size(-1)), x.reshape(-1), unit_grad=True)
+            elif k == "mat":
+                loss = ops.mse_loss(self.matcher(nx_1, nx_2, seed=seed), c_label)
+            else:
+                loss = ops.token_ce(self.classifier(x, seed=seed), label)
+            loss.backward()
+            vals[k] = loss.detach()
+            self.groups[k].gather_grads(False)
+            if reducer is not None:
+                if i + 1 < len(order):
+                    reducer([self.groups[k]], True)
+                else:
+                    reducer([self.groups[k]])
         live = [self.groups[k] for k in self.flags if self.flags[k]]
-        for g in live:
-            g.gather_grads(False)
-        if reducer is not None:
-            reducer(live)
         clip_groups(live, self.clip, self._scratch)
         for g in live:
             g.step()
             g.zero_grad()
-        return {"s_loss": s, "c_loss": c, "dn_loss": dn, "loss": total}
+        total = None
+        for k in ("cls", "mat", "dn"):
+            if vals[k] is not None:
+                total = vals[k] if total is None else total + vals[k]
+        return {"s_loss": vals["cls"], "c_loss": vals["mat"], "dn_loss": vals["dn"], "loss": total}
 
 
 class WarmupStage(nn.Module):
