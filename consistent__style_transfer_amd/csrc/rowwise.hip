@@ -450,6 +450,7 @@ extern "C" int cst_argmax_rows_gather(const float* x, long ld, int R, int V, int
 // z = res + dropout(x) ; y = LayerNorm(z) * gamma + beta.   One wavefront per row of d <= 1024.
 // ---------------------------------------------------------------------------------------------
 #define LN_MAXE 16
+template <int NE>
 __global__ __launch_bounds__(256) void add_layernorm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ res,
                                                                 const float* __restrict__ gamma, const float* __restrict__ beta,
                                                                 float eps, float* z, float* __restrict__ y,
@@ -460,10 +461,10 @@ __global__ __launch_bounds__(256) void add_layernorm_fwd_kernel(const float* __r
     const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= T) return;
     const uint32_t dseed = drop.p > 0.f ? cst_drop_seed(drop) : 0u;
-    float v[LN_MAXE];
+    float v[NE];
     float s = 0.f;
 #pragma unroll
-    for (int i = 0; i < LN_MAXE; ++i) {
+    for (int i = 0; i < NE; ++i) {
         const int c = lane + 64 * i;
         float t = 0.f;
         if (c < d) {
@@ -477,14 +478,14 @@ __global__ __launch_bounds__(256) void add_layernorm_fwd_kernel(const float* __r
     const float mu = wave_sum(s) / (float)d;
     float q = 0.f;
 #pragma unroll
-    for (int i = 0; i < LN_MAXE; ++i) {
+    for (int i = 0; i < NE; ++i) {
         const int c = lane + 64 * i;
         const float t = (c < d) ? v[i] - mu : 0.f;
         q += t * t;
     }
     const float rs = 1.0f / sqrtf(wave_sum(q) / (float)d + eps);
 #pragma unroll
-    for (int i = 0; i < LN_MAXE; ++i) {
+    for (int i = 0; i < NE; ++i) {
         const int c = lane + 64 * i;
         if (c < d) {
             if (z) z[row * d + c] = v[i];
@@ -504,8 +505,11 @@ extern "C" int cst_add_layernorm_fwd_b(const float* x, const float* res, const f
     CST_REQUIRE(T > 0 && d > 0 && d <= 64 * LN_MAXE, "cst_add_layernorm_fwd: d=%d unsupported (max %d)", d, 64 * LN_MAXE);
     CST_REQUIRE(!y_bf16 || ldyb >= d, "cst_add_layernorm_fwd: bf16 leading dimension < d");
     CstDrop dr = cst_make_drop(drop_p, drop_seed, drop_stream, drop_seed_dev);
-    hipLaunchKernelGGL(add_layernorm_fwd_kernel, dim3(cst_div_up(T, 4)), dim3(256), 0, (hipStream_t)stream,
-                       x, res, gamma, beta, eps, z, y, mean, rstd, T, d, dr, (unsigned short*)y_bf16, ldyb);
+#define LN_FWD(NEV) hipLaunchKernelGGL(add_layernorm_fwd_kernel<NEV>, dim3(cst_div_up(T, 4)), dim3(256), 0, (hipStream_t)stream, \
+                                       x, res, gamma, beta, eps, z, y, mean, rstd, T, d, dr, (unsigned short*)y_bf16, ldyb)
+    const int ne = cst_div_up(d, 64);
+    if (ne <= 4) LN_FWD(4); else if (ne <= 8) LN_FWD(8); else if (ne <= 12) LN_FWD(12); else LN_FWD(16);
+#undef LN_FWD
     CST_LAUNCH_CHECK("cst_add_layernorm_fwd");
     return CST_OK;
 }
@@ -520,24 +524,27 @@ extern "C" int cst_add_layernorm_fwd(const float* x, const float* res, const flo
 
 // backward: dz = rstd * (g - mean(g) - xhat * mean(g * xhat)), g = dy * gamma;
 // per-block partial column sums of dy*xhat (dgamma) and dy (dbeta) go to part[2][nblk][d].
+template <int NE>      // NE = ceil(d / 64) column groups per lane: arrays sized for the actual width, not for the 1024 maximum
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ z,
                                                             const float* __restrict__ mean, const float* __restrict__ rstd,
                                                             const float* __restrict__ gamma, float* dz,
                                                             float* __restrict__ part, int T, int d, int rows_per_block,
-                                                            unsigned short* __restrict__ dzb, long lddzb, CstDrop bdrop) {
-    __shared__ float sh[2][4][64 * LN_MAXE / 4];      // only used for d <= 256 per pass; see loop below
+                                                            unsigned short* __restrict__ dzb, long lddzb, CstDrop bdrop, int three) {
+    // three != 0: a third partial, the column sums of dropout'(dz) (the bias gradient of the Linear in front of this
+    // LayerNorm), and the partials laid out [block][3][d] so that ONE column-sum launch finishes all three
+    __shared__ float sh[3][4][256];      // only used for d <= 256 per pass; see loop below
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    float ag[LN_MAXE], ab[LN_MAXE];
+    float ag[NE], ab[NE], az[NE];
 #pragma unroll
-    for (int i = 0; i < LN_MAXE; ++i) { ag[i] = 0.f; ab[i] = 0.f; }
+    for (int i = 0; i < NE; ++i) { ag[i] = 0.f; ab[i] = 0.f; az[i] = 0.f; }
     const long r0 = (long)blockIdx.x * rows_per_block;
     const uint32_t bseed = (dzb && bdrop.p > 0.f) ? cst_drop_seed(bdrop) : 0u;
     for (long row = r0 + w; row < r0 + rows_per_block && row < T; row += 4) {
         const float mu = mean[row], rs = rstd[row];
-        float xh[LN_MAXE], g[LN_MAXE];
+        float xh[NE], g[NE];
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-        for (int i = 0; i < LN_MAXE; ++i) {
+        for (int i = 0; i < NE; ++i) {
             const int c = lane + 64 * i;
             if (c < d) {
                 const float dyv = dy[row * d + c];
@@ -549,7 +556,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
         }
         s1 = wave_sum(s1) / (float)d; s2 = wave_sum(s2) / (float)d;
 #pragma unroll
-        for (int i = 0; i < LN_MAXE; ++i) {
+        for (int i = 0; i < NE; ++i) {
             const int c = lane + 64 * i;
             if (c < d) {
                 const float dv = rs * (g[i] - s1 - xh[i] * s2);
@@ -559,25 +566,37 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
                     if (bdrop.p > 0.f) t *= cst_drop_mask(bdrop, bseed, (uint32_t)(row * d + c));
                     __bf16 h = (__bf16)t;
                     dzb[row * lddzb + c] = __builtin_bit_cast(unsigned short, h);
+                    az[i] += t;
                 }
             }
         }
     }
     // reduce the 4 waves' partial sums through LDS, 4 column groups (of 64) at a time
     const long nblk = gridDim.x;
-    for (int i0 = 0; i0 < LN_MAXE; i0 += 4) {
+#pragma unroll
+    for (int i0 = 0; i0 < NE; i0 += 4) {
         if (i0 * 64 >= d) break;
         __syncthreads();
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { sh[0][w][i * 64 + lane] = ag[i0 + i]; sh[1][w][i * 64 + lane] = ab[i0 + i]; }
+        for (int i = 0; i < 4; ++i) {
+            if (i0 + i < NE) {
+                sh[0][w][i * 64 + lane] = ag[i0 + i]; sh[1][w][i * 64 + lane] = ab[i0 + i]; sh[2][w][i * 64 + lane] = az[i0 + i];
+            }
+        }
         __syncthreads();
         // 256 threads <-> 256 columns of this pass
         const int c = i0 * 64 + threadIdx.x;
         if (c < d) {
             const float sg = (sh[0][0][threadIdx.x] + sh[0][1][threadIdx.x]) + (sh[0][2][threadIdx.x] + sh[0][3][threadIdx.x]);
             const float sb = (sh[1][0][threadIdx.x] + sh[1][1][threadIdx.x]) + (sh[1][2][threadIdx.x] + sh[1][3][threadIdx.x]);
-            part[(0 * nblk + blockIdx.x) * d + c] = sg;
-            part[(1 * nblk + blockIdx.x) * d + c] = sb;
+            if (three) {
+                const float sz = (sh[2][0][threadIdx.x] + sh[2][1][threadIdx.x]) + (sh[2][2][threadIdx.x] + sh[2][3][threadIdx.x]);
+                float* pr = part + (long)blockIdx.x * 3 * d;
+                pr[c] = sg; pr[d + c] = sb; pr[2 * d + c] = sz;
+            } else {
+                part[(0 * nblk + blockIdx.x) * d + c] = sg;
+                part[(1 * nblk + blockIdx.x) * d + c] = sb;
+            }
         }
     }
 }
@@ -634,18 +653,25 @@ extern "C" int cst_layernorm_bwd_b(const float* dy, const float* z, const float*
                                    float* dz, float* dgamma, float* dbeta, int accumulate,
                                    float* workspace, long workspace_floats, int T, int d,
                                    void* dz_bf16, long lddzb, float drop_p, uint32_t drop_seed, uint32_t drop_stream, const void* drop_seed_dev,
-                                   void* stream) {
+                                   float* dparams3, void* stream) {
     CST_REQUIRE(dy && z && mean && rstd && gamma && dz && workspace, "cst_layernorm_bwd: null pointer");
     CST_REQUIRE(T > 0 && d > 0 && d <= 64 * LN_MAXE, "cst_layernorm_bwd: d=%d unsupported", d);
     CST_REQUIRE(!dz_bf16 || lddzb >= d, "cst_layernorm_bwd: bf16 leading dimension < d");
+    CST_REQUIRE(!dparams3 || dz_bf16, "cst_layernorm_bwd: the fused bias gradient needs the bf16 output");
     const int nblk = T < 4096 ? cst_div_up(T, 4) : 1024;      // one row per wave per pass: latency hidden by occupancy
-    CST_REQUIRE(workspace_floats >= 2L * nblk * d, "cst_layernorm_bwd: workspace too small (%ld < %ld)", workspace_floats, 2L * nblk * d);
+    const long need = (dparams3 ? 3L : 2L) * nblk * d;
+    CST_REQUIRE(workspace_floats >= need, "cst_layernorm_bwd: workspace too small (%ld < %ld)", workspace_floats, need);
     const int rpb = cst_div_up(T, nblk);
     hipStream_t st = (hipStream_t)stream;
     CstDrop bd = cst_make_drop(drop_p, drop_seed, drop_stream, drop_seed_dev);
-    hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(nblk), dim3(256), 0, st, dy, z, mean, rstd, gamma, dz, workspace, T, d, rpb,
-                       (unsigned short*)dz_bf16, lddzb, bd);
+#define LN_BWD(NEV) hipLaunchKernelGGL(layernorm_bwd_kernel<NEV>, dim3(nblk), dim3(256), 0, st, dy, z, mean, rstd, gamma, dz, workspace, T, d, rpb, \
+                                       (unsigned short*)dz_bf16, lddzb, bd, dparams3 ? 1 : 0)
+    const int ne = cst_div_up(d, 64);
+    if (ne <= 4) LN_BWD(4); else if (ne <= 8) LN_BWD(8); else if (ne <= 12) LN_BWD(12); else LN_BWD(16);
+#undef LN_BWD
     CST_LAUNCH_CHECK("cst_layernorm_bwd");
+    if (dparams3)                                         // (dgamma | dbeta | dbias) in one pass over [nblk, 3d]
+        return cst_colsum(workspace, 3L * d, nblk, 3 * d, dparams3, accumulate, stream);
     if (dgamma) {
         int rc = cst_colsum(workspace, d, nblk, d, dgamma, accumulate, stream);
         if (rc) return rc;
@@ -661,7 +687,7 @@ extern "C" int cst_layernorm_bwd(const float* dy, const float* z, const float* m
                                  float* dz, float* dgamma, float* dbeta, int accumulate,
                                  float* workspace, long workspace_floats, int T, int d, void* stream) {
     return cst_layernorm_bwd_b(dy, z, mean, rstd, gamma, dz, dgamma, dbeta, accumulate, workspace, workspace_floats, T, d,
-                               nullptr, 0, 0.f, 0, 0, nullptr, stream);
+                               nullptr, 0, 0.f, 0, 0, nullptr, nullptr, stream);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -429,13 +429,15 @@ def _ln_bwd(dy, z, mean, rstd, gamma, want_param_grads, dzb_drop=None):
     T, d = dy.shape
     dz = torch.empty_like(dy)
     if dzb_drop is not None:
-        nws = call_plain("cst_layernorm_bwd_workspace_floats", T, d)
+        nws = call_plain("cst_layernorm_bwd_workspace_floats", T, d) * 3 // 2
         ws = torch.empty(nws, device=dy.device, dtype=torch.float32)
-        dg = torch.empty(d, device=dy.device, dtype=torch.float32) if want_param_grads else None
-        db = torch.empty(d, device=dy.device, dtype=torch.float32) if want_param_grads else None
         dzb = torch.empty(T, d, device=dy.device, dtype=torch.int16)
-        call("cst_layernorm_bwd_b", dy, z, mean, rstd, gamma, dz, dg, db, 0, ws, nws, T, d, dzb, d, *dzb_drop.args())
-        return dz, dg, db, dzb
+        if want_param_grads:
+            p3 = torch.empty(3 * d, device=dy.device, dtype=torch.float32)         # dgamma | dbeta | bias gradient of the Linear in front
+            call("cst_layernorm_bwd_b", dy, z, mean, rstd, gamma, dz, None, None, 0, ws, nws, T, d, dzb, d, *dzb_drop.args(), p3)
+            return dz, p3[:d], p3[d:2 * d], dzb, p3[2 * d:]
+        call("cst_layernorm_bwd_b", dy, z, mean, rstd, gamma, dz, None, None, 0, ws, nws, T, d, dzb, d, *dzb_drop.args(), None)
+        return dz, None, None, dzb, None
     nws = call_plain("cst_layernorm_bwd_workspace_floats", T, d)
     ws = torch.empty(nws, device=dy.device, dtype=torch.float32)
     dg = torch.empty(d, device=dy.device, dtype=torch.float32) if want_param_grads else None
@@ -572,7 +574,7 @@ class EncoderLayerBf16Fn(torch.autograd.Function):
         new = lambda *s: torch.empty(*s, device=dev, dtype=torch.float32)
         dy2 = dy2.contiguous()
         if fuse_b:
-            dz2, dn2w, dn2b, dfb = _ln_bwd(dy2, z2, m2, r2, n2_w, wg, dzb_drop=drop.at(sb + 3))   # bf16(dropout2'(dz2)) from the LN kernel
+            dz2, dn2w, dn2b, dfb, dl2b_f = _ln_bwd(dy2, z2, m2, r2, n2_w, wg, dzb_drop=drop.at(sb + 3))   # bf16(dropout2'(dz2)) from the LN kernel
             dft = None
         else:
             dz2, dn2w, dn2b = _ln_bwd(dy2, z2, m2, r2, n2_w, wg)
@@ -582,7 +584,7 @@ class EncoderLayerBf16Fn(torch.autograd.Function):
         gemm_bf16(dfb, l2_t, T, F, Cb=dhb, aux=hb, act=3, gate_scale=drop.scale)       # relu' and dropout' fused
         dy1 = gemm_bf16(dhb, l1_t, T, d, C=new(T, d), addend=dz2)
         if fuse_b:
-            dz1, dn1w, dn1b, dob = _ln_bwd(dy1, z1, m1, r1, n1_w, wg, dzb_drop=drop.at(sb + 1))
+            dz1, dn1w, dn1b, dob, doutb_f = _ln_bwd(dy1, z1, m1, r1, n1_w, wg, dzb_drop=drop.at(sb + 1))
             dot = None
         else:
             dz1, dn1w, dn1b = _ln_bwd(dy1, z1, m1, r1, n1_w, wg)
@@ -609,9 +611,12 @@ class EncoderLayerBf16Fn(torch.autograd.Function):
                 dl1w = gemm_bf16(dht, wy1, F, d, C=new(F, d))
                 doutw = gemm_bf16(dot, watt, d, d, C=new(d, d))
                 dinw = gemm_bf16(dqt, wx, 3 * d, d, C=new(3 * d, d))
-            dl2b = colsum_bf16(dfb, d) if drop.p > 0 else colsum(dz2)
+            if fuse_b:                                    # finished by the LayerNorm backward's own column-sum pass
+                dl2b, doutb = dl2b_f, doutb_f
+            else:
+                dl2b = colsum_bf16(dfb, d) if drop.p > 0 else colsum(dz2)
+                doutb = colsum_bf16(dob, d) if drop.p > 0 else colsum(dz1)
             dl1b = colsum_bf16(dhb, F)
-            doutb = colsum_bf16(dob, d) if drop.p > 0 else colsum(dz1)
             dinb = colsum(dqkv)
         return (dx, dinw, dinb, doutw, doutb, dl1w, dl1b, dl2w, dl2b, dn1w, dn1b, dn2w, dn2b,
                 None, None, None, None, None)

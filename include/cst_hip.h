@@ -134,12 +134,14 @@ int cst_layernorm_bwd(const float* dy, const float* z, const float* mean, const 
                       float* dz, float* dgamma, float* dbeta, int accumulate,
                       float* workspace, long workspace_floats, int T, int d, void* stream);
 /* _b: also dz_bf16 = bf16(dropout'(dz)) with the given dropout descriptor (element index row*d + c): the gradient that
- * flows through the dropout in front of the residual add, as the GEMMs behind this LayerNorm consume it. */
+ * flows through the dropout in front of the residual add, as the GEMMs behind this LayerNorm consume it.
+ * dparams3 (optional, [3d]): (dgamma | dbeta | column sums of dropout'(dz) = the bias gradient of the Linear in front of the
+ * LayerNorm) finished by ONE column-sum pass; needs 3*nblk*d workspace floats (1.5x cst_layernorm_bwd_workspace_floats). */
 int cst_layernorm_bwd_b(const float* dy, const float* z, const float* mean, const float* rstd, const float* gamma,
                         float* dz, float* dgamma, float* dbeta, int accumulate,
                         float* workspace, long workspace_floats, int T, int d,
                         void* dz_bf16, long lddzb, float drop_p, uint32_t drop_seed, uint32_t drop_stream, const void* drop_seed_dev,
-                        void* stream);
+                        float* dparams3, void* stream);
 /* out[c] (+)= sum_r X[r,c]  (bias gradients). */
 int cst_colsum(const float* X, long ld, int M, int N, float* out, int accumulate, void* stream);
 /* out[0] (+)= scale * sum(in[0..n)), one block, deterministic. */
