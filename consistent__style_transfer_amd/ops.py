@@ -333,8 +333,9 @@ class LinearFn(torch.autograd.Function):
         return dx, dW, db, None, None
 
 
-class VocabProjFn(torch.autograd.Function):
-    """logits = x W^T + b for the V-sized output head (mlm.py:24, :46) on the bf16-operand GEMMs: forward reads the
+class LinearBf16Fn(torch.autograd.Function):
+    """y = x W^T + b on the bf16-operand GEMMs -- the V-sized output head (mlm.py:24, :46) and other plain Linears with
+    many rows (RelGAN_D's highway, discriminator.py:46): forward reads the
     bf16 twin of x written by the last LayerNorm and the cached weight copy; backward reads the bf16 twin of dlogits
     written by the token-CE kernel (a cast pass otherwise): dx on the NT kernel, dW = dlogits^T x on the transposed-
     read kernel -- the 184 MB fp32 logits gradient is never re-read as a GEMM operand."""
@@ -371,11 +372,19 @@ def vocab_proj(x, W, b=None):
     T, d = x.shape
     V = W.shape[0]
     if not _STATE["f32"] and T % 64 == 0 and d % 64 == 0 and V % 8 == 0:
-        return VocabProjFn.apply(x, W, b)
+        return LinearBf16Fn.apply(x, W, b)
     return linear(x, W, b)
 
 
+def _big_plain_linear(x, W, act, drop):
+    """Plain (no activation / dropout) Linear with enough rows to pay for bf16 operand copies: the RelGAN_D highway."""
+    M, K = x.shape
+    return (not _STATE["f32"]) and act == 0 and drop.p <= 0 and M >= 1024 and M % 64 == 0 and K % 8 == 0 and W.shape[0] % 8 == 0
+
+
 def linear(x, W, b=None, act=0, drop=NO_DROP):
+    if _big_plain_linear(x, W, act, drop):
+        return LinearBf16Fn.apply(x, W, b)          # same three bf16 products: forward NT, dgrad NT, weight gradient TT
     return LinearFn.apply(x, W, b, act, drop)
 
 
