@@ -244,7 +244,7 @@ class GeneratorFn(torch.autograd.Function):
         ctx.cfg = (B, Lp, T, V, E, H, Hd, soft, inv_tau, drop, in_drop, inp.dim() == 3, use_b)
         ctx.save_for_backward(*params, emb, ids_in, label_i, label, h0cat, memory, hprev, genc, cenc, c_cat, c0,
                               wcat, XH, gdec, cdec, iffn, iffn_d, patt, r1, out, ids_fb, x_c, coins, zeros_c,
-                              inp if inp.dim() == 3 else None, wcat_t, r1b)
+                              inp if inp.dim() == 3 else None, wcat_t, r1b, XHb, ifdb)
         ctx.mark_non_differentiable(ids_fb)
         return out, ids_fb
 
@@ -255,7 +255,7 @@ class GeneratorFn(torch.autograd.Function):
         n = len(PARAM_KEYS)
         P = dict(zip(PARAM_KEYS, sv[:n]))
         (emb, ids_in, label_i, label, h0cat, memory, hprev, genc, cenc, c_cat, c0, wcat, XH, gdec, cdec, iffn,
-         iffn_d, patt, r1, out, ids_fb, x_c, coins, zeros_c, inp3, wcat_t, r1b) = sv[n:]
+         iffn_d, patt, r1, out, ids_fb, x_c, coins, zeros_c, inp3, wcat_t, r1b, XHb, ifdb) = sv[n:]
         dev = dout.device
         E_tok = P["token_embedding.weight"]
         dout = dout.contiguous()                      # (B,T,V); in softmax mode rewritten in place to dlogits
@@ -273,29 +273,31 @@ class GeneratorFn(torch.autograd.Function):
         diffn_all = _new(dev, B, T, W_)
         df2 = diffn_all.view(B, T * W_)
         Vp = (V + 63) // 64 * 64
-        fn1_t = fn2_t = dgdb = dlb_all = None
+        fn1_t = fn2_t = dgdb_all = dp1b_all = dlb_all = None
         if use_b:
             fn1_t = weight_bf16(P["fn_1.weight"])[1]                # [W_, Hd]
             fn2_t = weight_bf16(P["fn_2.weight"])[1]                # [Hd, up64(V)]
-            dgdb = _i16(dev, B, 4 * Hd)
+            dgdb_all = _i16(dev, T, B, 4 * Hd)                      # bf16 dgates of every step: dgrad operand now, wgrad operand later
+            dp1b_all = _i16(dev, B, T * Hd)                         # bf16 d(fn_1 pre-activation), same role
             if soft:
                 # bf16 dlogits of ALL steps (softmax backward writes slice s): per-step dgrad operand now, operand of
                 # the fn_2 weight gradient after the loop; only the K-padding columns need zeroing
                 dlb_all = _i16(dev, B, T * Vp)
                 if Vp != V:
                     dlb_all.view(B, T, Vp)[:, :, V:].zero_()
-                dp1b = _i16(dev, B, Hd)
             else:
                 dlb_all = ops._side_take(dout)                       # written by the token-CE kernel next to dlogits
                 if dlb_all is not None:
                     dlb_all = dlb_all.view(B, T * Vp)
+        dp1b_ok = soft and use_b                          # dp1b_all holds every step's bf16 d(fn_1 pre-activation) after the loop
         if not soft:
             # all dlogits are known up front (token CE): one large dgrad through fn_2 (+LeakyReLU gate)
             # and one through fn_1 instead of T small ones
             if dlb_all is not None:
-                dp1b_all = _i16(dev, B * T, Hd)
-                gemm_bf16(dlb_all.view(B * T, Vp), fn2_t, B * T, Hd, C=dpre1.view(B * T, Hd), Cb=dp1b_all, aux=r1b.view(B * T, Hd), act=4)
-                gemm_bf16(dp1b_all, fn1_t, B * T, W_, C=diffn_all.view(B * T, W_))
+                gemm_bf16(dlb_all.view(B * T, Vp), fn2_t, B * T, Hd, C=dpre1.view(B * T, Hd), Cb=dp1b_all.view(B * T, Hd),
+                          aux=r1b.view(B * T, Hd), act=4)
+                gemm_bf16(dp1b_all.view(B * T, Hd), fn1_t, B * T, W_, C=diffn_all.view(B * T, W_))
+                dp1b_ok = True
             else:
                 dgrad(dout.view(B * T, V), P["fn_2.weight"], out=dpre1.view(B * T, Hd), aux=r1.view(B * T, Hd), act=4)
                 dgrad(dpre1.view(B * T, Hd), P["fn_1.weight"], out=diffn_all.view(B * T, W_))
@@ -314,11 +316,11 @@ class GeneratorFn(torch.autograd.Function):
                 c_prev = c0 if s == 0 else cdec[s - 1]
                 diffn = df2[:, s * W_:(s + 1) * W_]
                 if s == T - 1:
-                    _cell_bwd(gdec[s], c_prev, cdec[s], diffn[:, :Hd], None, None, dgd[s], dc, B, Hd, dgb=dgdb)
+                    _cell_bwd(gdec[s], c_prev, cdec[s], diffn[:, :Hd], None, None, dgd[s], dc, B, Hd, dgb=dgdb_all[s])
                 else:
-                    _gemm_cell_bwd([dict(Ab=dgdb, Bb=wcat_t, gates=gdec[s], c_prev=c_prev, c_new=cdec[s], dh_extra=diffn[:, :Hd],
-                                         dc_in=dc, dgates=dgd[s], dc_prev=dc, dgb=dgdb, n_extra=E, extra_out=dXH_all[s + 1][:, :E])], B, Hd)
-            gemm_bf16(dgdb, wcat_t, B, E + Hd, C=dXH_all[0])
+                    _gemm_cell_bwd([dict(Ab=dgdb_all[s + 1], Bb=wcat_t, gates=gdec[s], c_prev=c_prev, c_new=cdec[s], dh_extra=diffn[:, :Hd],
+                                         dc_in=dc, dgates=dgd[s], dc_prev=dc, dgb=dgdb_all[s], n_extra=E, extra_out=dXH_all[s + 1][:, :E])], B, Hd)
+            gemm_bf16(dgdb_all[0], wcat_t, B, E + Hd, C=dXH_all[0])
         for s in (() if steps_fused else range(T - 1, -1, -1)):
             dl = dout2[:, s * V:(s + 1) * V]
             dXH = dXH_all[s + 1] if s + 1 < T else None        # written by step s+1's dgrad below
@@ -341,6 +343,7 @@ class GeneratorFn(torch.autograd.Function):
                 r1s = r12[:, s * Hd:(s + 1) * Hd]
                 dp1s = dp12[:, s * Hd:(s + 1) * Hd]
                 if use_b:
+                    dp1b = dp1b_all[:, s * Hd:(s + 1) * Hd]
                     gemm_bf16(dlb, fn2_t, B, Hd, C=dp1s, Cb=dp1b, aux=r1b[:, s * Hd:(s + 1) * Hd], act=4)   # through LeakyReLU
                     gemm_bf16(dp1b, fn1_t, B, W_, C=diffn, drop=fd)                                          # through dropout(i_ffn)
                 else:
@@ -353,9 +356,9 @@ class GeneratorFn(torch.autograd.Function):
             c_prev = c0 if s == 0 else cdec[s - 1]
             last = s == T - 1
             _cell_bwd(gdec[s], c_prev, cdec[s], diffn[:, :Hd], None if last else dXH[:, E:], None if last else dc,
-                      dgd[s], dc, B, Hd, dgb=dgdb if use_b else None)
+                      dgd[s], dc, B, Hd, dgb=dgdb_all[s] if use_b else None)
             if use_b:
-                gemm_bf16(dgdb, wcat_t, B, E + Hd, C=dXH_all[s])
+                gemm_bf16(dgdb_all[s], wcat_t, B, E + Hd, C=dXH_all[s])
             else:
                 dgrad(dgd[s], wcat, out=dXH_all[s])
         # embedding gradients of the tokens fed to steps 1..T-1, all steps in one scatter
@@ -385,10 +388,17 @@ class GeneratorFn(torch.autograd.Function):
         else:
             G["fn_2.weight"] = wgrad(dout.view(B * T, V), r1.view(B * T, Hd))
         dp1 = dpre1.view(B * T, Hd)
-        G["fn_1.weight"] = wgrad(dp1, iffn_d.view(B * T, W_))
+        tt_ok = use_b and (B * T) % 64 == 0 and E % 8 == 0            # weight gradients straight from the bf16 row-major copies
+        if tt_ok and dp1b_ok and ifdb is not None:
+            G["fn_1.weight"] = ops.gemm_bf16_tt(dp1b_all.view(B * T, Hd), ifdb.view(B * T, W_), Hd, W_)
+        else:
+            G["fn_1.weight"] = wgrad(dp1, iffn_d.view(B * T, W_))
         G["fn_1.bias"] = colsum(dp1)
         dg2 = dgd.view(T * B, 4 * Hd)
-        dwcat = wgrad(dg2, XH.view(T * B, E + Hd))
+        if tt_ok and XHb is not None:
+            dwcat = ops.gemm_bf16_tt(dgdb_all.view(T * B, 4 * Hd), XHb.view(T * B, E + Hd), 4 * Hd, E + Hd)
+        else:
+            dwcat = wgrad(dg2, XH.view(T * B, E + Hd))
         G["decoder.weight_ih_l0"] = dwcat[:, :E].contiguous()
         G["decoder.weight_hh_l0"] = dwcat[:, E:].contiguous()
         db = colsum(dg2)
