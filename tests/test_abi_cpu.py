@@ -35,6 +35,24 @@ def test_argument_errors_are_status_codes_not_exceptions():
     assert L.fn["cst_layernorm_bwd_workspace_floats"](4608, 512) == 2 * 1024 * 512
 
 
+def test_fused_entry_points_validate_their_limits():
+    """The fused kernels state their shape limits as status 1 + message (the host wrappers fall back before that)."""
+    L = _lib.lib()
+    P = 16                                                    # a fake, 16-byte aligned, never dereferenced pointer
+    # transposed-read GEMM: K must be a multiple of 64, M and N multiples of 8
+    assert L.fn["cst_gemm_bf16_tt"](P, 8, P, 8, P, 8, 8, 8, 100, 0, 1, None, 0, None) == 1 and "multiple of 64" in L.last_error()
+    assert L.fn["cst_gemm_bf16_tt"](P, 8, P, 8, P, 8, 12, 8, 64, 0, 1, None, 0, None) == 1
+    # RelGAN_D convolution: window k * E/R <= 40
+    assert L.fn["cst_relconv_fwd"](P, 2, 18, 128, 8, 5, P, P, 300, P, 300, P, None) == 1 and "limits" in L.last_error()
+    assert L.fn["cst_relconv_fwd"](P, 2, 3, 128, 16, 5, P, P, 300, P, 300, P, None) == 1 and "L >= k" in L.last_error()
+    assert L.fn["cst_relconv_bwd_weight_workspace_floats"](256, 16, 5, 128, 300) == 256 * 41 * 300
+    # all-steps decoder attention backward: 2 D <= 1024, L <= 64
+    assert L.fn["cst_dot_attn_bwd_steps"](P, 0, 0, P, 0, 0, P, P, P, 4, 3, 7, 768, 0.0, 0, 0, None, None) == 1
+    assert L.fn["cst_dot_attn_bwd_steps"](P, 0, 0, P, 0, 0, P, P, P, 4, 3, 70, 64, 0.0, 0, 0, None, None) == 1
+    # bf16 token-CE twin needs the vector path
+    assert L.fn["cst_token_ce_b"](P, 10, P, 4, 10, P, P, 10, 1.0, P, 16, None) == 1
+
+
 def test_no_cpu_fallback_in_product_path():
     """The product package must not import the oracle or route compute through torch on CPU."""
     root = os.path.dirname(os.path.abspath(_lib.__file__))
