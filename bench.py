@@ -216,8 +216,19 @@ def main():
     if os.environ.get("CST_FORCE_SEGMENTS") and reducer is None:
         reducer = lambda groups, defer=False: None     # single-GPU rehearsal of the segmented (N > 1) launch path
     use_graph = not args.no_graph
-    if use_graph:
+    if use_graph and world > 1:
+        # the segmented capture (graph | eager all-reduce | graph ...) is rehearsed on one GPU only; if it cannot be
+        # built on this node every rank falls back to eager launches together rather than losing the measurement
+        failed = 0.0
+        try:
+            pipe = GraphedPipeline(stages_, batches, reducer)
+        except Exception as e:                                     # noqa: BLE001
+            print(f"[bench] rank {rank}: segmented graph capture failed ({type(e).__name__}: {e}); eager launches", file=sys.stderr)
+            failed = 1.0
+        use_graph = max_over_ranks(failed, device) == 0.0
+    elif use_graph:
         pipe = GraphedPipeline(stages_, batches, reducer)
+    if use_graph:
         step = lambda it: pipe.step(batches, it)
     else:
         step = lambda it: run_step(stages_, batches, it, reducer)
