@@ -68,12 +68,13 @@ class GraphedStep:
             self.graphs.append(cur[0])
             self.points.append((list(groups), defer))     # nothing has run during capture: nothing to reduce yet
             cur[0] = torch.cuda.CUDAGraph()
-            cur[0].capture_begin(pool=pool)
+            cur[0].capture_begin(pool=pool, capture_error_mode="thread_local")
 
         self._hook = hook
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
-            cur[0].capture_begin(pool=pool)
+            # thread_local: RCCL's watchdog / proxy threads keep querying events while this thread captures
+            cur[0].capture_begin(pool=pool, capture_error_mode="thread_local")
             self.static_out = self._body()
             cur[0].capture_end()
             self.graphs.append(cur[0])
