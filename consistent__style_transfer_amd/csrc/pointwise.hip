@@ -221,9 +221,13 @@ __global__ __launch_bounds__(256) void tps_embed_bwd_kernel(const float* __restr
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + lane;
     const int l = blockIdx.y;
+    // blockIdx.z owns a slice of the batch rows: enough workgroups to fill the chip; the position / segment sums of
+    // the slices meet in atomics (the token table already does)
+    const int per = (B + gridDim.z - 1) / gridDim.z;
+    const int b0 = blockIdx.z * per, b1 = min(B, b0 + per);
     float s = 0.f;
     if (c < d) {
-        for (int b = w; b < B; b += 4) {
+        for (int b = b0 + w; b < b1; b += 4) {
             const float g = dx[((long)b * S + off + l) * d + c];
             s += g;
             if (ids) { const long id = ids[(long)b * L + l]; if (dEtok && id >= 0 && id < V) atomicAdd(&dEtok[id * d + c], g); }
@@ -234,7 +238,7 @@ __global__ __launch_bounds__(256) void tps_embed_bwd_kernel(const float* __restr
     __syncthreads();
     if (w == 0 && c < d) {
         const float t = (sh[0][lane] + sh[1][lane]) + (sh[2][lane] + sh[3][lane]);
-        if (dEpos) dEpos[(long)l * d + c] += t;       // one block owns (l, c): no race
+        if (dEpos) atomicAdd(&dEpos[(long)l * d + c], t);
         if (dseg) atomicAdd(&dseg[c], t);
     }
 }
@@ -242,7 +246,8 @@ __global__ __launch_bounds__(256) void tps_embed_bwd_kernel(const float* __restr
 extern "C" int cst_tps_embed_bwd(const float* dx, const int64_t* ids, float* dpre, float* dEtok, float* dEpos, float* dseg_row,
                                  int B, int L, int d, int S, int off, int V, void* stream) {
     CST_REQUIRE(dx && B > 0 && L > 0 && d > 0 && off + L <= S, "cst_tps_embed_bwd: bad arguments");
-    hipLaunchKernelGGL(tps_embed_bwd_kernel, dim3(cst_div_up(d, 64), L), dim3(256), 0, (hipStream_t)stream,
+    const int zs = B >= 64 ? cst_div_up(B, 32) : 1;
+    hipLaunchKernelGGL(tps_embed_bwd_kernel, dim3(cst_div_up(d, 64), L, zs), dim3(256), 0, (hipStream_t)stream,
                        dx, ids, dpre, dEtok, dEpos, dseg_row, B, L, d, S, off, V);
     CST_LAUNCH_CHECK("cst_tps_embed_bwd");
     return CST_OK;
@@ -570,8 +575,20 @@ __global__ __launch_bounds__(256) void multi_accumulate_kernel(const float* cons
     if (!src) return;
     const long s0 = chunk_start[blockIdx.x], n = sizes[t];
     float* dst = flat + dst_off[t];
-    for (long i = s0 + threadIdx.x; i < s0 + MT_CHUNK && i < n; i += 256)
-        dst[i] = accumulate ? dst[i] + src[i] : src[i];
+    const long end = min(n, s0 + MT_CHUNK);
+    constexpr int NIT = MT_CHUNK / 256;                        // 16 elements per thread: all loads issued before the first store
+    float v[NIT];
+#pragma unroll
+    for (int k = 0; k < NIT; ++k) {
+        const long i = min(s0 + threadIdx.x + 256L * k, end - 1);
+        v[k] = src[i];
+        if (accumulate) v[k] += dst[i];
+    }
+#pragma unroll
+    for (int k = 0; k < NIT; ++k) {
+        const long i = s0 + threadIdx.x + 256L * k;
+        if (i < end) dst[i] = v[k];
+    }
 }
 
 extern "C" int cst_multi_accumulate(const void* srcs_dev, const long* dst_off_dev, const long* sizes_dev,
