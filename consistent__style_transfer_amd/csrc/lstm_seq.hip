@@ -1,0 +1,170 @@
+// Whole-sequence BiLSTM encoder recurrences for gfx950 (reference: the nn.LSTM(bidirectional=True) of
+// src/model/rnn.py:25-27 called at rnn.py:57,62), one launch per pass instead of two launches per time step.
+//
+// A recurrence is sequential in time but independent across batch rows, so a workgroup takes 16 batch rows of one
+// direction through ALL L' steps with no inter-workgroup synchronisation: B/16 x 2 workgroups, each a chain of
+// L' steps of
+//     gates[16, 4H] = h_{t-1}[16, H] W_hh^T  (+ the precomputed input projection, bias included)
+// on v_mfma_f32_16x16x32_bf16.  Wave w owns hidden units [64w, 64w+64) of all four gates, so the cell update of a
+// (row, unit) pair finds its i, f, g, o pre-activations in the same lane and register slot of four accumulator
+// tiles: the cell runs in registers, c never leaves them, and h_t goes back to LDS in bf16 as the next step's A
+// operand.  W_hh (512 KB in bf16 at H = 256) does not fit the LDS and is streamed from L2 every step: 128 16-byte
+// loads per lane and step, requested a tile ahead of the MFMAs that consume them.
+//
+// The backward pass mirrors it: dgates_t (cell backward, in registers) goes to LDS in bf16 as the A operand of
+// dh_{t-1} = dgates_t W_hh, whose accumulator tiles land in the register slots the cell backward of step t-1 reads.
+//
+// H = 256 (4 waves x 64 units); B % 16 == 0; every fp32 row pointer 16-byte aligned.
+#include "cst_common.h"
+
+typedef unsigned short bf16_t;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
+
+__device__ __forceinline__ bf16_t sq_f2bf(float v) { __bf16 h = (__bf16)v; return __builtin_bit_cast(unsigned short, h); }
+// Hardware exp2 / reciprocal forms (v_exp_f32, v_rcp_f32; ~1e-6 relative): a workgroup does 4096 cell updates per step on
+// four SIMDs, and the libm expf / tanhf expansions alone took 10 us of each step.
+__device__ __forceinline__ float sq_sigmoid(float x) { return __frcp_rn(1.f + __expf(-x)); }
+__device__ __forceinline__ float sq_tanh(float x) { return 2.f * __frcp_rn(1.f + __expf(-2.f * x)) - 1.f; }
+
+constexpr int SQ_H = 256;              // hidden units per direction
+constexpr int SQ_J = SQ_H / 64;        // 16-unit tiles per gate per wave
+constexpr int SQ_KK = SQ_H / 32;       // 32-wide k steps of h W_hh^T
+constexpr int SQ_HS = SQ_H + 8;        // LDS row stride of the h tile (bf16 elements): 16-byte aligned, rows 4 banks apart
+
+struct LstmSeqDir {
+    const bf16_t* whh;                 // W_hh in bf16 FRAGMENT order [wave 4][gate 4][tile 4][k step 8][lane 64][8]: see cst_lstm_seq_fwd
+    const float* xp;                   // [B, L*4H] input projection incl. both biases
+    const float* h0;                   // [B, .] initial hidden state (leading dimension ldh0)
+    float* gates;                      // [L, B, 4H] activated gates (kept for backward)
+    float* cenc;                       // [L, B, H]  cell states of steps 0..L-2 (slot of the step's time index)
+    float* hprev;                      // [B, L*H]   h entering each time index (B operand of dW_hh)
+    float* c_last;                     // [B, .]     cell state after the last step (leading dimension ldcl)
+    int reverse;                       // 0: t = n, 1: t = L-1-n
+};
+struct LstmSeqArgs {
+    LstmSeqDir dir[2];
+    float* mem;                        // [B, L*2H]  h_t of direction d at column t*2H + d*H
+    bf16_t* memb;                      // same layout, bf16
+    int B, L;
+    long ldw, ldh0, ldcl;
+};
+
+__global__ __launch_bounds__(256) void lstm_seq_fwd_kernel(LstmSeqArgs a) {
+    constexpr int H = SQ_H;
+    __shared__ __attribute__((aligned(16))) bf16_t hA[16 * SQ_HS];
+    const int d = blockIdx.y;
+    const LstmSeqDir& D = a.dir[d];
+    const int r0 = blockIdx.x * 16;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int lr = lane & 15, lq = lane >> 4;
+    const int L = a.L, B = a.B;
+    // h_{-1}: bf16 into the A tile, fp32 into hprev at the first time index
+    {
+        const int t0 = D.reverse ? L - 1 : 0;
+        for (int i = threadIdx.x; i < 16 * H; i += 256) {
+            const int r = i / H, u = i - r * H;
+            const float v = D.h0[(long)(r0 + r) * a.ldh0 + u];
+            hA[r * SQ_HS + u] = sq_f2bf(v);
+            D.hprev[(long)(r0 + r) * L * H + (long)t0 * H + u] = v;
+        }
+    }
+    float c[SQ_J][4];
+#pragma unroll
+    for (int j = 0; j < SQ_J; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) c[j][r] = 0.f;
+    // B fragment of (gate q, tile j, k step kk) = W_hh row q*H + 64w + 16j + lr, columns 32kk + 8lq .. +7, stored so that the
+    // 64 lanes of one load instruction read one contiguous KiB (row-scattered 16-byte pieces keep the texture path busy
+    // 16 cache lines per instruction and ran this kernel at 1/6 of its speed)
+    const bf16_t* wfrag = D.whh + ((long)w * 16 * SQ_KK * 64 + lane) * 8;
+
+    for (int n = 0; n < L; ++n) {
+        const int t = D.reverse ? L - 1 - n : n;
+        f32x4_t acc[4][SQ_J];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int j = 0; j < SQ_J; ++j) acc[q][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        // W_hh fragments, three tiles in flight
+        u32x4_t bb[3][SQ_KK];
+        auto load_b = [&](int ti, u32x4_t (&dst)[SQ_KK]) {
+            const bf16_t* wn = wfrag + (long)ti * SQ_KK * 64 * 8;
+#pragma unroll
+            for (int kk = 0; kk < SQ_KK; ++kk) dst[kk] = *reinterpret_cast<const u32x4_t*>(wn + kk * 64 * 8);
+        };
+        load_b(0, bb[0]);
+        load_b(1, bb[1]);
+        __syncthreads();                                  // h tile of this step complete (and last step's reads done)
+        u32x4_t af[SQ_KK];
+#pragma unroll
+        for (int kk = 0; kk < SQ_KK; ++kk)
+            af[kk] = *reinterpret_cast<const u32x4_t*>(&hA[lr * SQ_HS + kk * 32 + lq * 8]);
+        __syncthreads();                                  // every wave holds its A fragments: the tile may be overwritten
+#pragma unroll
+        for (int ti = 0; ti < 4 * SQ_J; ++ti) {
+            if (ti + 2 < 4 * SQ_J) load_b(ti + 2, bb[(ti + 2) % 3]);
+            f32x4_t s = acc[ti / SQ_J][ti % SQ_J];
+#pragma unroll
+            for (int kk = 0; kk < SQ_KK; ++kk)
+                s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, af[kk]), __builtin_bit_cast(bf16x8_t, bb[ti % 3][kk]), s, 0, 0, 0);
+            acc[ti / SQ_J][ti % SQ_J] = s;
+        }
+        // input projection of this time index: requested only now -- the VMEM counter holds 63 outstanding operations, and
+        // 64 more loads in flight across the tile loop would force it to drain between tiles
+        float xv[4][SQ_J][4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int j = 0; j < SQ_J; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    xv[q][j][r] = D.xp[(long)(r0 + 4 * lq + r) * L * 4 * H + (long)t * 4 * H + q * H + 64 * w + 16 * j + lr];
+        // cell: accumulator element r of tile (q, j) is gate q of (row 4lq + r, unit 64w + 16j + lr)
+        const bool last = n == L - 1;
+        const int tn = D.reverse ? t - 1 : t + 1;          // time index of the next step
+#pragma unroll
+        for (int j = 0; j < SQ_J; ++j) {
+            const int u = 64 * w + 16 * j + lr;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = r0 + 4 * lq + r;
+                const float gi = sq_sigmoid(acc[0][j][r] + xv[0][j][r]);
+                const float gf = sq_sigmoid(acc[1][j][r] + xv[1][j][r]);
+                const float gg = sq_tanh(acc[2][j][r] + xv[2][j][r]);
+                const float go = sq_sigmoid(acc[3][j][r] + xv[3][j][r]);
+                const float cn = gf * c[j][r] + gi * gg;
+                const float h = go * sq_tanh(cn);
+                c[j][r] = cn;
+                float* g = D.gates + ((long)t * B + row) * 4 * H + u;
+                g[0] = gi; g[H] = gf; g[2 * H] = gg; g[3 * H] = go;
+                if (last) D.c_last[(long)row * a.ldcl + u] = cn;
+                else D.cenc[((long)t * B + row) * H + u] = cn;
+                const long mo = (long)row * L * 2 * H + (long)t * 2 * H + d * H + u;
+                a.mem[mo] = h;
+                const bf16_t hb = sq_f2bf(h);
+                a.memb[mo] = hb;
+                if (!last) D.hprev[(long)row * L * H + (long)tn * H + u] = h;
+                hA[(4 * lq + r) * SQ_HS + u] = hb;
+            }
+        }
+    }
+}
+
+extern "C" int cst_lstm_seq_fwd(const void* whh0, const void* whh1, const float* xp0, const float* xp1,
+                                const float* h0, long ldh0, float* gates0, float* gates1, float* cenc0, float* cenc1,
+                                float* hprev0, float* hprev1, float* c_last, long ldcl, float* mem, void* mem_bf16,
+                                int B, int L, int H, void* stream) {
+    CST_REQUIRE(whh0 && whh1 && xp0 && xp1 && h0 && gates0 && gates1 && cenc0 && cenc1 && hprev0 && hprev1 && c_last && mem && mem_bf16,
+                "cst_lstm_seq_fwd: null pointer");
+    CST_REQUIRE(H == SQ_H && B > 0 && B % 16 == 0 && L > 0, "cst_lstm_seq_fwd: needs H == %d and B %% 16 == 0 (H=%d, B=%d)", SQ_H, H, B);
+    CST_REQUIRE(((((uintptr_t)whh0) | ((uintptr_t)whh1)) & 15) == 0, "cst_lstm_seq_fwd: W_hh fragment copies must be 16-byte aligned");
+    LstmSeqArgs a;
+    a.dir[0] = LstmSeqDir{(const bf16_t*)whh0, xp0, h0, gates0, cenc0, hprev0, c_last, 0};
+    a.dir[1] = LstmSeqDir{(const bf16_t*)whh1, xp1, h0 + H, gates1, cenc1, hprev1, c_last + H, 1};
+    a.mem = mem; a.memb = (bf16_t*)mem_bf16; a.B = B; a.L = L; a.ldw = 0; a.ldh0 = ldh0; a.ldcl = ldcl;
+    hipLaunchKernelGGL(lstm_seq_fwd_kernel, dim3(B / 16, 2), dim3(256), 0, (hipStream_t)stream, a);
+    CST_LAUNCH_CHECK("cst_lstm_seq_fwd");
+    return CST_OK;
+}

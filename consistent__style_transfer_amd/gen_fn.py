@@ -74,6 +74,13 @@ def _cell_bwd(gates, c_prev, c_new, dh, dh2, dc, dgates, dc_prev, B, H, dgb=None
          dgb, _st(dgb), B, H)
 
 
+def _lstm_frag_order(wb, H):
+    """bf16 W_hh [4H, H] (K contiguous) -> the MFMA-fragment order cst_lstm_seq_fwd streams:
+    [wave][gate][tile][k step][lane = 16 lq + lr][8], element = W_hh[q*H + 64w + 16j + lr][32kk + 8lq + e]."""
+    v = wb[:, :H].reshape(4, 4, H // 64, 16, H // 32, 4, 8)           # (q, w, j, lr, kk, lq, e)
+    return v.permute(1, 0, 2, 4, 5, 3, 6).contiguous()               # (w, q, j, kk, lq, lr, e)
+
+
 def _bf16_ok(*dims):
     """The direct-to-LDS GEMM needs every reduction length to be a multiple of 64 (one 128-byte LDS
     row of bf16); the reference's module constants are, toy test sizes are not."""
@@ -136,7 +143,13 @@ class GeneratorFn(torch.autograd.Function):
             xp = linear_fwd(emb, w_ih, bsum).view(B, Lp * 4 * H)        # (B, L', 4H)
             order = list(range(Lp)) if d == 0 else list(range(Lp - 1, -1, -1))
             enc.append((w_hh, weight_bf16(w_hh)[0] if use_b else None, xp, order, hprev[d].view(B, Lp * H)))
-        for n in range(Lp):
+        seq_fused = use_b and H == 256 and B % 16 == 0
+        if seq_fused:
+            # both directions, all L' steps, one launch: 16 batch rows per workgroup, no inter-workgroup dependencies
+            (_, wb0, xp0, _, _), (_, wb1, xp1, _, _) = enc
+            call("cst_lstm_seq_fwd", _lstm_frag_order(wb0, H), _lstm_frag_order(wb1, H), xp0, xp1, h0cat, 2 * H, genc[0], genc[1], cenc[0], cenc[1],
+                 hprev[0], hprev[1], c_cat, 2 * H, memory, memb, B, Lp, H)
+        for n in (() if seq_fused else range(Lp)):
             probs = []
             for d, (w_hh, whh_b, xp, order, hp2) in enumerate(enc):
                 t = order[n]

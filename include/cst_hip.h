@@ -192,6 +192,21 @@ int cst_lstm_cell_fwd(float* gates, long ldg, const float* c_prev, long ldcp, fl
 int cst_gemm_bf16_tt(const void* A, long lda, const void* B, long ldb, float* C, long ldc, int M, int N, int K,
                      int accumulate, int splitk, float* workspace, long workspace_floats, void* stream);
 
+/* All L time steps of both directions of the BiLSTM encoder (rnn.py:25-27, called at rnn.py:57, :62) in ONE launch: a
+ * workgroup takes 16 batch rows of one direction through the whole sequence (recurrences are independent across batch
+ * rows), h W_hh^T on the bf16 matrix pipe with W_hh streamed from L2 each step, cell state in registers.
+ *   whh{0,1}: W_hh of the forward / reverse direction in bf16 MFMA-fragment order [wave 4][gate 4][tile 4][k step 8][lane 64][8]
+ *   (element [w][q][j][kk][16*lq + lr][e] = W_hh[q*H + 64w + 16j + lr][32kk + 8lq + e]: every 64-lane load reads one
+ *   contiguous KiB); xp{0,1}: [B, L*4H] input projections
+ *   incl. biases; h0 [B, ldh0]: forward direction's initial state at column 0, reverse at column H; outputs as the
+ *   per-step path writes them: gates{0,1} [L,B,4H] (activated), cenc{0,1} [L,B,H], hprev{0,1} [B, L*H] (h entering each
+ *   time index), c_last [B, ldcl] (final cell states at columns 0 / H), mem [B, L*2H] and its bf16 twin.
+ * H must be 256 and B a multiple of 16 (status 1 otherwise: use the per-step entry points). */
+int cst_lstm_seq_fwd(const void* whh0, const void* whh1, const float* xp0, const float* xp1,
+                     const float* h0, long ldh0, float* gates0, float* gates1, float* cenc0, float* cenc1,
+                     float* hprev0, float* hprev1, float* c_last, long ldcl, float* mem, void* mem_bf16,
+                     int B, int L, int H, void* stream);
+
 /* One recurrent step of nn.LSTM (rnn.py:25-33, called at rnn.py:57 and :75) in two launches, for one problem
  * or for two independent problems of one shape (the *2 / *_p2 arguments; A2 == NULL: single) -- the two
  * directions of the bidirectional encoder share every dimension and leading dimension.

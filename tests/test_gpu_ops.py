@@ -709,3 +709,48 @@ def test_vocab_proj_bf16_matches_linear(ops):
         grads.append([x.grad, W.grad, b.grad])
     for a, r in zip(*grads):
         assert (a - r).norm() / (r.norm() + 1e-12) < 1e-2
+
+
+def test_lstm_seq_fwd_equals_per_step_path(ops):
+    """The one-launch BiLSTM encoder forward against the per-step gate GEMM + cell launches it replaces."""
+    from consistent__style_transfer_amd import gen_fn
+    from consistent__style_transfer_amd._lib import call
+    B, L, H = 32, 5, 256
+    whh = [dev(rnd(4 * H, H, seed=1 + d, scale=0.08)) for d in range(2)]
+    wb = [ops.cast_bf16(w, want_t=False)[0] for w in whh]
+    xp = [dev(rnd(B, L * 4 * H, seed=3 + d, scale=0.5)) for d in range(2)]
+    h0 = dev(rnd(B, 2 * H, seed=5, scale=0.5))
+
+    def bufs():
+        return dict(genc=torch.empty(2, L, B, 4 * H, device="cuda"), cenc=torch.zeros(2, L, B, H, device="cuda"),
+                    hprev=torch.empty(2, B, L, H, device="cuda"), c_cat=torch.empty(B, 2 * H, device="cuda"),
+                    mem=torch.empty(B, L, 2 * H, device="cuda"), memb=torch.zeros(B, L * 2 * H, device="cuda", dtype=torch.int16))
+    r, f = bufs(), bufs()
+    # reference: the per-step fused GEMM + cell (itself tested against gemm + cell kernels)
+    mem2, zeros_c = r["mem"].view(B, L * 2 * H), torch.zeros(B, H, device="cuda")
+    for d in range(2):
+        order = list(range(L)) if d == 0 else list(range(L - 1, -1, -1))
+        hp2 = r["hprev"][d].view(B, L * H)
+        for n, t in enumerate(order):
+            if n == 0:
+                h_in = h0[:, d * H:(d + 1) * H]
+                hp2[:, t * H:(t + 1) * H].copy_(h_in)
+                Ab, c_in = ops.cast_bf16(h_in, want_t=False)[0], zeros_c
+            else:
+                tp = order[n - 1]
+                Ab, c_in = r["memb"][:, tp * 2 * H + d * H: tp * 2 * H + (d + 1) * H], r["cenc"][d, tp]
+            last = n == L - 1
+            gen_fn._gemm_cell_fwd([dict(Ab=Ab, Bb=wb[d], gates=r["genc"][d, t], c_prev=c_in, h_out=mem2[:, t * 2 * H + d * H: t * 2 * H + (d + 1) * H],
+                                        c_out=r["c_cat"][:, d * H:(d + 1) * H] if last else r["cenc"][d, t],
+                                        h_out2=None if last else hp2[:, order[n + 1] * H:(order[n + 1] + 1) * H],
+                                        addend=xp[d][:, t * 4 * H:(t + 1) * 4 * H], hb=r["memb"][:, t * 2 * H + d * H: t * 2 * H + (d + 1) * H])], B, H)
+    call("cst_lstm_seq_fwd", gen_fn._lstm_frag_order(wb[0], H), gen_fn._lstm_frag_order(wb[1], H), xp[0], xp[1], h0, 2 * H, f["genc"][0], f["genc"][1], f["cenc"][0], f["cenc"][1],
+         f["hprev"][0], f["hprev"][1], f["c_cat"], 2 * H, f["mem"], f["memb"], B, L, H)
+    torch.cuda.synchronize()
+    for k in ("genc", "hprev", "c_cat", "mem"):
+        close(f[k], r[k], 2e-3, 2e-3, k)                       # bf16 h feedback: rounding-level differences compound over the steps
+    for d in range(2):                                        # cell states of every step but the last (that one lives in c_cat)
+        order = list(range(L)) if d == 0 else list(range(L - 1, -1, -1))
+        for t in order[:-1]:
+            close(f["cenc"][d, t], r["cenc"][d, t], 2e-3, 2e-3)
+    close(f["memb"].view(torch.bfloat16).float(), r["memb"].view(torch.bfloat16).float(), 2e-2, 2e-2)
