@@ -51,7 +51,7 @@ struct LstmSeqArgs {
     long ldw, ldh0, ldcl;
 };
 
-__global__ __launch_bounds__(256) void lstm_seq_fwd_kernel(LstmSeqArgs a) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void lstm_seq_fwd_kernel(LstmSeqArgs a) {
     constexpr int H = SQ_H;
     __shared__ __attribute__((aligned(16))) bf16_t hA[16 * SQ_HS];
     const int d = blockIdx.y;
@@ -105,11 +105,13 @@ __global__ __launch_bounds__(256) void lstm_seq_fwd_kernel(LstmSeqArgs a) {
 #pragma unroll
         for (int ti = 0; ti < 4 * SQ_J; ++ti) {
             if (ti + 2 < 4 * SQ_J) load_b(ti + 2, bb[(ti + 2) % 3]);
+            __builtin_amdgcn_sched_barrier(0);            // keep two tiles of loads in flight: the scheduler otherwise sinks them next to their use
             f32x4_t s = acc[ti / SQ_J][ti % SQ_J];
 #pragma unroll
             for (int kk = 0; kk < SQ_KK; ++kk)
                 s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, af[kk]), __builtin_bit_cast(bf16x8_t, bb[ti % 3][kk]), s, 0, 0, 0);
             acc[ti / SQ_J][ti % SQ_J] = s;
+            __builtin_amdgcn_sched_barrier(0);
         }
         // input projection of this time index: requested only now -- the VMEM counter holds 63 outstanding operations, and
         // 64 more loads in flight across the tile loop would force it to drain between tiles
@@ -166,5 +168,130 @@ extern "C" int cst_lstm_seq_fwd(const void* whh0, const void* whh1, const float*
     a.mem = mem; a.memb = (bf16_t*)mem_bf16; a.B = B; a.L = L; a.ldw = 0; a.ldh0 = ldh0; a.ldcl = ldcl;
     hipLaunchKernelGGL(lstm_seq_fwd_kernel, dim3(B / 16, 2), dim3(256), 0, (hipStream_t)stream, a);
     CST_LAUNCH_CHECK("cst_lstm_seq_fwd");
+    return CST_OK;
+}
+
+// =============================================================================================
+// Backward of the same recurrences: per step the LSTM cell backward in registers, dgates (bf16) to LDS as the A
+// operand of dh_{t-1}[16, H] = dgates[16, 4H] W_hh, whose accumulator tiles are the register slots the next cell
+// backward reads.  W_hh^T is streamed in fragment order [wave][k step 32][tile 4][lane 64][8].
+// =============================================================================================
+constexpr int SQ_GS = 4 * SQ_H + 8;    // LDS row stride of the dgates tile (bf16 elements)
+constexpr int SQ_KB = 4 * SQ_H / 32;   // 32-wide k steps over the 4H gate columns
+
+struct LstmSeqBwdDir {
+    const bf16_t* wt;                  // W_hh^T in bf16 fragment order (see cst_lstm_seq_bwd)
+    const float* gates;                // [L, B, 4H] activated gates of the forward pass
+    const float* cenc;                 // [L, B, H]
+    const float* c_last;               // [B, .]  (ldcl)
+    const float* dc_last;              // [B, .]  gradient w.r.t. the final cell state (lddcl)
+    float* dgates;                     // [B, L*4H] pre-activation gate gradients (operand of the weight gradients)
+    float* dh0;                        // [B, .]  gradient w.r.t. the initial hidden state (lddh0)
+    int reverse;
+};
+struct LstmSeqBwdArgs {
+    LstmSeqBwdDir dir[2];
+    const float* dmem;                 // [B, L*2H] gradient w.r.t. the encoder states (direction d at column t*2H + d*H)
+    int B, L;
+    long ldcl, lddcl, lddh0;
+};
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void lstm_seq_bwd_kernel(LstmSeqBwdArgs a) {
+    constexpr int H = SQ_H;
+    __shared__ __attribute__((aligned(16))) bf16_t gA[16 * SQ_GS];
+    const int d = blockIdx.y;
+    const LstmSeqBwdDir& D = a.dir[d];
+    const int r0 = blockIdx.x * 16;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int lr = lane & 15, lq = lane >> 4;
+    const int L = a.L, B = a.B;
+    float dc[SQ_J][4], dhr[SQ_J][4];
+#pragma unroll
+    for (int j = 0; j < SQ_J; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            dc[j][r] = D.dc_last[(long)(r0 + 4 * lq + r) * a.lddcl + 64 * w + 16 * j + lr];
+            dhr[j][r] = 0.f;
+        }
+    const bf16_t* wfrag = D.wt + ((long)w * SQ_KB * SQ_J * 64 + lane) * 8;
+
+    for (int n = L - 1; n >= 0; --n) {
+        const int t = D.reverse ? L - 1 - n : n;
+        const int tp = D.reverse ? t + 1 : t - 1;          // time index of the forward step before this one
+        // ---- cell backward of step n (element r of tile j = (row 4lq + r, unit 64w + 16j + lr)) ----
+#pragma unroll
+        for (int j = 0; j < SQ_J; ++j) {
+            const int u = 64 * w + 16 * j + lr;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = r0 + 4 * lq + r;
+                const float* g = D.gates + ((long)t * B + row) * 4 * H + u;
+                const float gi = g[0], gf = g[H], gg = g[2 * H], go = g[3 * H];
+                const float cn = (n == L - 1) ? D.c_last[(long)row * a.ldcl + u] : D.cenc[((long)t * B + row) * H + u];
+                const float cp = (n == 0) ? 0.f : D.cenc[((long)tp * B + row) * H + u];
+                const float dht = a.dmem[(long)row * L * 2 * H + (long)t * 2 * H + d * H + u] + dhr[j][r];
+                const float tc = sq_tanh(cn);
+                const float dct = dc[j][r] + dht * go * (1.f - tc * tc);
+                const float d0 = dct * gg * gi * (1.f - gi);
+                const float d1 = dct * cp * gf * (1.f - gf);
+                const float d2 = dct * gi * (1.f - gg * gg);
+                const float d3 = dht * tc * go * (1.f - go);
+                dc[j][r] = dct * gf;
+                float* dg = D.dgates + (long)row * L * 4 * H + (long)t * 4 * H + u;
+                dg[0] = d0; dg[H] = d1; dg[2 * H] = d2; dg[3 * H] = d3;
+                bf16_t* ga = gA + (4 * lq + r) * SQ_GS + u;
+                ga[0] = sq_f2bf(d0); ga[H] = sq_f2bf(d1); ga[2 * H] = sq_f2bf(d2); ga[3 * H] = sq_f2bf(d3);
+            }
+        }
+        __syncthreads();                                  // the dgates tile is complete
+        // ---- dh_{prev}[16, 64 units of this wave] = dgates[16, 4H] W_hh[4H, units] ----
+        f32x4_t acc[SQ_J];
+#pragma unroll
+        for (int j = 0; j < SQ_J; ++j) acc[j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        u32x4_t bb[3][SQ_J];
+        auto load_b = [&](int kk, u32x4_t (&dst)[SQ_J]) {
+            const bf16_t* wn = wfrag + (long)kk * SQ_J * 64 * 8;
+#pragma unroll
+            for (int j = 0; j < SQ_J; ++j) dst[j] = *reinterpret_cast<const u32x4_t*>(wn + j * 64 * 8);
+        };
+        load_b(0, bb[0]);
+        load_b(1, bb[1]);
+#pragma unroll
+        for (int kk = 0; kk < SQ_KB; ++kk) {
+            if (kk + 2 < SQ_KB) load_b(kk + 2, bb[(kk + 2) % 3]);
+            const u32x4_t af = *reinterpret_cast<const u32x4_t*>(&gA[lr * SQ_GS + kk * 32 + lq * 8]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < SQ_J; ++j)
+                acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, af), __builtin_bit_cast(bf16x8_t, bb[kk % 3][j]), acc[j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int j = 0; j < SQ_J; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dhr[j][r] = acc[j][r];
+        __syncthreads();                                  // all reads of the dgates tile done before the next step overwrites it
+    }
+#pragma unroll
+    for (int j = 0; j < SQ_J; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) D.dh0[(long)(r0 + 4 * lq + r) * a.lddh0 + 64 * w + 16 * j + lr] = dhr[j][r];
+}
+
+extern "C" int cst_lstm_seq_bwd(const void* wt0, const void* wt1, const float* gates0, const float* gates1,
+                                const float* cenc0, const float* cenc1, const float* c_last, long ldcl,
+                                const float* dc_last, long lddcl, const float* dmem,
+                                float* dgates0, float* dgates1, float* dh0, long lddh0,
+                                int B, int L, int H, void* stream) {
+    CST_REQUIRE(wt0 && wt1 && gates0 && gates1 && cenc0 && cenc1 && c_last && dc_last && dmem && dgates0 && dgates1 && dh0,
+                "cst_lstm_seq_bwd: null pointer");
+    CST_REQUIRE(H == SQ_H && B > 0 && B % 16 == 0 && L > 0, "cst_lstm_seq_bwd: needs H == %d and B %% 16 == 0 (H=%d, B=%d)", SQ_H, H, B);
+    CST_REQUIRE(((((uintptr_t)wt0) | ((uintptr_t)wt1)) & 15) == 0, "cst_lstm_seq_bwd: W_hh^T fragment copies must be 16-byte aligned");
+    LstmSeqBwdArgs a;
+    a.dir[0] = LstmSeqBwdDir{(const bf16_t*)wt0, gates0, cenc0, c_last, dc_last, dgates0, dh0, 0};
+    a.dir[1] = LstmSeqBwdDir{(const bf16_t*)wt1, gates1, cenc1, c_last + H, dc_last + H, dgates1, dh0 + H, 1};
+    a.dmem = dmem; a.B = B; a.L = L; a.ldcl = ldcl; a.lddcl = lddcl; a.lddh0 = lddh0;
+    hipLaunchKernelGGL(lstm_seq_bwd_kernel, dim3(B / 16, 2), dim3(256), 0, (hipStream_t)stream, a);
+    CST_LAUNCH_CHECK("cst_lstm_seq_bwd");
     return CST_OK;
 }

@@ -81,6 +81,13 @@ def _lstm_frag_order(wb, H):
     return v.permute(1, 0, 2, 4, 5, 3, 6).contiguous()               # (w, q, j, kk, lq, lr, e)
 
 
+def _lstm_frag_order_t(wt, H):
+    """bf16 W_hh^T [H, 4H] (K = 4H contiguous) -> the fragment order cst_lstm_seq_bwd streams:
+    [wave][k step][tile][lane = 16 lq + lr][8], element = W_hh^T[64w + 16j + lr][32kk + 8lq + e]."""
+    v = wt[:, :4 * H].reshape(4, H // 64, 16, 4 * H // 32, 4, 8)      # (w, j, lr, kk, lq, e)
+    return v.permute(0, 3, 1, 4, 2, 5).contiguous()                  # (w, kk, j, lq, lr, e)
+
+
 def _bf16_ok(*dims):
     """The direct-to-LDS GEMM needs every reduction length to be a multiple of 64 (one 128-byte LDS
     row of bf16); the reference's module constants are, toy test sizes are not."""
@@ -431,7 +438,12 @@ class GeneratorFn(torch.autograd.Function):
             w_ih, w_hh = P["encoder.weight_ih_l0" + suf], P["encoder.weight_hh_l0" + suf]
             order = list(range(Lp)) if d == 0 else list(range(Lp - 1, -1, -1))
             encb.append((w_ih, w_hh, weight_bf16(w_hh)[1] if use_b else None, order, dge[d].view(B, Lp * 4 * H)))   # whh_t [H, 4H]
-        for n_ in range(Lp - 1, -1, -1):
+        seq_bwd = use_b and H == 256 and B % 16 == 0
+        if seq_bwd:
+            # both directions, all steps, one launch (mirror of cst_lstm_seq_fwd)
+            call("cst_lstm_seq_bwd", _lstm_frag_order_t(encb[0][2], H), _lstm_frag_order_t(encb[1][2], H), genc[0], genc[1],
+                 cenc[0], cenc[1], c_cat, 2 * H, dc_cat, dc_cat.stride(0), dmem, dge[0], dge[1], dh0cat, 2 * H, B, Lp, H)
+        for n_ in (() if seq_bwd else range(Lp - 1, -1, -1)):
             probs = []
             for d, (w_ih, w_hh, whh_t, order, dg2d) in enumerate(encb):
                 t = order[n_]
@@ -453,7 +465,7 @@ class GeneratorFn(torch.autograd.Function):
             if probs:
                 _gemm_cell_bwd(probs, B, H)
         for d, (w_ih, w_hh, whh_t, order, dg2d) in enumerate(encb):
-            if use_b:
+            if use_b and not seq_bwd:
                 gemm_bf16(dgtb2[d], whh_t, B, H, C=dh0cat[:, d * H:(d + 1) * H])
             dgf = dge[d].view(B * Lp, 4 * H)
             suf = "" if d == 0 else "_reverse"

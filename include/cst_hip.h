@@ -207,6 +207,17 @@ int cst_lstm_seq_fwd(const void* whh0, const void* whh1, const float* xp0, const
                      float* hprev0, float* hprev1, float* c_last, long ldcl, float* mem, void* mem_bf16,
                      int B, int L, int H, void* stream);
 
+/* Backward of cst_lstm_seq_fwd, also one launch: per step the cell backward in registers and dh_{prev} = dgates W_hh on
+ * the bf16 matrix pipe.  wt{0,1}: W_hh^T in bf16 fragment order [wave 4][k step 32][tile 4][lane 64][8] (element
+ * [w][kk][j][16*lq + lr][e] = W_hh[32kk + 8lq + e][64w + 16j + lr]); gates / cenc / c_last as the forward wrote them;
+ * dc_last [B, lddcl]: gradient w.r.t. the final cell states (columns 0 / H); dmem [B, L*2H]: gradient w.r.t. the encoder
+ * states; outputs dgates{0,1} [B, L*4H] (pre-activation gate gradients at column t*4H) and dh0 [B, lddh0]. */
+int cst_lstm_seq_bwd(const void* wt0, const void* wt1, const float* gates0, const float* gates1,
+                     const float* cenc0, const float* cenc1, const float* c_last, long ldcl,
+                     const float* dc_last, long lddcl, const float* dmem,
+                     float* dgates0, float* dgates1, float* dh0, long lddh0,
+                     int B, int L, int H, void* stream);
+
 /* One recurrent step of nn.LSTM (rnn.py:25-33, called at rnn.py:57 and :75) in two launches, for one problem
  * or for two independent problems of one shape (the *2 / *_p2 arguments; A2 == NULL: single) -- the two
  * directions of the bidirectional encoder share every dimension and leading dimension.

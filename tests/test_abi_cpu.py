@@ -49,6 +49,9 @@ def test_fused_entry_points_validate_their_limits():
     # all-steps decoder attention backward: 2 D <= 1024, L <= 64
     assert L.fn["cst_dot_attn_bwd_steps"](P, 0, 0, P, 0, 0, P, P, P, 4, 3, 7, 768, 0.0, 0, 0, None, None) == 1
     assert L.fn["cst_dot_attn_bwd_steps"](P, 0, 0, P, 0, 0, P, P, P, 4, 3, 70, 64, 0.0, 0, 0, None, None) == 1
+    # whole-sequence encoder kernels: H == 256, B % 16 == 0
+    assert L.fn["cst_lstm_seq_fwd"](P, P, P, P, P, 512, P, P, P, P, P, P, P, 512, P, P, 32, 5, 128, None) == 1 and "H == 256" in L.last_error()
+    assert L.fn["cst_lstm_seq_bwd"](P, P, P, P, P, P, P, 512, P, 512, P, P, P, P, 512, 24, 5, 256, None) == 1
     # bf16 token-CE twin needs the vector path
     assert L.fn["cst_token_ce_b"](P, 10, P, 4, 10, P, P, 10, 1.0, P, 16, None) == 1
 

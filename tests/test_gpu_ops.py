@@ -754,3 +754,41 @@ def test_lstm_seq_fwd_equals_per_step_path(ops):
         for t in order[:-1]:
             close(f["cenc"][d, t], r["cenc"][d, t], 2e-3, 2e-3)
     close(f["memb"].view(torch.bfloat16).float(), r["memb"].view(torch.bfloat16).float(), 2e-2, 2e-2)
+
+
+def test_lstm_seq_bwd_equals_per_step_path(ops):
+    """The one-launch BiLSTM encoder backward against the per-step cell backward + dh GEMM launches it replaces."""
+    from consistent__style_transfer_amd import gen_fn
+    from consistent__style_transfer_amd._lib import call
+    B, L, H = 32, 5, 256
+    whh = [dev(rnd(4 * H, H, seed=1 + d, scale=0.08)) for d in range(2)]
+    wt = [ops.cast_bf16(w)[1] for w in whh]                                   # W_hh^T [H, 4H] bf16
+    genc = torch.sigmoid(dev(rnd(2, L, B, 4 * H, seed=3)))
+    genc[:, :, :, 2 * H:3 * H] = torch.tanh(dev(rnd(2, L, B, H, seed=4)))    # the g gate lives in (-1, 1)
+    cenc, c_cat = dev(rnd(2, L, B, H, seed=5)), dev(rnd(B, 2 * H, seed=6))
+    dc_cat, dmem = dev(rnd(B, 2 * H, seed=7)), dev(rnd(B, L * 2 * H, seed=8))
+    zeros_c = torch.zeros(B, H, device="cuda")
+    # reference: the per-step path of gen_fn (cell backward, then fused dh GEMM + cell backward of the step before)
+    r_dge, r_dh0 = torch.empty(2, B, L, 4 * H, device="cuda"), torch.empty(B, 2 * H, device="cuda")
+    for d in range(2):
+        order = list(range(L)) if d == 0 else list(range(L - 1, -1, -1))
+        dg2d, dce = r_dge[d].view(B, L * 4 * H), torch.empty(B, H, device="cuda")
+        dgb = torch.zeros(B, 4 * H, device="cuda", dtype=torch.int16)
+        for n_ in range(L - 1, -1, -1):
+            t = order[n_]
+            lastf = n_ == L - 1
+            c_new = c_cat[:, d * H:(d + 1) * H] if lastf else cenc[d, t]
+            c_prev = zeros_c if n_ == 0 else cenc[d, order[n_ - 1]]
+            dgt, dmt = dg2d[:, t * 4 * H:(t + 1) * 4 * H], dmem[:, t * 2 * H + d * H: t * 2 * H + (d + 1) * H]
+            if lastf:
+                gen_fn._cell_bwd(genc[d, t], c_prev, c_new, dmt, None, dc_cat[:, d * H:(d + 1) * H], dgt, dce, B, H, dgb=dgb)
+            else:
+                gen_fn._gemm_cell_bwd([dict(Ab=dgb, Bb=wt[d], gates=genc[d, t], c_prev=c_prev, c_new=c_new, dh_extra=dmt, dc_in=dce,
+                                            dgates=dgt, dc_prev=dce, dgb=dgb)], B, H)
+        ops.gemm_bf16(dgb, wt[d], B, H, C=r_dh0[:, d * H:(d + 1) * H])
+    f_dge, f_dh0 = torch.empty(2, B, L, 4 * H, device="cuda"), torch.empty(B, 2 * H, device="cuda")
+    call("cst_lstm_seq_bwd", gen_fn._lstm_frag_order_t(wt[0], H), gen_fn._lstm_frag_order_t(wt[1], H), genc[0], genc[1], cenc[0], cenc[1],
+         c_cat, 2 * H, dc_cat, 2 * H, dmem, f_dge[0], f_dge[1], f_dh0, 2 * H, B, L, H)
+    torch.cuda.synchronize()
+    close(f_dge, r_dge, 5e-3, 5e-3)                  # bf16 dgates feedback: rounding-level differences compound over the steps
+    close(f_dh0, r_dh0, 5e-3, 5e-3)
