@@ -195,6 +195,7 @@ struct GatherTail {
     const int64_t* ids_b; long ldb; const int* coin;
     int E, V;
     CstDrop drop;
+    unsigned short* pb; long ldpb; int wpb;   // softmax only: bf16 twin of the probabilities, zero in columns [V, wpb)
 };
 
 __device__ __forceinline__ void gather_tail(const GatherTail& t, long r, int id_a) {
@@ -248,6 +249,21 @@ __global__ __launch_bounds__(NTH) void softmax_tau_vec_kernel(const float* __res
         if (c < V) { upd(x.v[i].x, c, bv, bi); upd(x.v[i].y, c + 1, bv, bi); upd(x.v[i].z, c + 2, bv, bi); upd(x.v[i].w, c + 3, bv, bi); }
     }
     x.store(p + r * ldp, V);
+    if (tail.pb) {                                // operand of the soft-embedding products that consume all steps at once
+#pragma unroll
+        for (int i = 0; i < NV4; ++i) {
+            const int c = (threadIdx.x + NTH * i) * 4;
+            if (c < tail.wpb) {
+                uint2 u = make_uint2(0u, 0u);
+                if (c < V) {
+                    __bf16 h0 = (__bf16)x.v[i].x, h1 = (__bf16)x.v[i].y, h2 = (__bf16)x.v[i].z, h3 = (__bf16)x.v[i].w;
+                    u.x = (uint32_t)__builtin_bit_cast(unsigned short, h0) | ((uint32_t)__builtin_bit_cast(unsigned short, h1) << 16);
+                    u.y = (uint32_t)__builtin_bit_cast(unsigned short, h2) | ((uint32_t)__builtin_bit_cast(unsigned short, h3) << 16);
+                }
+                *reinterpret_cast<uint2*>(tail.pb + r * tail.ldpb + c) = u;
+            }
+        }
+    }
     if (amax || tail.table) {
         block_argmax(bv, bi, red, redi);
         if (amax && threadIdx.x == 0) amax[r] = bi;
@@ -288,6 +304,7 @@ static GatherTail make_tail(const float* table, long ldt, int E, float* out, lon
     t.table = table; t.ldt = ldt; t.out = out; t.ldo = ldo; t.outb = (unsigned short*)out_bf16; t.ldob = ldob;
     t.ids_b = ids_b; t.ldb = ldb; t.coin = coin_dev; t.E = E; t.V = V;
     t.drop = cst_make_drop(drop_p, drop_seed, drop_stream, drop_seed_dev);
+    t.pb = nullptr; t.ldpb = 0; t.wpb = 0;
     return t;
 }
 
@@ -296,6 +313,12 @@ static int softmax_tau_launch(const float* logits, long ld, float inv_tau, float
     CST_REQUIRE(logits && p, "cst_softmax_tau: null pointer");
     CST_REQUIRE(R > 0 && V > 0 && ld >= V && ldp >= V, "cst_softmax_tau: bad shape");
     hipStream_t st = (hipStream_t)stream;
+    if (tail.pb) {
+        CST_REQUIRE(tail.wpb >= V && tail.wpb % 4 == 0 && tail.ldpb >= tail.wpb && tail.ldpb % 4 == 0 && (((uintptr_t)tail.pb) & 7) == 0,
+                    "cst_softmax_tau_gather_b: bad bf16 output");
+        CST_REQUIRE(row_vec_ok(logits, ld, V) && row_vec_ok(p, ldp, V) && tail.wpb < V + 64 && V <= 16384,
+                    "cst_softmax_tau_gather_b: the bf16 twin needs the vector path (16-byte aligned rows, V %% 4 == 0, V <= 16384) and wpb < V + 64");
+    }
     if (row_vec_ok(logits, ld, V) && row_vec_ok(p, ldp, V) && R <= 1024 && V > 4096 && V <= 12288) {
         // few rows (one decode step): 1024-thread workgroups keep 4x the loads in flight per CU
         hipLaunchKernelGGL((softmax_tau_vec_kernel<3, 1024>), dim3(R), dim3(1024), 0, st, logits, ld, inv_tau, p, ldp, argmax_out, V, tail);
@@ -322,6 +345,19 @@ extern "C" int cst_softmax_tau_gather(const float* logits, long ld, float inv_ta
                                       void* stream) {
     CST_REQUIRE(table && out && E > 0 && ldt >= E && ldo >= E, "cst_softmax_tau_gather: bad gather arguments");
     GatherTail t = make_tail(table, ldt, E, out, ldo, out_bf16, ldob, ids_b, ldb, coin_dev, V, drop_p, drop_seed, drop_stream, drop_seed_dev);
+    return softmax_tau_launch(logits, ld, inv_tau, p, ldp, argmax_out, R, V, t, stream);
+}
+
+extern "C" int cst_softmax_tau_gather_b(const float* logits, long ld, float inv_tau, float* p, long ldp,
+                                        void* p_bf16, long ldpb, int wpb, int64_t* argmax_out, int R, int V,
+                                        const float* table, long ldt, int E, float* out, long ldo, void* out_bf16, long ldob,
+                                        const int64_t* ids_b, long ldb, const int* coin_dev,
+                                        float drop_p, uint32_t drop_seed, uint32_t drop_stream, const void* drop_seed_dev,
+                                        void* stream) {
+    CST_REQUIRE(p_bf16, "cst_softmax_tau_gather_b: null bf16 output");
+    CST_REQUIRE(!table || (out && E > 0 && ldt >= E && ldo >= E), "cst_softmax_tau_gather_b: bad gather arguments");
+    GatherTail t = make_tail(table, ldt, E, out, ldo, out_bf16, ldob, ids_b, ldb, coin_dev, V, drop_p, drop_seed, drop_stream, drop_seed_dev);
+    t.pb = (unsigned short*)p_bf16; t.ldpb = ldpb; t.wpb = wpb;
     return softmax_tau_launch(logits, ld, inv_tau, p, ldp, argmax_out, R, V, t, stream);
 }
 

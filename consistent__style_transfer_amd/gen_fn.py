@@ -217,6 +217,10 @@ class GeneratorFn(torch.autograd.Function):
         out2 = out.view(B, T * V)
         r12 = r1.view(B, T * Hd)
         x_c = x.contiguous() if x is not None else None
+        # soft decode: the softmax kernel also writes the bf16 twin of the distributions, the operand of the critics'
+        # shared soft-embedding product over all steps (ops.SharedSoftEmbedFn)
+        Vp = (V + 63) // 64 * 64
+        outb = _i16(dev, B, T * Vp) if (soft and use_b and V % 4 == 0 and V <= 16384) else None
         for s in range(T):
             c_in = c0 if s == 0 else cdec[s - 1]
             h_next = XH[s + 1][:, E:] if s + 1 < T else None
@@ -257,10 +261,12 @@ class GeneratorFn(torch.autograd.Function):
                 if not (soft or x_c is None):
                     fb.update(ids_b=x_c[:, s], ldb=T, coin=coins[s:s + 1])
             if soft:
-                softmax_tau(o_s, inv_tau, o_s, ids_fb[s], gather=fb)
+                softmax_tau(o_s, inv_tau, o_s, ids_fb[s], gather=fb, p_b=outb[:, s * Vp:(s + 1) * Vp] if outb is not None else None)
             else:
                 argmax_rows(o_s, ids_fb[s], gather=fb)
 
+        if outb is not None:
+            ops._side_put(out, outb.view(B * T, Vp))
         ctx.cfg = (B, Lp, T, V, E, H, Hd, soft, inv_tau, drop, in_drop, inp.dim() == 3, use_b)
         ctx.save_for_backward(*params, emb, ids_in, label_i, label, h0cat, memory, hprev, genc, cenc, c_cat, c0,
                               wcat, XH, gdec, cdec, iffn, iffn_d, patt, r1, out, ids_fb, x_c, coins, zeros_c,

@@ -261,10 +261,15 @@ def argmax_rows(x, out=None, gather=None):
     return out
 
 
-def softmax_tau(logits, inv_tau, p, argmax_out=None, gather=None):
-    """gather = dict(table, out, out_b, ids_b, ldb, coin, drop): also embed the token fed to the next step."""
+def softmax_tau(logits, inv_tau, p, argmax_out=None, gather=None, p_b=None):
+    """gather = dict(table, out, out_b, ids_b, ldb, coin, drop): also embed the token fed to the next step.
+    p_b: int16 [R, up64(V)] view -> also the zero-padded bf16 twin of p."""
     R, V = logits.shape
-    if gather is None:
+    if p_b is not None:
+        ga = _gather_args(gather) if gather is not None else (None, 0, 0, None, 0, None, 0, None, 1, None, *NO_DROP.args())
+        call("cst_softmax_tau_gather_b", logits, _ld(logits), float(inv_tau), p, _ld(p), p_b, p_b.stride(0), p_b.shape[1],
+             argmax_out, R, V, *ga)
+    elif gather is None:
         call("cst_softmax_tau", logits, _ld(logits), float(inv_tau), p, _ld(p), argmax_out, R, V)
     else:
         call("cst_softmax_tau_gather", logits, _ld(logits), float(inv_tau), p, _ld(p), argmax_out, R, V, *_gather_args(gather))
@@ -981,8 +986,14 @@ class SharedSoftEmbedFn(torch.autograd.Function):
         tcat = torch.cat(cols, dim=1)                                      # [V, sum E_i], contiguous
         S = tcat.shape[1]
         out = torch.empty(R, S, device=p.device, dtype=torch.float32)
-        gemm(p, True, tcat, False, out, R, S, V)
-        ctx.save_for_backward(p, tcat)
+        pb = _side_take(p) if not _STATE["f32"] else None                        # bf16 twin written by the decoder's softmax
+        tc_rm = None
+        if pb is not None and pb.shape == (R, _up64(V)):
+            tc_rm, tc_tr = cast_bf16(tcat)                                 # [V, up64(S)] for d p, [S, up64(V)] for the product
+            gemm_bf16(pb, tc_tr, R, S, C=out)
+        else:
+            gemm(p, True, tcat, False, out, R, S, V)
+        ctx.save_for_backward(p, tcat, tc_rm)
         ctx.cfg = (widths, evs)
         offs, o = [], 0
         for w in widths:
@@ -992,7 +1003,7 @@ class SharedSoftEmbedFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, *douts):
-        p, tcat = ctx.saved_tensors
+        p, tcat, tc_rm = ctx.saved_tensors
         widths, evs = ctx.cfg
         R, V = p.shape
         S = tcat.shape[1]
@@ -1007,7 +1018,10 @@ class SharedSoftEmbedFn(torch.autograd.Function):
         dp = None
         if ctx.needs_input_grad[0]:
             dp = torch.empty(R, V, device=p.device, dtype=torch.float32)
-            gemm(dcat, True, tcat, True, dp, R, V, S)
+            if tc_rm is not None:
+                gemm_bf16(cast_bf16(dcat, want_t=False)[0], tc_rm, R, V, C=dp)
+            else:
+                gemm(dcat, True, tcat, True, dp, R, V, S)
         dts = [None] * len(widths)
         if any(ctx.needs_input_grad[2:]):
             dt = torch.empty(V, S, device=p.device, dtype=torch.float32)

@@ -107,6 +107,15 @@ int cst_softmax_tau_gather(const float* logits, long ld, float inv_tau, float* p
                            const int64_t* ids_b, long ldb, const int* coin_dev,
                            float drop_p, uint32_t drop_seed, uint32_t drop_stream, const void* drop_seed_dev,
                            void* stream);
+/* The same, also writing the bf16 twin of the probabilities (row stride ldpb, zero in columns [V, wpb), wpb < V + 64):
+ * the operand of the products that embed all steps' distributions at once (main_optimize.py:96-111: matcher,
+ * classifier and discriminator embed sample_p).  table == NULL: no fed-back embedding (last decode step). */
+int cst_softmax_tau_gather_b(const float* logits, long ld, float inv_tau, float* p, long ldp,
+                             void* p_bf16, long ldpb, int wpb, int64_t* argmax_out, int R, int V,
+                             const float* table, long ldt, int E, float* out, long ldo, void* out_bf16, long ldob,
+                             const int64_t* ids_b, long ldb, const int* coin_dev,
+                             float drop_p, uint32_t drop_seed, uint32_t drop_stream, const void* drop_seed_dev,
+                             void* stream);
 /* dx = inv_tau * p * (dp - sum(dp * p)); dx may alias dp. */
 int cst_softmax_tau_bwd(const float* p, long ldp, const float* dp, long lddp, float inv_tau,
                         float* dx, long lddx, void* dx_bf16, long lddxb, int R, int V, void* stream);

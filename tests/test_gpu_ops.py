@@ -221,6 +221,57 @@ def test_softmax_tau(ops, R, V, tau):
     close(dx, xr.grad, 5e-4, 1e-5)      # p*(dp - sum(dp p)) cancels; the sum order depends on the workgroup width
 
 
+@pytest.mark.parametrize("R,V,with_gather", [(40, 10000, True), (40, 10000, False), (9, 1000, True), (5, 4100, False)])
+def test_softmax_tau_bf16_twin(ops, R, V, with_gather):
+    """cst_softmax_tau_gather_b: same p / argmax / fed-back embedding as the plain entries, plus bf16(p) with zero padding."""
+    x = dev(rnd(R, V, seed=5, scale=2.0))
+    E, Vp, T = 16, (V + 63) // 64 * 64, 3
+    tab = dev(rnd(V, E, seed=6))
+    p0 = torch.empty(R, V, device="cuda")
+    am0 = torch.empty(R, dtype=torch.int64, device="cuda")
+    e0 = torch.full((R, E), float("nan"), device="cuda")
+    ops.softmax_tau(x, 2.0, p0, am0, gather=dict(table=tab, out=e0) if with_gather else None)
+    p1 = torch.empty(R, V, device="cuda")
+    am1 = torch.empty(R, dtype=torch.int64, device="cuda")
+    e1 = torch.full((R, E), float("nan"), device="cuda")
+    big = torch.full((R, T * Vp), 0x7fc0, dtype=torch.int16, device="cuda")       # rows strided like the decoder's buffer
+    pb = big[:, Vp:2 * Vp]
+    ops.softmax_tau(x, 2.0, p1, am1, gather=dict(table=tab, out=e1) if with_gather else None, p_b=pb)
+    assert torch.equal(p0, p1) and torch.equal(am0, am1)
+    if with_gather:
+        assert torch.equal(e0, e1) and torch.equal(e1, tab[am1])
+    assert torch.equal(pb[:, :V].contiguous().view(torch.bfloat16), p1.to(torch.bfloat16))
+    assert (pb[:, V:] == 0).all()
+    assert (big[:, :Vp] == 0x7fc0).all() and (big[:, 2 * Vp:] == 0x7fc0).all()
+
+
+def test_shared_soft_embed_bf16_twin_matches_staged_product(ops):
+    """ops.SharedSoftEmbedFn on the softmax kernel's bf16 twin == the fp32-staged product (both round operands to bf16)."""
+    ops.set_precision("bf16")
+    R, V = 192, 10000
+    Vp = (V + 63) // 64 * 64
+    x = dev(rnd(R, V, seed=7, scale=2.0))
+    tabs = [dev(rnd(V, 128, seed=8)), dev(rnd(V, 256, seed=9)), dev(rnd(64, V, seed=10))]
+    evs = (False, False, True)
+    douts = [dev(rnd(R, w, seed=11 + i)) for i, w in enumerate((128, 256, 64))]
+    res = []
+    for twin in (False, True):
+        p = torch.empty(R, V, device="cuda")
+        pb = torch.empty(R, Vp, dtype=torch.int16, device="cuda") if twin else None
+        ops.softmax_tau(x, 1.0, p, None, p_b=pb)
+        p.requires_grad_(True)
+        if twin:
+            ops._side_put(p, pb)
+        outs = ops.SharedSoftEmbedFn.apply(p, evs, *tabs)
+        torch.autograd.backward(outs, douts)
+        res.append(([o.detach().clone() for o in outs], p.grad.clone()))
+    for a, b in zip(res[0][0], res[1][0]):
+        close(a, b, 1e-3, 1e-4)
+    close(res[0][1], res[1][1], 2e-2, 2e-2 * float(res[0][1].abs().max()))     # d p: dout is rounded to bf16 by a cast here, in staging there
+    ref = torch.softmax(x, -1).cpu() @ tabs[1].cpu()
+    close(res[1][0][1], ref, 3e-2, 3e-2 * float(ref.abs().max()))
+
+
 def test_argmax_ties_first_index(ops):
     x = torch.zeros(3, 1000)
     x[0, 17] = x[0, 500] = 2.0
