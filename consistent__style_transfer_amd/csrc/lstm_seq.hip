@@ -40,6 +40,7 @@ struct LstmSeqDir {
     float* gates;                      // [L, B, 4H] activated gates (kept for backward)
     float* cenc;                       // [L, B, H]  cell states of steps 0..L-2 (slot of the step's time index)
     float* hprev;                      // [B, L*H]   h entering each time index (B operand of dW_hh)
+    bf16_t* hprevb;                    // optional bf16 twin of hprev (operand of the transposed-read weight-gradient product)
     float* c_last;                     // [B, .]     cell state after the last step (leading dimension ldcl)
     int reverse;                       // 0: t = n, 1: t = L-1-n
 };
@@ -68,6 +69,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             const float v = D.h0[(long)(r0 + r) * a.ldh0 + u];
             hA[r * SQ_HS + u] = sq_f2bf(v);
             D.hprev[(long)(r0 + r) * L * H + (long)t0 * H + u] = v;
+            if (D.hprevb) D.hprevb[(long)(r0 + r) * L * H + (long)t0 * H + u] = sq_f2bf(v);
         }
     }
     float c[SQ_J][4];
@@ -147,7 +149,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 a.mem[mo] = h;
                 const bf16_t hb = sq_f2bf(h);
                 a.memb[mo] = hb;
-                if (!last) D.hprev[(long)row * L * H + (long)tn * H + u] = h;
+                if (!last) {
+                    D.hprev[(long)row * L * H + (long)tn * H + u] = h;
+                    if (D.hprevb) D.hprevb[(long)row * L * H + (long)tn * H + u] = hb;
+                }
                 hA[(4 * lq + r) * SQ_HS + u] = hb;
             }
         }
@@ -156,15 +161,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 
 extern "C" int cst_lstm_seq_fwd(const void* whh0, const void* whh1, const float* xp0, const float* xp1,
                                 const float* h0, long ldh0, float* gates0, float* gates1, float* cenc0, float* cenc1,
-                                float* hprev0, float* hprev1, float* c_last, long ldcl, float* mem, void* mem_bf16,
+                                float* hprev0, float* hprev1, void* hprev0_bf16, void* hprev1_bf16,
+                                float* c_last, long ldcl, float* mem, void* mem_bf16,
                                 int B, int L, int H, void* stream) {
     CST_REQUIRE(whh0 && whh1 && xp0 && xp1 && h0 && gates0 && gates1 && cenc0 && cenc1 && hprev0 && hprev1 && c_last && mem && mem_bf16,
                 "cst_lstm_seq_fwd: null pointer");
     CST_REQUIRE(H == SQ_H && B > 0 && B % 16 == 0 && L > 0, "cst_lstm_seq_fwd: needs H == %d and B %% 16 == 0 (H=%d, B=%d)", SQ_H, H, B);
     CST_REQUIRE(((((uintptr_t)whh0) | ((uintptr_t)whh1)) & 15) == 0, "cst_lstm_seq_fwd: W_hh fragment copies must be 16-byte aligned");
     LstmSeqArgs a;
-    a.dir[0] = LstmSeqDir{(const bf16_t*)whh0, xp0, h0, gates0, cenc0, hprev0, c_last, 0};
-    a.dir[1] = LstmSeqDir{(const bf16_t*)whh1, xp1, h0 + H, gates1, cenc1, hprev1, c_last + H, 1};
+    CST_REQUIRE(!hprev0_bf16 == !hprev1_bf16, "cst_lstm_seq_fwd: pass both bf16 hprev twins or neither");
+    a.dir[0] = LstmSeqDir{(const bf16_t*)whh0, xp0, h0, gates0, cenc0, hprev0, (bf16_t*)hprev0_bf16, c_last, 0};
+    a.dir[1] = LstmSeqDir{(const bf16_t*)whh1, xp1, h0 + H, gates1, cenc1, hprev1, (bf16_t*)hprev1_bf16, c_last + H, 1};
     a.mem = mem; a.memb = (bf16_t*)mem_bf16; a.B = B; a.L = L; a.ldw = 0; a.ldh0 = ldh0; a.ldcl = ldcl;
     hipLaunchKernelGGL(lstm_seq_fwd_kernel, dim3(B / 16, 2), dim3(256), 0, (hipStream_t)stream, a);
     CST_LAUNCH_CHECK("cst_lstm_seq_fwd");
@@ -186,6 +193,7 @@ struct LstmSeqBwdDir {
     const float* c_last;               // [B, .]  (ldcl)
     const float* dc_last;              // [B, .]  gradient w.r.t. the final cell state (lddcl)
     float* dgates;                     // [B, L*4H] pre-activation gate gradients (operand of the weight gradients)
+    bf16_t* dgatesb;                   // optional bf16 twin of dgates
     float* dh0;                        // [B, .]  gradient w.r.t. the initial hidden state (lddh0)
     int reverse;
 };
@@ -240,7 +248,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 float* dg = D.dgates + (long)row * L * 4 * H + (long)t * 4 * H + u;
                 dg[0] = d0; dg[H] = d1; dg[2 * H] = d2; dg[3 * H] = d3;
                 bf16_t* ga = gA + (4 * lq + r) * SQ_GS + u;
-                ga[0] = sq_f2bf(d0); ga[H] = sq_f2bf(d1); ga[2 * H] = sq_f2bf(d2); ga[3 * H] = sq_f2bf(d3);
+                const bf16_t b0 = sq_f2bf(d0), b1 = sq_f2bf(d1), b2 = sq_f2bf(d2), b3 = sq_f2bf(d3);
+                ga[0] = b0; ga[H] = b1; ga[2 * H] = b2; ga[3 * H] = b3;
+                if (D.dgatesb) {
+                    bf16_t* gb = D.dgatesb + (long)row * L * 4 * H + (long)t * 4 * H + u;
+                    gb[0] = b0; gb[H] = b1; gb[2 * H] = b2; gb[3 * H] = b3;
+                }
             }
         }
         __syncthreads();                                  // the dgates tile is complete
@@ -281,15 +294,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 extern "C" int cst_lstm_seq_bwd(const void* wt0, const void* wt1, const float* gates0, const float* gates1,
                                 const float* cenc0, const float* cenc1, const float* c_last, long ldcl,
                                 const float* dc_last, long lddcl, const float* dmem,
-                                float* dgates0, float* dgates1, float* dh0, long lddh0,
-                                int B, int L, int H, void* stream) {
+                                float* dgates0, float* dgates1, void* dgates0_bf16, void* dgates1_bf16,
+                                float* dh0, long lddh0, int B, int L, int H, void* stream) {
     CST_REQUIRE(wt0 && wt1 && gates0 && gates1 && cenc0 && cenc1 && c_last && dc_last && dmem && dgates0 && dgates1 && dh0,
                 "cst_lstm_seq_bwd: null pointer");
     CST_REQUIRE(H == SQ_H && B > 0 && B % 16 == 0 && L > 0, "cst_lstm_seq_bwd: needs H == %d and B %% 16 == 0 (H=%d, B=%d)", SQ_H, H, B);
     CST_REQUIRE(((((uintptr_t)wt0) | ((uintptr_t)wt1)) & 15) == 0, "cst_lstm_seq_bwd: W_hh^T fragment copies must be 16-byte aligned");
     LstmSeqBwdArgs a;
-    a.dir[0] = LstmSeqBwdDir{(const bf16_t*)wt0, gates0, cenc0, c_last, dc_last, dgates0, dh0, 0};
-    a.dir[1] = LstmSeqBwdDir{(const bf16_t*)wt1, gates1, cenc1, c_last + H, dc_last + H, dgates1, dh0 + H, 1};
+    CST_REQUIRE(!dgates0_bf16 == !dgates1_bf16, "cst_lstm_seq_bwd: pass both bf16 dgates twins or neither");
+    a.dir[0] = LstmSeqBwdDir{(const bf16_t*)wt0, gates0, cenc0, c_last, dc_last, dgates0, (bf16_t*)dgates0_bf16, dh0, 0};
+    a.dir[1] = LstmSeqBwdDir{(const bf16_t*)wt1, gates1, cenc1, c_last + H, dc_last + H, dgates1, (bf16_t*)dgates1_bf16, dh0 + H, 1};
     a.dmem = dmem; a.B = B; a.L = L; a.ldcl = ldcl; a.lddcl = lddcl; a.lddh0 = lddh0;
     hipLaunchKernelGGL(lstm_seq_bwd_kernel, dim3(B / 16, 2), dim3(256), 0, (hipStream_t)stream, a);
     CST_LAUNCH_CHECK("cst_lstm_seq_bwd");

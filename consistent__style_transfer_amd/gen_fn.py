@@ -121,13 +121,18 @@ class GeneratorFn(torch.autograd.Function):
 
         # ---- encoder input embedding (rnn.py:58-61) ------------------------------------------
         emb = _new(dev, B * Lp, E)
+        use_b = _bf16_ok(H, 4 * H, E + Hd, 4 * Hd, Hd + 2 * H, Hd)      # bf16-operand GEMMs for the recurrent products
+        seq_fused = use_b and H == 256 and B % 16 == 0                  # whole-sequence encoder kernels
+        # the encoder's input-side products (x W_ih^T, d emb, dW_ih, dW_hh) on bf16 twins written by their producers
+        enc_b = seq_fused and E % 64 == 0 and (B * Lp) % 64 == 0
+        embb = _i16(dev, B * Lp, E) if enc_b else None
         if inp.dim() == 2:
             ids_in = inp.contiguous().reshape(-1)
-            embed_gather(E_tok, emb, ids_a=ids_in, drop=drop.at(STREAM_G_EMB_IN))
+            embed_gather(E_tok, emb, ids_a=ids_in, drop=drop.at(STREAM_G_EMB_IN), out_b=embb)
             in_drop = drop.at(STREAM_G_EMB_IN)
         else:
             ids_in = argmax_rows(inp.reshape(B * Lp, V))        # hard_sample(inp) @ E == row gather
-            embed_gather(E_tok, emb, ids_a=ids_in)
+            embed_gather(E_tok, emb, ids_a=ids_in, out_b=embb)
             in_drop = NO_DROP
 
         # ---- BiLSTM encoder (rnn.py:57,62) ---------------------------------------------------
@@ -141,21 +146,23 @@ class GeneratorFn(torch.autograd.Function):
         zeros_c = torch.zeros(B, H, device=dev, dtype=torch.float32)
         mem2 = memory.view(B, Lp * 2 * H)
         W_ = Hd + 2 * H
-        use_b = _bf16_ok(H, 4 * H, E + Hd, 4 * Hd, W_, Hd)      # bf16-operand GEMMs for the recurrent products
+        hprevb = _i16(dev, 2, B, Lp, H) if enc_b else None
         memb = _i16(dev, B, Lp * 2 * H) if use_b else None     # bf16 copy of the encoder states (A operand of h W_hh^T)
         enc = []
         for d, suf in enumerate(("", "_reverse")):
             w_ih, w_hh = P["encoder.weight_ih_l0" + suf], P["encoder.weight_hh_l0" + suf]
             bsum = axpby(P["encoder.bias_ih_l0" + suf].view(1, -1), 1.0, P["encoder.bias_hh_l0" + suf].view(1, -1), 1.0).view(-1)
-            xp = linear_fwd(emb, w_ih, bsum).view(B, Lp * 4 * H)        # (B, L', 4H)
+            if enc_b:
+                xp = gemm_bf16(embb, weight_bf16(w_ih)[0], B * Lp, 4 * H, C=_new(dev, B * Lp, 4 * H), bias=bsum).view(B, Lp * 4 * H)
+            else:
+                xp = linear_fwd(emb, w_ih, bsum).view(B, Lp * 4 * H)        # (B, L', 4H)
             order = list(range(Lp)) if d == 0 else list(range(Lp - 1, -1, -1))
             enc.append((w_hh, weight_bf16(w_hh)[0] if use_b else None, xp, order, hprev[d].view(B, Lp * H)))
-        seq_fused = use_b and H == 256 and B % 16 == 0
         if seq_fused:
             # both directions, all L' steps, one launch: 16 batch rows per workgroup, no inter-workgroup dependencies
             (_, wb0, xp0, _, _), (_, wb1, xp1, _, _) = enc
             call("cst_lstm_seq_fwd", _lstm_frag_order(wb0, H), _lstm_frag_order(wb1, H), xp0, xp1, h0cat, 2 * H, genc[0], genc[1], cenc[0], cenc[1],
-                 hprev[0], hprev[1], c_cat, 2 * H, memory, memb, B, Lp, H)
+                 hprev[0], hprev[1], hprevb[0] if enc_b else None, hprevb[1] if enc_b else None, c_cat, 2 * H, memory, memb, B, Lp, H)
         for n in (() if seq_fused else range(Lp)):
             probs = []
             for d, (w_hh, whh_b, xp, order, hp2) in enumerate(enc):
@@ -270,7 +277,7 @@ class GeneratorFn(torch.autograd.Function):
         ctx.cfg = (B, Lp, T, V, E, H, Hd, soft, inv_tau, drop, in_drop, inp.dim() == 3, use_b)
         ctx.save_for_backward(*params, emb, ids_in, label_i, label, h0cat, memory, hprev, genc, cenc, c_cat, c0,
                               wcat, XH, gdec, cdec, iffn, iffn_d, patt, r1, out, ids_fb, x_c, coins, zeros_c,
-                              inp if inp.dim() == 3 else None, wcat_t, r1b, XHb, ifdb)
+                              inp if inp.dim() == 3 else None, wcat_t, r1b, XHb, ifdb, embb, hprevb)
         ctx.mark_non_differentiable(ids_fb)
         return out, ids_fb
 
@@ -281,7 +288,7 @@ class GeneratorFn(torch.autograd.Function):
         n = len(PARAM_KEYS)
         P = dict(zip(PARAM_KEYS, sv[:n]))
         (emb, ids_in, label_i, label, h0cat, memory, hprev, genc, cenc, c_cat, c0, wcat, XH, gdec, cdec, iffn,
-         iffn_d, patt, r1, out, ids_fb, x_c, coins, zeros_c, inp3, wcat_t, r1b, XHb, ifdb) = sv[n:]
+         iffn_d, patt, r1, out, ids_fb, x_c, coins, zeros_c, inp3, wcat_t, r1b, XHb, ifdb, embb, hprevb) = sv[n:]
         dev = dout.device
         E_tok = P["token_embedding.weight"]
         dout = dout.contiguous()                      # (B,T,V); in softmax mode rewritten in place to dlogits
@@ -445,10 +452,13 @@ class GeneratorFn(torch.autograd.Function):
             order = list(range(Lp)) if d == 0 else list(range(Lp - 1, -1, -1))
             encb.append((w_ih, w_hh, weight_bf16(w_hh)[1] if use_b else None, order, dge[d].view(B, Lp * 4 * H)))   # whh_t [H, 4H]
         seq_bwd = use_b and H == 256 and B % 16 == 0
+        enc_b = seq_bwd and embb is not None
+        dgeb = _i16(dev, 2, B * Lp, 4 * H) if enc_b else None
         if seq_bwd:
             # both directions, all steps, one launch (mirror of cst_lstm_seq_fwd)
             call("cst_lstm_seq_bwd", _lstm_frag_order_t(encb[0][2], H), _lstm_frag_order_t(encb[1][2], H), genc[0], genc[1],
-                 cenc[0], cenc[1], c_cat, 2 * H, dc_cat, dc_cat.stride(0), dmem, dge[0], dge[1], dh0cat, 2 * H, B, Lp, H)
+                 cenc[0], cenc[1], c_cat, 2 * H, dc_cat, dc_cat.stride(0), dmem, dge[0], dge[1],
+                 dgeb[0] if enc_b else None, dgeb[1] if enc_b else None, dh0cat, 2 * H, B, Lp, H)
         for n_ in (() if seq_bwd else range(Lp - 1, -1, -1)):
             probs = []
             for d, (w_ih, w_hh, whh_t, order, dg2d) in enumerate(encb):
@@ -475,12 +485,18 @@ class GeneratorFn(torch.autograd.Function):
                 gemm_bf16(dgtb2[d], whh_t, B, H, C=dh0cat[:, d * H:(d + 1) * H])
             dgf = dge[d].view(B * Lp, 4 * H)
             suf = "" if d == 0 else "_reverse"
-            G["encoder.weight_hh_l0" + suf] = wgrad(dgf, hprev[d].view(B * Lp, H))
-            G["encoder.weight_ih_l0" + suf] = wgrad(dgf, emb)
+            if enc_b:
+                # dgates^T [h_prev], dgates^T emb through transposed LDS reads of the row-major bf16 twins; d emb on the bf16 GEMM
+                G["encoder.weight_hh_l0" + suf] = ops.gemm_bf16_tt(dgeb[d], hprevb[d].view(B * Lp, H), 4 * H, H)
+                G["encoder.weight_ih_l0" + suf] = ops.gemm_bf16_tt(dgeb[d], embb, 4 * H, E)
+                gemm_bf16(dgeb[d], weight_bf16(w_ih)[1], B * Lp, E, C=demb, accumulate=d == 1)
+            else:
+                G["encoder.weight_hh_l0" + suf] = wgrad(dgf, hprev[d].view(B * Lp, H))
+                G["encoder.weight_ih_l0" + suf] = wgrad(dgf, emb)
+                dgrad(dgf, w_ih, out=demb, accumulate=d == 1)
             dbe = colsum(dgf)
             G["encoder.bias_ih_l0" + suf] = dbe
             G["encoder.bias_hh_l0" + suf] = dbe.clone()
-            dgrad(dgf, w_ih, out=demb, accumulate=d == 1)
         dstyle_e = torch.zeros_like(P["enc_style_embedding.weight"])
         embed_scatter_add(dstyle_e, dh0cat, ids_a=label_i)
         G["enc_style_embedding.weight"] = dstyle_e

@@ -209,23 +209,26 @@ int cst_gemm_bf16_tt(const void* A, long lda, const void* B, long ldb, float* C,
  *   contiguous KiB); xp{0,1}: [B, L*4H] input projections
  *   incl. biases; h0 [B, ldh0]: forward direction's initial state at column 0, reverse at column H; outputs as the
  *   per-step path writes them: gates{0,1} [L,B,4H] (activated), cenc{0,1} [L,B,H], hprev{0,1} [B, L*H] (h entering each
- *   time index), c_last [B, ldcl] (final cell states at columns 0 / H), mem [B, L*2H] and its bf16 twin.
+ *   time index; hprev{0,1}_bf16: optional bf16 twins, both or neither -- the operand of the transposed-read dW_hh product),
+ *   c_last [B, ldcl] (final cell states at columns 0 / H), mem [B, L*2H] and its bf16 twin.
  * H must be 256 and B a multiple of 16 (status 1 otherwise: use the per-step entry points). */
 int cst_lstm_seq_fwd(const void* whh0, const void* whh1, const float* xp0, const float* xp1,
                      const float* h0, long ldh0, float* gates0, float* gates1, float* cenc0, float* cenc1,
-                     float* hprev0, float* hprev1, float* c_last, long ldcl, float* mem, void* mem_bf16,
+                     float* hprev0, float* hprev1, void* hprev0_bf16, void* hprev1_bf16,
+                     float* c_last, long ldcl, float* mem, void* mem_bf16,
                      int B, int L, int H, void* stream);
 
 /* Backward of cst_lstm_seq_fwd, also one launch: per step the cell backward in registers and dh_{prev} = dgates W_hh on
  * the bf16 matrix pipe.  wt{0,1}: W_hh^T in bf16 fragment order [wave 4][k step 32][tile 4][lane 64][8] (element
  * [w][kk][j][16*lq + lr][e] = W_hh[32kk + 8lq + e][64w + 16j + lr]); gates / cenc / c_last as the forward wrote them;
  * dc_last [B, lddcl]: gradient w.r.t. the final cell states (columns 0 / H); dmem [B, L*2H]: gradient w.r.t. the encoder
- * states; outputs dgates{0,1} [B, L*4H] (pre-activation gate gradients at column t*4H) and dh0 [B, lddh0]. */
+ * states; outputs dgates{0,1} [B, L*4H] (pre-activation gate gradients at column t*4H), optionally their bf16 twins
+ * (both or neither: operands of the weight-gradient and input-gradient products) and dh0 [B, lddh0]. */
 int cst_lstm_seq_bwd(const void* wt0, const void* wt1, const float* gates0, const float* gates1,
                      const float* cenc0, const float* cenc1, const float* c_last, long ldcl,
                      const float* dc_last, long lddcl, const float* dmem,
-                     float* dgates0, float* dgates1, float* dh0, long lddh0,
-                     int B, int L, int H, void* stream);
+                     float* dgates0, float* dgates1, void* dgates0_bf16, void* dgates1_bf16,
+                     float* dh0, long lddh0, int B, int L, int H, void* stream);
 
 /* One recurrent step of nn.LSTM (rnn.py:25-33, called at rnn.py:57 and :75) in two launches, for one problem
  * or for two independent problems of one shape (the *2 / *_p2 arguments; A2 == NULL: single) -- the two

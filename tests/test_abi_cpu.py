@@ -50,8 +50,8 @@ def test_fused_entry_points_validate_their_limits():
     assert L.fn["cst_dot_attn_bwd_steps"](P, 0, 0, P, 0, 0, P, P, P, 4, 3, 7, 768, 0.0, 0, 0, None, None) == 1
     assert L.fn["cst_dot_attn_bwd_steps"](P, 0, 0, P, 0, 0, P, P, P, 4, 3, 70, 64, 0.0, 0, 0, None, None) == 1
     # whole-sequence encoder kernels: H == 256, B % 16 == 0
-    assert L.fn["cst_lstm_seq_fwd"](P, P, P, P, P, 512, P, P, P, P, P, P, P, 512, P, P, 32, 5, 128, None) == 1 and "H == 256" in L.last_error()
-    assert L.fn["cst_lstm_seq_bwd"](P, P, P, P, P, P, P, 512, P, 512, P, P, P, P, 512, 24, 5, 256, None) == 1
+    assert L.fn["cst_lstm_seq_fwd"](P, P, P, P, P, 512, P, P, P, P, P, P, None, None, P, 512, P, P, 32, 5, 128, None) == 1 and "H == 256" in L.last_error()
+    assert L.fn["cst_lstm_seq_bwd"](P, P, P, P, P, P, P, 512, P, 512, P, P, P, None, None, P, 512, 24, 5, 256, None) == 1
     # softmax with a bf16 twin: the twin pointer is mandatory
     assert L.fn["cst_softmax_tau_gather_b"](P, 10000, 1.0, P, 10000, None, 10048, 10048, None, 4, 10000, None, 0, 0, None, 0, None, 0,
                                             None, 1, None, 0.0, 0, 0, None, None) == 1 and "null bf16" in L.last_error()

@@ -795,9 +795,11 @@ def test_lstm_seq_fwd_equals_per_step_path(ops):
                                         c_out=r["c_cat"][:, d * H:(d + 1) * H] if last else r["cenc"][d, t],
                                         h_out2=None if last else hp2[:, order[n + 1] * H:(order[n + 1] + 1) * H],
                                         addend=xp[d][:, t * 4 * H:(t + 1) * 4 * H], hb=r["memb"][:, t * 2 * H + d * H: t * 2 * H + (d + 1) * H])], B, H)
+    hpb = torch.empty(2, B, L, H, device="cuda", dtype=torch.int16)
     call("cst_lstm_seq_fwd", gen_fn._lstm_frag_order(wb[0], H), gen_fn._lstm_frag_order(wb[1], H), xp[0], xp[1], h0, 2 * H, f["genc"][0], f["genc"][1], f["cenc"][0], f["cenc"][1],
-         f["hprev"][0], f["hprev"][1], f["c_cat"], 2 * H, f["mem"], f["memb"], B, L, H)
+         f["hprev"][0], f["hprev"][1], hpb[0], hpb[1], f["c_cat"], 2 * H, f["mem"], f["memb"], B, L, H)
     torch.cuda.synchronize()
+    assert torch.equal(hpb.view(torch.bfloat16), f["hprev"].to(torch.bfloat16))      # the optional bf16 twin of hprev
     for k in ("genc", "hprev", "c_cat", "mem"):
         close(f[k], r[k], 2e-3, 2e-3, k)                       # bf16 h feedback: rounding-level differences compound over the steps
     for d in range(2):                                        # cell states of every step but the last (that one lives in c_cat)
@@ -838,8 +840,10 @@ def test_lstm_seq_bwd_equals_per_step_path(ops):
                                             dgates=dgt, dc_prev=dce, dgb=dgb)], B, H)
         ops.gemm_bf16(dgb, wt[d], B, H, C=r_dh0[:, d * H:(d + 1) * H])
     f_dge, f_dh0 = torch.empty(2, B, L, 4 * H, device="cuda"), torch.empty(B, 2 * H, device="cuda")
+    f_dgb = torch.empty(2, B, L, 4 * H, device="cuda", dtype=torch.int16)
     call("cst_lstm_seq_bwd", gen_fn._lstm_frag_order_t(wt[0], H), gen_fn._lstm_frag_order_t(wt[1], H), genc[0], genc[1], cenc[0], cenc[1],
-         c_cat, 2 * H, dc_cat, 2 * H, dmem, f_dge[0], f_dge[1], f_dh0, 2 * H, B, L, H)
+         c_cat, 2 * H, dc_cat, 2 * H, dmem, f_dge[0], f_dge[1], f_dgb[0], f_dgb[1], f_dh0, 2 * H, B, L, H)
     torch.cuda.synchronize()
+    assert torch.equal(f_dgb.view(torch.bfloat16), f_dge.to(torch.bfloat16))         # the optional bf16 twin of dgates
     close(f_dge, r_dge, 5e-3, 5e-3)                  # bf16 dgates feedback: rounding-level differences compound over the steps
     close(f_dh0, r_dh0, 5e-3, 5e-3)

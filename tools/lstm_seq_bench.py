@@ -11,7 +11,7 @@ h0 = torch.randn(B, 2 * H, device="cuda") * 0.5
 genc, cenc = torch.empty(2, L, B, 4 * H, device="cuda"), torch.zeros(2, L, B, H, device="cuda")
 hprev, c_cat = torch.empty(2, B, L, H, device="cuda"), torch.empty(B, 2 * H, device="cuda")
 mem, memb = torch.empty(B, L, 2 * H, device="cuda"), torch.zeros(B, L * 2 * H, device="cuda", dtype=torch.int16)
-f = lambda: call("cst_lstm_seq_fwd", gen_fn._lstm_frag_order(wb[0], H), gen_fn._lstm_frag_order(wb[1], H), xp[0], xp[1], h0, 2 * H, genc[0], genc[1], cenc[0], cenc[1], hprev[0], hprev[1], c_cat, 2 * H, mem, memb, B, L, H)
+f = lambda: call("cst_lstm_seq_fwd", gen_fn._lstm_frag_order(wb[0], H), gen_fn._lstm_frag_order(wb[1], H), xp[0], xp[1], h0, 2 * H, genc[0], genc[1], cenc[0], cenc[1], hprev[0], hprev[1], None, None, c_cat, 2 * H, mem, memb, B, L, H)
 for _ in range(3): f()
 torch.cuda.synchronize()
 a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
