@@ -78,7 +78,7 @@ def _bf16_round(t):
     return t.to(torch.bfloat16).float()
 
 
-@pytest.mark.parametrize("R,C", [(5, 7), (64, 64), (100, 130), (4608, 512), (37, 2048)])
+@pytest.mark.parametrize("R,C", [(5, 7), (64, 64), (100, 130), (4608, 512), (37, 2048), (2048, 512), (10000, 768), (101, 36), (3, 4), (130, 260)])
 def test_cast_bf16(ops, R, C):
     x = rnd(R, C, seed=1)
     rm, tr = ops.cast_bf16(dev(x))
