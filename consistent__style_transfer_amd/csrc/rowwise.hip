@@ -533,6 +533,75 @@ __global__ __launch_bounds__(256) void add_layernorm_fwd_kernel(const float* __r
     if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
 }
 
+// d == 256 * NV and 16-byte aligned operands (the module constants 512 / 768 / 1024): one float4 per lane per 256 columns,
+// every load of the row in flight before the first use, 16-byte stores (8-byte for the bf16 twin)
+template <int NV>
+__global__ __launch_bounds__(256) void add_layernorm_fwd_vec_kernel(const float* __restrict__ x, const float* __restrict__ res,
+                                                                    const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                    float eps, float* z, float* __restrict__ y,
+                                                                    float* __restrict__ mean, float* __restrict__ rstd,
+                                                                    int T, CstDrop drop, unsigned short* __restrict__ yb, long ldyb) {
+    constexpr int d = 256 * NV;
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= T) return;
+    float4 v[NV], r[NV], ga[NV], be[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) v[i] = *reinterpret_cast<const float4*>(x + row * d + 4 * lane + 256 * i);
+    if (res) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) r[i] = *reinterpret_cast<const float4*>(res + row * d + 4 * lane + 256 * i);
+    } else {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) r[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        ga[i] = *reinterpret_cast<const float4*>(gamma + 4 * lane + 256 * i);
+        be[i] = *reinterpret_cast<const float4*>(beta + 4 * lane + 256 * i);
+    }
+    if (drop.p > 0.f) {
+        const uint32_t dseed = cst_drop_seed(drop);
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const uint32_t e = (uint32_t)(row * d + 4 * lane + 256 * i);
+            v[i].x *= cst_drop_mask(drop, dseed, e); v[i].y *= cst_drop_mask(drop, dseed, e + 1);
+            v[i].z *= cst_drop_mask(drop, dseed, e + 2); v[i].w *= cst_drop_mask(drop, dseed, e + 3);
+        }
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        v[i].x += r[i].x; v[i].y += r[i].y; v[i].z += r[i].z; v[i].w += r[i].w;
+        s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+    }
+    const float mu = wave_sum(s) / (float)d;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const float a = v[i].x - mu, b = v[i].y - mu, c = v[i].z - mu, e = v[i].w - mu;
+        q += (a * a + b * b) + (c * c + e * e);
+    }
+    const float rs = 1.0f / sqrtf(wave_sum(q) / (float)d + eps);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const long o = row * d + 4 * lane + 256 * i;
+        if (z) *reinterpret_cast<float4*>(z + o) = v[i];
+        float4 yv;
+        yv.x = (v[i].x - mu) * rs * ga[i].x + be[i].x; yv.y = (v[i].y - mu) * rs * ga[i].y + be[i].y;
+        yv.z = (v[i].z - mu) * rs * ga[i].z + be[i].z; yv.w = (v[i].w - mu) * rs * ga[i].w + be[i].w;
+        *reinterpret_cast<float4*>(y + o) = yv;
+        if (yb) {                                                     // next GEMM's A operand
+            __bf16 h0 = (__bf16)yv.x, h1 = (__bf16)yv.y, h2 = (__bf16)yv.z, h3 = (__bf16)yv.w;
+            uint2 u;
+            u.x = (uint32_t)__builtin_bit_cast(unsigned short, h0) | ((uint32_t)__builtin_bit_cast(unsigned short, h1) << 16);
+            u.y = (uint32_t)__builtin_bit_cast(unsigned short, h2) | ((uint32_t)__builtin_bit_cast(unsigned short, h3) << 16);
+            *reinterpret_cast<uint2*>(yb + row * ldyb + 4 * lane + 256 * i) = u;
+        }
+    }
+    if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
+}
+
 extern "C" int cst_add_layernorm_fwd_b(const float* x, const float* res, const float* gamma, const float* beta, float eps,
                                        float* z, float* y, float* mean, float* rstd, int T, int d,
                                        float drop_p, uint32_t drop_seed, uint32_t drop_stream, const void* drop_seed_dev,
@@ -541,6 +610,15 @@ extern "C" int cst_add_layernorm_fwd_b(const float* x, const float* res, const f
     CST_REQUIRE(T > 0 && d > 0 && d <= 64 * LN_MAXE, "cst_add_layernorm_fwd: d=%d unsupported (max %d)", d, 64 * LN_MAXE);
     CST_REQUIRE(!y_bf16 || ldyb >= d, "cst_add_layernorm_fwd: bf16 leading dimension < d");
     CstDrop dr = cst_make_drop(drop_p, drop_seed, drop_stream, drop_seed_dev);
+    const uintptr_t al = (uintptr_t)x | (uintptr_t)res | (uintptr_t)gamma | (uintptr_t)beta | (uintptr_t)z | (uintptr_t)y;
+    if (d % 256 == 0 && d <= 1024 && (al & 15) == 0 && (!y_bf16 || (ldyb % 4 == 0 && (((uintptr_t)y_bf16) & 7) == 0))) {
+#define LN_FWD_V(NV) hipLaunchKernelGGL(add_layernorm_fwd_vec_kernel<NV>, dim3(cst_div_up(T, 4)), dim3(256), 0, (hipStream_t)stream, \
+                                        x, res, gamma, beta, eps, z, y, mean, rstd, T, dr, (unsigned short*)y_bf16, ldyb)
+        if (d == 256) LN_FWD_V(1); else if (d == 512) LN_FWD_V(2); else if (d == 768) LN_FWD_V(3); else LN_FWD_V(4);
+#undef LN_FWD_V
+        CST_LAUNCH_CHECK("cst_add_layernorm_fwd");
+        return CST_OK;
+    }
 #define LN_FWD(NEV) hipLaunchKernelGGL(add_layernorm_fwd_kernel<NEV>, dim3(cst_div_up(T, 4)), dim3(256), 0, (hipStream_t)stream, \
                                        x, res, gamma, beta, eps, z, y, mean, rstd, T, d, dr, (unsigned short*)y_bf16, ldyb)
     const int ne = cst_div_up(d, 64);
@@ -637,6 +715,109 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
     }
 }
 
+// d == 256 * NV, 16-byte aligned operands: float4 per lane per 256 columns, the next row of the wave requested before the
+// current one is reduced (the per-row chain load -> two wave reductions -> store otherwise leaves the memory pipe idle).
+template <int NV>
+__global__ __launch_bounds__(256) void layernorm_bwd_vec_kernel(const float* __restrict__ dy, const float* __restrict__ z,
+                                                                const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                                const float* __restrict__ gamma, float* dz,
+                                                                float* __restrict__ part, int T, int rows_per_block,
+                                                                unsigned short* __restrict__ dzb, long lddzb, CstDrop bdrop, int three) {
+    constexpr int d = 256 * NV;
+    __shared__ float sh[3][4][256];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    float4 ag[NV], ab[NV], az[NV], ga[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        ag[i] = ab[i] = az[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        ga[i] = *reinterpret_cast<const float4*>(gamma + 4 * lane + 256 * i);
+    }
+    const long r0 = (long)blockIdx.x * rows_per_block;
+    const long rend = min((long)T, r0 + rows_per_block);
+    const uint32_t bseed = (dzb && bdrop.p > 0.f) ? cst_drop_seed(bdrop) : 0u;
+    float4 dyn[NV], zn[NV];
+    float mun = 0.f, rsn = 0.f;
+    long row = r0 + w;
+    if (row < rend) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            dyn[i] = *reinterpret_cast<const float4*>(dy + row * d + 4 * lane + 256 * i);
+            zn[i] = *reinterpret_cast<const float4*>(z + row * d + 4 * lane + 256 * i);
+        }
+        mun = mean[row]; rsn = rstd[row];
+    }
+    while (row < rend) {
+        float4 dyv[NV], xh[NV], g[NV];
+        const float mu = mun, rs = rsn;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) { dyv[i] = dyn[i]; xh[i] = zn[i]; }
+        const long nrow = row + 4;
+        if (nrow < rend) {
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                dyn[i] = *reinterpret_cast<const float4*>(dy + nrow * d + 4 * lane + 256 * i);
+                zn[i] = *reinterpret_cast<const float4*>(z + nrow * d + 4 * lane + 256 * i);
+            }
+            mun = mean[nrow]; rsn = rstd[nrow];
+        }
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            xh[i].x = (xh[i].x - mu) * rs; xh[i].y = (xh[i].y - mu) * rs; xh[i].z = (xh[i].z - mu) * rs; xh[i].w = (xh[i].w - mu) * rs;
+            g[i].x = dyv[i].x * ga[i].x; g[i].y = dyv[i].y * ga[i].y; g[i].z = dyv[i].z * ga[i].z; g[i].w = dyv[i].w * ga[i].w;
+            s1 += (g[i].x + g[i].y) + (g[i].z + g[i].w);
+            s2 += (g[i].x * xh[i].x + g[i].y * xh[i].y) + (g[i].z * xh[i].z + g[i].w * xh[i].w);
+            ag[i].x += dyv[i].x * xh[i].x; ag[i].y += dyv[i].y * xh[i].y; ag[i].z += dyv[i].z * xh[i].z; ag[i].w += dyv[i].w * xh[i].w;
+            ab[i].x += dyv[i].x; ab[i].y += dyv[i].y; ab[i].z += dyv[i].z; ab[i].w += dyv[i].w;
+        }
+        s1 = wave_sum(s1) / (float)d; s2 = wave_sum(s2) / (float)d;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const long o = row * d + 4 * lane + 256 * i;
+            float4 dv;
+            dv.x = rs * (g[i].x - s1 - xh[i].x * s2); dv.y = rs * (g[i].y - s1 - xh[i].y * s2);
+            dv.z = rs * (g[i].z - s1 - xh[i].z * s2); dv.w = rs * (g[i].w - s1 - xh[i].w * s2);
+            *reinterpret_cast<float4*>(dz + o) = dv;
+            if (dzb) {          // dropout'(dz) in bf16: A operand of the dgrad / weight-gradient GEMMs behind this LayerNorm
+                float4 t = dv;
+                if (bdrop.p > 0.f) {
+                    const uint32_t e = (uint32_t)o;
+                    t.x *= cst_drop_mask(bdrop, bseed, e); t.y *= cst_drop_mask(bdrop, bseed, e + 1);
+                    t.z *= cst_drop_mask(bdrop, bseed, e + 2); t.w *= cst_drop_mask(bdrop, bseed, e + 3);
+                }
+                __bf16 h0 = (__bf16)t.x, h1 = (__bf16)t.y, h2 = (__bf16)t.z, h3 = (__bf16)t.w;
+                uint2 u;
+                u.x = (uint32_t)__builtin_bit_cast(unsigned short, h0) | ((uint32_t)__builtin_bit_cast(unsigned short, h1) << 16);
+                u.y = (uint32_t)__builtin_bit_cast(unsigned short, h2) | ((uint32_t)__builtin_bit_cast(unsigned short, h3) << 16);
+                *reinterpret_cast<uint2*>(dzb + row * lddzb + 4 * lane + 256 * i) = u;
+                az[i].x += t.x; az[i].y += t.y; az[i].z += t.z; az[i].w += t.w;
+            }
+        }
+        row = nrow;
+    }
+    // the 4 waves' partial column sums through LDS, 256 columns at a time
+    const long nblk = gridDim.x;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        __syncthreads();
+        *reinterpret_cast<float4*>(&sh[0][w][4 * lane]) = ag[i];
+        *reinterpret_cast<float4*>(&sh[1][w][4 * lane]) = ab[i];
+        *reinterpret_cast<float4*>(&sh[2][w][4 * lane]) = az[i];
+        __syncthreads();
+        const int t = threadIdx.x, c = 256 * i + t;
+        const float sg = (sh[0][0][t] + sh[0][1][t]) + (sh[0][2][t] + sh[0][3][t]);
+        const float sb = (sh[1][0][t] + sh[1][1][t]) + (sh[1][2][t] + sh[1][3][t]);
+        if (three) {
+            const float sz = (sh[2][0][t] + sh[2][1][t]) + (sh[2][2][t] + sh[2][3][t]);
+            float* pr = part + (long)blockIdx.x * 3 * d;
+            pr[c] = sg; pr[d + c] = sb; pr[2 * d + c] = sz;
+        } else {
+            part[(0 * nblk + blockIdx.x) * d + c] = sg;
+            part[(1 * nblk + blockIdx.x) * d + c] = sb;
+        }
+    }
+}
+
 // out[c] (+)= sum_r X[r, c]   (r over M rows); grid (colgroups, rowsplits); atomics when split
 __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ X, long ld, int M, int N,
                                                      float* __restrict__ out, int rows_per_split, int use_atomic, int accumulate) {
@@ -700,11 +881,17 @@ extern "C" int cst_layernorm_bwd_b(const float* dy, const float* z, const float*
     const int rpb = cst_div_up(T, nblk);
     hipStream_t st = (hipStream_t)stream;
     CstDrop bd = cst_make_drop(drop_p, drop_seed, drop_stream, drop_seed_dev);
+    const uintptr_t al = (uintptr_t)dy | (uintptr_t)z | (uintptr_t)gamma | (uintptr_t)dz;
+    const bool vec = d % 256 == 0 && d <= 1024 && (al & 15) == 0 && (!dz_bf16 || (lddzb % 4 == 0 && (((uintptr_t)dz_bf16) & 7) == 0));
+#define LN_BWD_V(NV) hipLaunchKernelGGL(layernorm_bwd_vec_kernel<NV>, dim3(nblk), dim3(256), 0, st, dy, z, mean, rstd, gamma, dz, workspace, T, rpb, \
+                                        (unsigned short*)dz_bf16, lddzb, bd, dparams3 ? 1 : 0)
 #define LN_BWD(NEV) hipLaunchKernelGGL(layernorm_bwd_kernel<NEV>, dim3(nblk), dim3(256), 0, st, dy, z, mean, rstd, gamma, dz, workspace, T, d, rpb, \
                                        (unsigned short*)dz_bf16, lddzb, bd, dparams3 ? 1 : 0)
     const int ne = cst_div_up(d, 64);
-    if (ne <= 4) LN_BWD(4); else if (ne <= 8) LN_BWD(8); else if (ne <= 12) LN_BWD(12); else LN_BWD(16);
+    if (vec) { if (d == 256) LN_BWD_V(1); else if (d == 512) LN_BWD_V(2); else if (d == 768) LN_BWD_V(3); else LN_BWD_V(4); }
+    else if (ne <= 4) LN_BWD(4); else if (ne <= 8) LN_BWD(8); else if (ne <= 12) LN_BWD(12); else LN_BWD(16);
 #undef LN_BWD
+#undef LN_BWD_V
     CST_LAUNCH_CHECK("cst_layernorm_bwd");
     if (dparams3)                                         // (dgamma | dbeta | dbias) in one pass over [nblk, 3d]
         return cst_colsum(workspace, 3L * d, nblk, 3 * d, dparams3, accumulate, stream);

@@ -279,7 +279,7 @@ def test_argmax_ties_first_index(ops):
     assert ops.argmax_rows(dev(x)).cpu().tolist() == [17, 999, 0]
 
 
-@pytest.mark.parametrize("T,d", [(10, 32), (257, 512), (64, 768), (5, 1024), (9, 100)])
+@pytest.mark.parametrize("T,d", [(10, 32), (257, 512), (64, 768), (5, 1024), (9, 100), (33, 256)])
 def test_add_layernorm(ops, T, d):
     from consistent__style_transfer_amd.ops import _ln_bwd, _ln_fwd
     x, res, g, b = rnd(T, d, seed=1), rnd(T, d, seed=2), 1 + 0.1 * rnd(d, seed=3), rnd(d, seed=4)
