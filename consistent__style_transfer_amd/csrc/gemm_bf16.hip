@@ -884,7 +884,24 @@ __global__ __launch_bounds__(1024) void cst_gemm_bf16_lstm_attn_kernel(LstmAttnE
     float* qs = ms + L * D;          // [D]    h_t
     float* sc = qs + D;              // [64]
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    // memory tile: four 16-byte loads in flight per thread, then the cell's operands on top of them
+    // the cell's operands first (split-K slabs, bias, c_{t-1}), then the memory tile: both sets of loads are in flight
+    // together -- issued behind the tile's LDS stores they cost the kernel a second memory round trip
+    float pre[4] = {0.f, 0.f, 0.f, 0.f}, cprev = 0.f;
+    if (tid < D) {
+        const int u = tid;
+        const long MN = (long)q.M * 4 * D;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const long off = (long)b * 4 * D + (long)g * D + u;
+            const float s0 = q.slab[off];
+            const float s1 = q.slab[(q.splits > 1 ? MN : 0) + off];          // unconditional load, select below: stays in flight with s0
+            float a = ((q.bias ? q.bias[g * D + u] : 0.f) + s0) + (q.splits > 1 ? s1 : 0.f);
+            for (int s = 2; s < q.splits; ++s) a += q.slab[s * MN + off];
+            pre[g] = a;
+        }
+        cprev = q.c_prev[(long)b * q.ldcp + u];
+    }
+    // memory tile: four 16-byte loads in flight per thread
     {
         const float4* src = reinterpret_cast<const float4*>(q.mem + (long)b * L * D);
         float4* dst = reinterpret_cast<float4*>(ms);
@@ -902,17 +919,8 @@ __global__ __launch_bounds__(1024) void cst_gemm_bf16_lstm_attn_kernel(LstmAttnE
     }
     if (tid < D) {
         const int u = tid;
-        const long MN = (long)q.M * 4 * D;
-        float pre[4];
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const long off = (long)b * 4 * D + (long)g * D + u;
-            float a = q.bias ? q.bias[g * D + u] : 0.f;
-            for (int s = 0; s < q.splits; ++s) a += q.slab[s * MN + off];
-            pre[g] = a;
-        }
         const float gi = lstm_sigmoid(pre[0]), gf = lstm_sigmoid(pre[1]), gg = tanhf(pre[2]), go = lstm_sigmoid(pre[3]);
-        const float c = gf * q.c_prev[(long)b * q.ldcp + u] + gi * gg;
+        const float c = gf * cprev + gi * gg;
         const float h = go * tanhf(c);
         float* g = q.gates + (long)b * q.ldg + u;
         g[0] = gi; g[D] = gf; g[2 * D] = gg; g[3 * D] = go;
