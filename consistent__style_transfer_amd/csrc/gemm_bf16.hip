@@ -484,6 +484,9 @@ __global__ __launch_bounds__(256) void cst_gemm_bf16_kernel(BGemmArgs g) {
     }
 }
 
+// BATCH: four slab loads in flight at a time (same summation order).  A runtime-bounded loop of one load and one dependent
+// add serialises the L2 latency of every split: worth it from 4 splits up (the long-K products run 16-24).
+template <bool BATCH>
 __global__ __launch_bounds__(256) void cst_gemm_bf16_reduce(BGemmArgs g) {
     const uint32_t dseed = g.drop.p > 0.f ? cst_drop_seed(g.drop) : 0u;
     const long MN = (long)g.M * g.N;
@@ -491,7 +494,17 @@ __global__ __launch_bounds__(256) void cst_gemm_bf16_reduce(BGemmArgs g) {
         const long Q = MN >> 2;
         for (long q = (long)blockIdx.x * 256 + threadIdx.x; q < Q; q += (long)gridDim.x * 256) {
             float4 acc = *reinterpret_cast<const float4*>(g.slab + 4 * q);
-            for (int s = 1; s < g.splits; ++s) {
+            int s = 1;
+            if constexpr (BATCH) {
+                const float* p = g.slab + 4 * q;
+                for (; s + 3 < g.splits; s += 4) {
+                    const float4 t0 = *reinterpret_cast<const float4*>(p + s * MN), t1 = *reinterpret_cast<const float4*>(p + (s + 1) * MN);
+                    const float4 t2 = *reinterpret_cast<const float4*>(p + (s + 2) * MN), t3 = *reinterpret_cast<const float4*>(p + (s + 3) * MN);
+                    acc.x = (((acc.x + t0.x) + t1.x) + t2.x) + t3.x; acc.y = (((acc.y + t0.y) + t1.y) + t2.y) + t3.y;
+                    acc.z = (((acc.z + t0.z) + t1.z) + t2.z) + t3.z; acc.w = (((acc.w + t0.w) + t1.w) + t2.w) + t3.w;
+                }
+            }
+            for (; s < g.splits; ++s) {
                 const float4 t = *reinterpret_cast<const float4*>(g.slab + s * MN + 4 * q);
                 acc.x += t.x; acc.y += t.y; acc.z += t.z; acc.w += t.w;
             }
@@ -587,7 +600,9 @@ extern "C" int cst_gemm_bf16(const void* A, long lda, const void* B, long ldb,
     if (splits > 1) {
         long mn = ((long)M * N + 3) / 4;          // four columns per thread on the vector path
         int rb = (int)((mn + 255) / 256); if (rb > 2048) rb = 2048;
-        hipLaunchKernelGGL(cst_gemm_bf16_reduce, dim3(rb), dim3(256), 0, st, g);
+        static const bool no_batch = getenv("CST_REDUCE_SERIAL") != nullptr;      // A/B switch for tools/splitk_bench_bf16.py
+        if (g.splits >= 5 && !no_batch) hipLaunchKernelGGL(cst_gemm_bf16_reduce<true>, dim3(rb), dim3(256), 0, st, g);
+        else hipLaunchKernelGGL(cst_gemm_bf16_reduce<false>, dim3(rb), dim3(256), 0, st, g);
         CST_LAUNCH_CHECK("cst_gemm_bf16_reduce");
     }
     return CST_OK;
@@ -629,7 +644,9 @@ extern "C" int cst_gemm_bf16_tt(const void* A, long lda, const void* B, long ldb
     if (splits > 1) {
         long mn = ((long)M * N + 3) / 4;
         int rb = (int)((mn + 255) / 256); if (rb > 2048) rb = 2048;
-        hipLaunchKernelGGL(cst_gemm_bf16_reduce, dim3(rb), dim3(256), 0, st, g);
+        static const bool no_batch = getenv("CST_REDUCE_SERIAL") != nullptr;      // A/B switch for tools/splitk_bench_bf16.py
+        if (g.splits >= 5 && !no_batch) hipLaunchKernelGGL(cst_gemm_bf16_reduce<true>, dim3(rb), dim3(256), 0, st, g);
+        else hipLaunchKernelGGL(cst_gemm_bf16_reduce<false>, dim3(rb), dim3(256), 0, st, g);
         CST_LAUNCH_CHECK("cst_gemm_bf16_reduce");
     }
     return CST_OK;

@@ -13,7 +13,7 @@ for M, N, K, note in SH:
     junk = torch.empty(64 * 1024 * 1024, device="cuda")          # 256 MB stream between GEMMs: evicts L2 like the real step
     res = []
     TILE = int(os.environ.get("TILE", "0"))
-    for sk in (0, 1, 2, 4):
+    for sk in (0, 1, 2, 4, 8):
         row = []
         for evict in (False, True):
             for _ in range(2):
@@ -38,4 +38,4 @@ for M, N, K, note in SH:
                 return a.elapsed_time(b) * 1000 / n
             row.append(t(g) - (t(g2) if evict else 0.0))
         res.append(row)
-    print(f"{note:16s} {M}x{N}x{K}  " + "  ".join(f"sk{s}: {r[0]:5.1f}/{r[1]:5.1f}us" for s, r in zip((0, 1, 2, 4), res)) + "   (hot / after a 32 MB memset)")
+    print(f"{note:16s} {M}x{N}x{K}  " + "  ".join(f"sk{s}: {r[0]:5.1f}/{r[1]:5.1f}us" for s, r in zip((0, 1, 2, 4, 8), res)) + "   (hot / after a 32 MB memset)")
