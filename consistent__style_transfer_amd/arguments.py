@@ -45,6 +45,12 @@ def build_parser():
     parser.add_argument('--seed', type=int, default=0, help="base seed (data order, noise, dropout, coins)")
     parser.add_argument('--max_steps', type=int, default=None, help="stop after this many training batches (smoke runs)")
     parser.add_argument('--val_batches', type=int, default=None, help="limit validation batches")
+    parser.add_argument('--replica_check_every', type=int, default=200,
+                        help="data parallel: verify every N steps that all ranks hold bit-identical parameters (0 = only per epoch)")
+    parser.add_argument('--token_cache', action="store_true",
+                        help="keep / reuse the binary token cache next to each data file (loader.TokenCache)")
+    parser.add_argument('--label_cache', type=str, default=None,
+                        help="pretrain: file of precomputed content-distance labels (loader.LabelCache format)")
     return parser
 
 

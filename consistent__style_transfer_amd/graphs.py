@@ -15,17 +15,22 @@ import torch
 
 from . import ops
 from ._lib import call
+from .optim import CaptureRecord, FlatGroup
 
 
 class GraphedStep:
-    def __init__(self, fn, example_inputs, seed_modules=(), warmup=2, reducer=None):
+    def __init__(self, fn, example_inputs, seed_modules=(), warmup=2, reducer=None, pool=None):
         """fn(*static_inputs) -> dict of tensors.  `example_inputs`: tensors fixing shapes/dtypes.
         `seed_modules`: modules whose dropout seed must advance on every replay.
 
         With a `reducer` (data parallelism) fn is called as fn(*static_inputs, reducer=hook): every
         call of the hook -- the points where the stage all-reduces its flat gradient buffers -- ends the
         graph being captured and starts the next one, and on replay the collective runs eagerly on the
-        stream between the two segment graphs (forward/backward/gather | all-reduce | clip/Adam ...)."""
+        stream between the two segment graphs (forward/backward/gather | all-reduce | clip/Adam ...).
+
+        `pool`: a torch.cuda.graph_pool_handle() shared with other GraphedSteps that are never replayed concurrently
+        and whose outputs are consumed before the next replay (trainer.StepCache: one graph per batch shape) -- their
+        activations then share one arena instead of one private pool per captured shape."""
         dev = example_inputs[0].device
         self.static_in = [t.clone() for t in example_inputs]
         self.seed_dev = torch.zeros(1, dtype=torch.int32, device=dev)
@@ -46,21 +51,32 @@ class GraphedStep:
         torch.cuda.synchronize()
         ops.capture_scope_reset()
         self.graphs, self.points = [], []
+        self.record = CaptureRecord()
+        for grp in list(FlatGroup._live):                 # pointer tables for every gather the capture will record
+            grp.reserve_tables()
+        FlatGroup._record = self.record
         try:
             if reducer is None:
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g):
+                with torch.cuda.graph(g, pool=pool):
                     self.static_out = self._body()
                 self.graphs.append(g)
             else:
-                self._capture_segments(s)
+                self._capture_segments(s, pool)
         finally:
+            FlatGroup._record = None
             ops.capture_scope_reset()
             self._hook = reducer
         torch.cuda.synchronize()
 
-    def _capture_segments(self, side):
-        pool = torch.cuda.graph_pool_handle()
+    def release(self):
+        """Drop the captured graphs and hand their gradient-pointer tables back (trainer.StepCache eviction)."""
+        self.graphs, self.points, self.static_out = [], [], None
+        self.record.release()
+
+    def _capture_segments(self, side, pool=None):
+        if pool is None:
+            pool = torch.cuda.graph_pool_handle()
         cur = [torch.cuda.CUDAGraph()]
 
         def hook(groups, defer=False):
@@ -94,4 +110,9 @@ class GraphedStep:
             if i < len(self.points):
                 groups, defer = self.points[i]
                 self.reducer(groups, defer) if defer else self.reducer(groups)
+        # the replay ran Adam on these groups through the C ABI: nothing torch can see changed, so the caches keyed on
+        # (tensor version, group version) -- ops.weight_bf16's copies used by EAGER code such as validation -- must
+        # be told.  Without this an eager forward after a run of replays reads bf16 weights from before the replays.
+        for grp in self.record.stepped:
+            grp.version += 1
         return self.static_out

@@ -81,6 +81,7 @@ def main(argv=None):
     args = fetch_args(argv)
     apply_model_constants(args)
     ops.set_precision(args.precision)
+    torch.manual_seed(args.seed)                              # identical random-init weights on every rank (then broadcast anyway)
     os.makedirs(f"{args.dump_dir}/{args.dataset}/{STAGE}-{args.ver}", exist_ok=True)
     args.task_dump_dir = f"{args.dump_dir}/{args.dataset}/{STAGE}-{args.ver}"
     os.makedirs(f"{args.out_dir}/{args.dataset}-{args.ver}", exist_ok=True)
@@ -94,6 +95,7 @@ def main(argv=None):
     if args.mode == "train":
         stage.train()
         stage.setup_optim()
+        trainer.sync_replicas(stage)
         stage._steps = StepCache(trainer.use_graph, [stage], trainer.reducer)
         train_ds = StyleDataset([f"{data_dir}/style.train.0", f"{data_dir}/style.train.1"], vocab, args.max_len, load_s2l)
         val_ds = StyleDataset([f"{data_dir}/style.dev.0", f"{data_dir}/style.dev.1"], vocab, args.max_len, load_s2l)

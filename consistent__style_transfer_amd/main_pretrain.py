@@ -62,6 +62,7 @@ def main(argv=None, label_fn=None):
     args = fetch_args(argv)
     apply_model_constants(args)
     ops.set_precision(args.precision)
+    torch.manual_seed(args.seed)                              # identical random-init weights on every rank (then broadcast anyway)
     os.makedirs(f"{args.dump_dir}/{args.dataset}/{STAGE}", exist_ok=True)
     args.task_dump_dir = f"{args.dump_dir}/{args.dataset}/{STAGE}"
     args.log_dir = f"{args.log_dir}/{args.dataset}"
@@ -71,6 +72,7 @@ def main(argv=None, label_fn=None):
     stage = PretrainAdapter(args, vocab).to(trainer.device)
     stage.train()
     stage.setup_optim()
+    trainer.sync_replicas(stage)
     stage._steps = StepCache(trainer.use_graph, [stage], trainer.reducer)
     data_dir = f"{args.data_dir}/{args.dataset}"
     train_ds = StyleDataset([f"{data_dir}/style.train.0", f"{data_dir}/style.train.1"], vocab, args.max_len, load_s2l)

@@ -51,6 +51,7 @@ def main(argv=None):
     args = fetch_args(argv)
     apply_model_constants(args)
     ops.set_precision(args.precision)
+    torch.manual_seed(args.seed)                              # identical random-init weights on every rank (then broadcast anyway)
     args.epochs = 1                                           # main_warmup.py:115-122
     if not any(a.startswith("--batch_size") for a in argv):
         args.batch_size = 512
@@ -63,6 +64,7 @@ def main(argv=None):
     stage = WarmupAdapter(args, vocab).to(trainer.device)
     stage.train()
     stage.setup_optim()
+    trainer.sync_replicas(stage)
     stage._steps = StepCache(trainer.use_graph, [stage], trainer.reducer)
     data_dir = f"{args.data_dir}/{args.dataset}"
     train_ds = StyleDataset([f"{data_dir}/style.train.0", f"{data_dir}/style.train.1"], vocab, args.max_len, load_s2l)

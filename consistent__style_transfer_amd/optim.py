@@ -10,6 +10,8 @@ per-parameter gradients autograd produced (cst_multi_accumulate), sums squares, 
 coefficient and applies Adam.  The flat gradient buffer is also what the data-parallel
 all-reduce operates on (parallel.py).
 """
+import weakref
+
 import torch
 
 from ._lib import call
@@ -17,7 +19,25 @@ from ._lib import call
 MT_CHUNK = 4096
 
 
+class CaptureRecord:
+    """What a hipGraph capture took from / did to the FlatGroups it touched: the gradient-pointer tables it baked in
+    (returned to their group when the graph is dropped) and the groups whose Adam step it contains (their `version`
+    has to move on every replay, see graphs.GraphedStep.__call__)."""
+
+    def __init__(self):
+        self.tables = []            # (group, (pinned host table, device table))
+        self.stepped = []           # groups, in first-step order, without duplicates
+
+    def release(self):
+        for grp, tab in self.tables:
+            grp._free_tables.append(tab)
+        self.tables = []
+
+
 class FlatGroup:
+    _live = weakref.WeakSet()       # every group alive in this process (graphs.GraphedStep tops up their table pools)
+    _record = None                  # the CaptureRecord of the capture in progress, if any
+
     def __init__(self, params, lr, betas=(0.9, 0.999), eps=1e-8):
         self.params = [p for p in params]
         assert self.params, "empty parameter group"
@@ -55,9 +75,28 @@ class FlatGroup:
         self._src_host = torch.zeros(len(sizes), dtype=torch.int64).pin_memory() if dev.type == "cuda" else None
         self.srcs = torch.zeros(len(sizes), dtype=torch.int64, device=dev)
         self._keep = None
-        self._captured_tables = [(torch.zeros(len(sizes), dtype=torch.int64).pin_memory() if dev.type == "cuda" else None,
-                                  torch.zeros(len(sizes), dtype=torch.int64, device=dev)) for _ in range(8)]
-        self._next_table = 0
+        # gradient-pointer tables for hipGraph captures: a captured graph re-reads its pinned table on every replay, so
+        # every capture owns the tables it used.  They are allocated here and in eager calls only (never while a
+        # stream is capturing) and there is no fixed number of them: reserve_tables() tops the free pool up.
+        self._free_tables = []
+        self._eager_gathers = 0                           # gather_grads calls since the last reserve_tables()
+        self.reserve_tables()
+        FlatGroup._live.add(self)
+
+    def _new_table(self):
+        dev = self.flat_p.device
+        n = len(self.sizes)
+        return (torch.zeros(n, dtype=torch.int64).pin_memory() if dev.type == "cuda" else torch.zeros(n, dtype=torch.int64),
+                torch.zeros(n, dtype=torch.int64, device=dev))
+
+    def reserve_tables(self, n=None):
+        """Make sure the next capture finds a free pointer table for every gather_grads call it will record: twice the
+        number of calls the eager pass in front of it made (at least 4).  Must not run while a stream is capturing."""
+        if n is None:
+            n = max(4, 2 * self._eager_gathers)
+        self._eager_gathers = 0
+        while len(self._free_tables) < n:
+            self._free_tables.append(self._new_table())
 
     def gather_grads(self, accumulate):
         """Move p.grad of every parameter into the flat gradient buffer (+= when `accumulate`, the
@@ -67,13 +106,19 @@ class FlatGroup:
             if any(g is None for g in grads):
                 self.flat_g.zero_()
         src_host, srcs = self._src_host, self.srcs
-        if torch.cuda.is_current_stream_capturing():
+        if self.flat_p.is_cuda and torch.cuda.is_current_stream_capturing():
             # a captured graph re-reads the pinned table on every replay: each capture needs its own
             # (two graphs over the same group -- e.g. the optimize stage's D-update / no-update
             # variants -- must not see each other's gradient addresses)
-            assert self._next_table < len(self._captured_tables), "more than 8 graph captures over one FlatGroup"
-            src_host, srcs = self._captured_tables[self._next_table]      # pre-allocated: no host allocation while capturing
-            self._next_table += 1
+            if not self._free_tables:
+                raise RuntimeError("FlatGroup.gather_grads: no free gradient-pointer table while capturing -- the capture "
+                                   "was not preceded by FlatGroup.reserve_tables() (graphs.GraphedStep does that)")
+            tab = self._free_tables.pop()                 # pre-allocated: no host allocation while capturing
+            src_host, srcs = tab
+            if FlatGroup._record is not None:
+                FlatGroup._record.tables.append((self, tab))
+        else:
+            self._eager_gathers += 1
         for i, g in enumerate(grads):
             if g is not None and not g.is_contiguous():
                 grads[i] = g.contiguous()
@@ -94,6 +139,9 @@ class FlatGroup:
 
     def step(self):
         self.version += 1
+        rec = FlatGroup._record
+        if rec is not None and not any(g is self for g in rec.stepped):
+            rec.stepped.append(self)
         call("cst_add_i32", self.step_dev, 1)
         call("cst_adam_step", self.flat_p, self.flat_g, self.m, self.v, self.total, float(self.lr),
              float(self.betas[0]), float(self.betas[1]), float(self.eps), self.step_dev)

@@ -87,6 +87,52 @@ class GradReducer:
         self._pending = []
 
 
+def _on_device():
+    return dist.is_initialized() and dist.get_backend() == "nccl"
+
+
+def broadcast_tensors(tensors, src=0):
+    """Make every rank start from rank `src`'s values (parameters: flat buffers of the trained groups and the frozen
+    critics' tensors).  Needed because each process builds its modules itself; identical seeds make this a no-op,
+    a forgotten seed or a checkpoint loaded on one rank only is repaired instead of silently training N models."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return
+    for t in tensors:
+        if _on_device() or not t.is_cuda:
+            dist.broadcast(t, src)
+        else:                                    # gloo with device tensors (single-GPU rehearsals): through the host
+            h = t.detach().cpu()
+            dist.broadcast(h, src)
+            t.copy_(h)
+
+
+def replica_checksum(tensors):
+    """Order-independent exact checksum of the BIT PATTERNS of fp32 tensors (int64 sum of the int32 views): equal
+    bits <=> equal checksum up to collisions, and no floating-point reduction order enters.  Diagnostic only -- this is
+    not on the compute path."""
+    tot = 0
+    for t in tensors:
+        tot += int(t.detach().reshape(-1).view(torch.int32).sum(dtype=torch.int64).item())
+    return tot & 0x7FFFFFFFFFFFFFFF
+
+
+def check_replicas(tensors, what=""):
+    """All ranks must hold bit-identical copies of `tensors` (the data-parallel contract: identical gradients enter
+    identical clips and Adam steps).  all-reduce MIN and MAX of the checksum; raise on every rank if they differ."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return True
+    c = replica_checksum(tensors)
+    dev = tensors[0].device if _on_device() else "cpu"
+    lo = torch.tensor([c], dtype=torch.int64, device=dev)
+    hi = lo.clone()
+    dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+    dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+    if int(lo.item()) != int(hi.item()):
+        raise RuntimeError(f"data-parallel replicas diverged{' (' + what + ')' if what else ''}: parameter checksum differs "
+                           f"across ranks (this rank {c:#x}, min {int(lo.item()):#x}, max {int(hi.item()):#x})")
+    return True
+
+
 def max_over_ranks(value, device):
     if not dist.is_initialized():
         return value

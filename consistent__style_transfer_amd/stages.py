@@ -83,6 +83,12 @@ class PretrainStage(nn.Module):
         self.groups = {k: FlatGroup(m.parameters(), self.lr) for k, m in self.named_models.items()}
         self._scratch = torch.zeros(1, device=dev, dtype=torch.float32)
 
+    def optim_groups(self):
+        return list(self.groups.values())
+
+    def replicated_tensors(self):
+        return [g.flat_p for g in self.groups.values()]
+
     def losses(self, batch, seed=None):
         """(s_loss, c_loss, dn_loss) -- main_pretrain.py:66-77; a frozen model contributes None."""
         x, nx_1, nx_2, nx, label, c_label = batch
@@ -153,6 +159,12 @@ class WarmupStage(nn.Module):
         self.group = FlatGroup(self.generator.parameters(), self.lr)
         self._scratch = torch.zeros(1, device=self.group.flat_p.device, dtype=torch.float32)
 
+    def optim_groups(self):
+        return [self.group]
+
+    def replicated_tensors(self):
+        return [self.group.flat_p]
+
     def loss(self, batch, coins=None, seed=None):
         nx, x, labels = batch
         lg = self.generator(nx, labels, x, labels, coins=coins, seed=seed)      # main_warmup.py:47-48
@@ -191,6 +203,14 @@ class OptimizeStage(nn.Module):
         self.d_group = FlatGroup(self.disc.parameters(), self.lr)
         self._scratch = torch.zeros(1, device=self.g_group.flat_p.device, dtype=torch.float32)
         self._all = list(self.parameters())
+
+    def optim_groups(self):
+        return [self.g_group, self.d_group]
+
+    def replicated_tensors(self):
+        """Everything that must be identical on every data-parallel rank: the trained groups and the frozen critics."""
+        frozen = [p.data for m in (self.classifier, self.matcher, self.nt_checker) for p in m.parameters()]
+        return [self.g_group.flat_p, self.d_group.flat_p] + frozen
 
     def forward(self, x, src_labels, tgt_labels, tau, seed=None):
         return self.generator(x, src_labels, None, tgt_labels, res_type="softmax", tau=tau, seed=seed)
@@ -264,7 +284,12 @@ class OptimizeStage(nn.Module):
         d = self.d_losses(batch, seed)
         d["loss"].backward()
         self.d_group.gather_grads(True)                   # += : accumulates until zero_grad (flat_g is 0 after it)
-        if reducer is not None and batch_idx % 4 == 0:
+        if reducer is not None:
+            # EVERY batch, not only the stepping ones: the accumulating buffer enters both clips of every batch (its
+            # sum of squares scales the generator's gradients above and is rescaled in place here), so it has to be
+            # rank-identical at all times.  Induction: all ranks hold the same accumulated buffer A before this batch's
+            # backward; afterwards rank r holds A + g_r, and AVG over ranks gives A + mean_r(g_r) = A + the global-batch
+            # gradient on every rank (all D losses are batch means over equal shards) -- exactly the one-process buffer.
             reducer([self.d_group])
         clip_groups([self.g_group, self.d_group], self.clip, self._scratch)
         if batch_idx % 4 == 0:                                                # main_optimize.py:85-88

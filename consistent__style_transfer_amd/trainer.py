@@ -27,7 +27,7 @@ import torch
 
 from .graphs import GraphedStep
 from .loader import GlobalBatchSampler, iterate_batches
-from .parallel import GradReducer, init_distributed, shard_batch
+from .parallel import GradReducer, broadcast_tensors, check_replicas, init_distributed, shard_batch
 
 
 class ScalarLogger:
@@ -90,6 +90,13 @@ class Trainer:
         self.sanity_batches = sanity_batches
         self.global_step = 0
         self.current_epoch = 0
+        self.replica_check_every = int(getattr(args, "replica_check_every", 200) or 0)
+
+    def sync_replicas(self, stage):
+        """Called once after stage.setup_optim(): rank 0's parameters everywhere, then verified."""
+        if self.world > 1:
+            broadcast_tensors(stage.replicated_tensors())
+            check_replicas(stage.replicated_tensors(), "after the initial broadcast")
 
     def put(self, batch):
         batch = shard_batch(batch, self.rank, self.world)
@@ -143,9 +150,13 @@ class Trainer:
                     vals["sentences_per_sec"] = n_last / max(now - t_last, 1e-9)
                     t_last, n_last = now, 0
                     self.logger.log(self.global_step, vals)
+                if self.world > 1 and self.replica_check_every and self.global_step % self.replica_check_every == 0:
+                    check_replicas(stage.replicated_tensors(), f"step {self.global_step}")
                 if args.max_steps is not None and self.global_step >= args.max_steps:
                     done = True
                     break
+            if self.world > 1:
+                check_replicas(stage.replicated_tensors(), f"end of epoch {epoch}")
             val_loss = validate(limit=args.val_batches)
             self.logger.log(self.global_step, {"val_loss": val_loss, "epoch": epoch})
             if self.rank == 0:
@@ -157,11 +168,25 @@ class Trainer:
 
 class StepCache:
     """hipGraph replay of a stage's train_step, re-captured whenever the static key changes (batch
-    shapes; the pretrain freeze flags; the optimize stage's D-update variant)."""
+    shapes; the pretrain freeze flags; the optimize stage's D-update variant).
 
-    def __init__(self, enabled, seed_modules, reducer=None):
+    Real batches are padded to the per-batch maximum and `transfer_noise` moves tokens between sentences
+    (loader.py:46-70), so the shape key keeps changing: 200 pretrain batches of the Yelp dev sample give ~30 distinct
+    (x, nx_1, nx_2, nx_3) shapes.  The cache is therefore unbounded in the number of captures over time (pointer
+    tables are allocated on demand, optim.FlatGroup.reserve_tables) but bounded in what it keeps: at most `capacity`
+    graphs, least recently used evicted, all of them captured into ONE shared memory pool (they are never replayed
+    concurrently and their outputs are read before the next replay), so resident memory is the largest graph's
+    activations, not the sum.  Batches are never padded to a fixed length: PAD positions are part of every loss
+    (main_pretrain.py:73)."""
+
+    def __init__(self, enabled, seed_modules, reducer=None, capacity=None):
         """`reducer` (world > 1): fn must accept a `reducer=` keyword; see graphs.GraphedStep."""
-        self.enabled, self.seed_modules, self.graphs, self.reducer = enabled, seed_modules, {}, reducer
+        from collections import OrderedDict
+        self.enabled, self.seed_modules, self.reducer = enabled, seed_modules, reducer
+        self.graphs = OrderedDict()
+        self.capacity = int(os.environ.get("CST_GRAPH_CACHE", "32")) if capacity is None else capacity
+        self.pool = None
+        self.captures = self.evictions = 0
 
     def run(self, key, fn, inputs):
         if not self.enabled:
@@ -169,7 +194,15 @@ class StepCache:
         k = (key,) + tuple((tuple(t.shape), t.dtype) for t in inputs)
         g = self.graphs.get(k)
         if g is None:
+            while len(self.graphs) >= max(1, self.capacity):
+                _, old = self.graphs.popitem(last=False)
+                old.release()
+                self.evictions += 1
+            if self.pool is None:
+                self.pool = torch.cuda.graph_pool_handle()
             # construction runs the step once eagerly on these inputs (a real training step), then captures
-            g = self.graphs[k] = GraphedStep(fn, list(inputs), self.seed_modules, warmup=1, reducer=self.reducer)
+            g = self.graphs[k] = GraphedStep(fn, list(inputs), self.seed_modules, warmup=1, reducer=self.reducer, pool=self.pool)
+            self.captures += 1
             return g.first_out
+        self.graphs.move_to_end(k)
         return g(*inputs)

@@ -37,16 +37,24 @@ class OracleOptimize:
         self.og = torch.optim.Adam(_params(Pg), lr=lr)
         self.od = torch.optim.Adam(_params(Pd), lr=lr)
 
-    def step(self, batch, batch_idx, coins):
+    def step(self, batch, batch_idx, coins, reduce=None):
+        """`reduce(P)`: data-parallel hook, called with a parameter dict whose .grad fields must be averaged over the
+        ranks in place -- at exactly the points where the product stage calls its reducer (stages.OptimizeStage.train_step):
+        the generator's gradients after its backward, and the discriminator's ACCUMULATED gradients after every
+        discriminator backward (they enter both clips of every batch, so they have to be rank-identical at all times)."""
         _req((self.Pg,), self.all)
         r = S.optimize_g_losses(self.Pg, self.Pc, self.Pm, self.Pd, batch, coins, self.hp, self.n_head, self.max_len)
         r["loss"].backward()
+        if reduce is not None:
+            reduce(self.Pg)
         _clip(self.all, 1.0)
         self.og.step()
         self.og.zero_grad()
         _req((self.Pd,), self.all)
         d = S.optimize_d_losses(self.Pg, self.Pd, batch, self.hp, self.max_len)
         d["loss"].backward()
+        if reduce is not None:
+            reduce(self.Pd)
         _clip(self.all, 1.0)
         if batch_idx % 4 == 0:
             self.od.step()

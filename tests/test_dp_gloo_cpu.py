@@ -11,6 +11,21 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 
+def _collect(procs, q, n, timeout=600):
+    """n results from the queue, failing fast when a worker died instead of waiting out the timeout."""
+    import queue as _q
+    import time as _t
+    got, t0 = [], _t.time()
+    while len(got) < n:
+        try:
+            got.append(q.get(timeout=2))
+        except _q.Empty:
+            dead = [p.exitcode for p in procs if p.exitcode not in (None, 0)]
+            assert not dead, f"worker exited with {dead}"
+            assert _t.time() - t0 < timeout, "timed out waiting for the workers"
+    return got
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -63,7 +78,7 @@ def test_dp2_gradient_average_equals_global_batch():
     procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    err, scale = q.get(timeout=120)
+    (err, scale), = _collect(procs, q, 1)
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
@@ -76,3 +91,92 @@ def test_shard_batch_rejects_uneven_split():
         shard_batch((torch.zeros(5, 3),), 0, 2)
     a, = shard_batch((torch.arange(12).reshape(4, 3),), 1, 2)
     assert a.tolist() == [[6, 7, 8], [9, 10, 11]]
+
+
+def _opt_worker(rank, world, port, out, steps):
+    """The optimize stage's data-parallel schedule on the oracle: G gradients averaged after the G backward, the
+    discriminator's accumulated gradients averaged after EVERY D backward (stages.OptimizeStage.train_step)."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    torch.set_num_threads(2)
+    from consistent__style_transfer_amd.parallel import check_replicas, init_distributed, shard_batch
+    from helpers import CONFIGS, det_params
+    from oracle import train as OT
+    from oracle.detinit import det_tokens
+    init_distributed("gloo")
+    c = CONFIGS["tiny"]
+    hp = dict(w_s=0.1, w_c=0.5, w_adv=1.0, w_bt=1.0, tau=0.1, gap=0.0)
+    B = 4
+
+    def build():
+        return OT.OracleOptimize(det_params("tiny", "G"), det_params("tiny", "cls"), det_params("tiny", "mat"), det_params("tiny", "dn"),
+                                 det_params("tiny", "disc"), hp, c["n_head"], c["max_len"], lr=1e-3)
+
+    def reduce(P):
+        for p in P.values():
+            if p.grad is not None:
+                dist.all_reduce(p.grad)
+                p.grad.div_(world)
+
+    dp = build()
+    full = build() if rank == 0 else None
+    for it in range(steps):
+        x = det_tokens(B, c["L"], c["V"], 100 + it)
+        labels = torch.tensor([0, 1, 1, 0])
+        coins = [bool((it + k) % 2) for k in range(c["L"])]
+        dp.step(shard_batch((x, labels), rank, world), it, coins, reduce=reduce)
+        if full is not None:
+            full.step((x, labels), it, coins)
+    # replicas must agree bit for bit (same averaged gradients into the same clip and Adam arithmetic)
+    check_replicas([p.data for p in dp.Pg.values()] + [p.data for p in dp.Pd.values()], "oracle optimize schedule")
+    if rank == 0:
+        err = max(float((a.data - b.data).abs().max()) for P, Q in ((dp.Pg, full.Pg), (dp.Pd, full.Pd)) for a, b in zip(P.values(), Q.values()))
+        out.put(err)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_dp2_optimize_schedule_keeps_replicas_identical_and_matches_global_batch():
+    """6 batches with lr 1e-3 (so the clip-scaled updates are far above rounding): batches 0 and 4 step the discriminator,
+    in between its gradients accumulate and are rescaled by both clips of every batch."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_opt_worker, args=(r, 2, port, q, 6)) for r in range(2)]
+    for p in procs:
+        p.start()
+    err, = _collect(procs, q, 1)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert err <= 1e-5, err
+
+
+def _diverge_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from consistent__style_transfer_amd.parallel import broadcast_tensors, check_replicas, init_distributed
+    init_distributed("gloo")
+    t = torch.arange(10, dtype=torch.float32) + (1e-6 if rank == 1 else 0.0)     # one ulp-scale difference on rank 1
+    try:
+        check_replicas([t], "unit test")
+        out.put((rank, "no error"))
+    except RuntimeError as e:
+        out.put((rank, "raised" if "diverged" in str(e) else str(e)))
+    broadcast_tensors([t])
+    check_replicas([t], "after broadcast")
+    out.put((rank, "ok"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_replica_check_raises_on_every_rank_and_broadcast_repairs():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_diverge_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted(_collect(procs, q, 4))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert got == [(0, "ok"), (0, "raised"), (1, "ok"), (1, "raised")], got
