@@ -10,7 +10,7 @@ import sys
 
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB = os.path.join(CSRC, "libcst_hip.so")
-SOURCES = ["common.hip", "gemm.hip", "gemm_bf16.hip", "rowwise.hip", "attention.hip", "pointwise.hip", "relconv.hip", "lstm_seq.hip"]
+SOURCES = ["common.hip", "gemm.hip", "gemm_bf16.hip", "rowwise.hip", "attention.hip", "attention_long.hip", "pointwise.hip", "relconv.hip", "lstm_seq.hip"]
 ARCH = "gfx950"
 
 

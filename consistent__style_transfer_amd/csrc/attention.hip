@@ -12,7 +12,13 @@
 //      rnn.py:76): one workgroup per batch row, memory (L' <= 64 rows of D) streamed once.
 #include "cst_common.h"
 
-#define MHA_SMAX 64
+#define MHA_SMAX 64                  // single-tile kernels below; 64 < S <= 128 goes to attention_long.hip
+#define MHA_SMAX_LONG 128
+
+int cst_mha_fwd_long(const float* qkv, float* out, float* lse, int B, int S, int H, int hd, float scale, CstDrop dr,
+                     void* outb, long ldob, hipStream_t st);
+int cst_mha_bwd_long(const float* qkv, const float* dout, const float* lse, float* dqkv, int B, int S, int H, int hd, float scale, CstDrop dr,
+                     void* dqb, long lddb, hipStream_t st);
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef __attribute__((address_space(1))) const void* gbl_ptr_t;
@@ -192,10 +198,16 @@ extern "C" int cst_mha_fwd_b(const float* qkv, float* out, float* lse, int B, in
                              void* out_bf16, long ldob, void* stream) {
     CST_REQUIRE(!out_bf16 || ldob >= (long)H * hd, "cst_mha_fwd: bf16 leading dimension < d");
     CST_REQUIRE(qkv && out && lse, "cst_mha_fwd: null pointer");
-    CST_REQUIRE(B > 0 && S > 0 && S <= MHA_SMAX && H > 0, "cst_mha_fwd: S=%d unsupported (max %d)", S, MHA_SMAX);
-    CST_REQUIRE(((uintptr_t)qkv & 15) == 0, "cst_mha_fwd: qkv must be 16-byte aligned");
+    CST_REQUIRE(B > 0 && S > 0 && S <= MHA_SMAX_LONG && H > 0, "cst_mha_fwd: S=%d unsupported (max %d)", S, MHA_SMAX_LONG);
+    CST_REQUIRE(((uintptr_t)qkv & 15) == 0 && hd % 4 == 0, "cst_mha_fwd: qkv must be 16-byte aligned, hd a multiple of 4");
     CstDrop dr = cst_make_drop(drop_p, drop_seed, drop_stream, drop_seed_dev);
     const float scale = 1.0f / sqrtf((float)hd);
+    if (S > MHA_SMAX) {
+        const int rc = cst_mha_fwd_long(qkv, out, lse, B, S, H, hd, scale, dr, out_bf16, ldob, (hipStream_t)stream);
+        if (rc != CST_OK) return rc;
+        CST_LAUNCH_CHECK("cst_mha_fwd (long)");
+        return CST_OK;
+    }
     const size_t lds = sizeof(float) * mha_fwd_lds_floats(S, hd);
     CST_REQUIRE(lds <= 160 * 1024, "cst_mha_fwd: LDS need %zu exceeds 160 KiB", lds);
     dim3 grid(B * H), block(MHA_NW * 64);
@@ -438,10 +450,16 @@ extern "C" int cst_mha_bwd_b(const float* qkv, const float* dout, const float* l
                              void* dqkv_bf16, long lddb, void* stream) {
     CST_REQUIRE(!dqkv_bf16 || lddb >= 3L * H * hd, "cst_mha_bwd: bf16 leading dimension < 3d");
     CST_REQUIRE(qkv && dout && lse && dqkv, "cst_mha_bwd: null pointer");
-    CST_REQUIRE(B > 0 && S > 0 && S <= MHA_SMAX && H > 0, "cst_mha_bwd: S=%d unsupported (max %d)", S, MHA_SMAX);
-    CST_REQUIRE((((uintptr_t)qkv | (uintptr_t)dout) & 15) == 0, "cst_mha_bwd: qkv / dout must be 16-byte aligned");
+    CST_REQUIRE(B > 0 && S > 0 && S <= MHA_SMAX_LONG && H > 0, "cst_mha_bwd: S=%d unsupported (max %d)", S, MHA_SMAX_LONG);
+    CST_REQUIRE((((uintptr_t)qkv | (uintptr_t)dout) & 15) == 0 && hd % 4 == 0, "cst_mha_bwd: qkv / dout must be 16-byte aligned, hd a multiple of 4");
     CstDrop dr = cst_make_drop(drop_p, drop_seed, drop_stream, drop_seed_dev);
     const float scale = 1.0f / sqrtf((float)hd);
+    if (S > MHA_SMAX) {
+        const int rc = cst_mha_bwd_long(qkv, dout, lse, dqkv, B, S, H, hd, scale, dr, dqkv_bf16, lddb, (hipStream_t)stream);
+        if (rc != CST_OK) return rc;
+        CST_LAUNCH_CHECK("cst_mha_bwd (long)");
+        return CST_OK;
+    }
     const size_t lds = sizeof(float) * mha_bwd_lds_floats(S, hd);
     CST_REQUIRE(lds <= 160 * 1024, "cst_mha_bwd: LDS need %zu exceeds 160 KiB", lds);
     dim3 grid(B * H), block(MHA_NW * 64);

@@ -156,8 +156,10 @@ int cst_colsum(const float* X, long ld, int M, int N, float* out, int accumulate
 /* out[0] (+)= scale * sum(in[0..n)), one block, deterministic. */
 int cst_reduce_sum(const float* in, long n, float scale, float* out, int accumulate, void* stream);
 
-/* Unmasked multi-head self-attention core, qkv [B,S,3d] -> out [B,S,d], lse [B,H,S]; S <= 64,
- * head dim in {8,16,32,64,96}; attention dropout on the probabilities (index ((b*H+h)*S+i)*S+j).
+/* Unmasked multi-head self-attention core, qkv [B,S,3d] -> out [B,S,d], lse [B,H,S]; attention dropout on the
+ * probabilities (index ((b*H+h)*S+i)*S+j).  S <= 64: one LDS-resident S x S plane per (batch row, head), head dim in
+ * {8,16,32,64,96}; 64 < S <= 128 (the book corpus: match.py:36-39 concatenates two sequences of max_len 30,
+ * arguments.py:43, lengthened by data_util.transfer_noise): K/V resident, queries in blocks, head dim in {8,64,96}.
  * nn.MultiheadAttention inside nn.TransformerEncoderLayer (mlm.py:20-22,43; match.py:18-20,39). */
 int cst_mha_fwd(const float* qkv, float* out, float* lse, int B, int S, int H, int hd,
                 float drop_p, uint32_t drop_seed, uint32_t drop_stream, const void* drop_seed_dev, void* stream);

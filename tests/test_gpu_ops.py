@@ -317,7 +317,12 @@ def test_colsum_and_reduce(ops):
 # ----------------------------------------------------------------------------------- attention
 @pytest.mark.parametrize("B,S,H,hd,p", [(2, 6, 4, 8, 0.0), (3, 13, 2, 32, 0.1), (2, 36, 8, 64, 0.0), (2, 36, 8, 64, 0.1),
                                         (1, 60, 8, 64, 0.0), (2, 18, 8, 96, 0.1), (1, 64, 2, 64, 0.0),
-                                        (2, 1, 2, 16, 0.0), (2, 17, 4, 16, 0.1), (2, 48, 2, 32, 0.1), (3, 33, 2, 64, 0.1)])
+                                        (2, 1, 2, 16, 0.0), (2, 17, 4, 16, 0.1), (2, 48, 2, 32, 0.1), (3, 33, 2, 64, 0.1),
+                                        # 64 < S <= 128: the query-blocked kernels of attention_long.hip (book corpus: the Matcher
+                                        # attends over cat(x1, x2), 60 positions before transfer_noise, ~80 after)
+                                        (2, 65, 2, 64, 0.0), (2, 80, 8, 64, 0.1), (1, 96, 2, 64, 0.1), (2, 97, 2, 64, 0.0),
+                                        (1, 128, 2, 64, 0.1), (2, 72, 4, 8, 0.1), (1, 128, 4, 8, 0.0), (2, 80, 2, 96, 0.1),
+                                        (1, 128, 2, 96, 0.1)])
 def test_mha(ops, B, S, H, hd, p):
     from consistent__style_transfer_amd._lib import call
     d = H * hd
@@ -338,6 +343,26 @@ def test_mha(ops, B, S, H, hd, p):
     dqkv = torch.empty(B * S, 3 * d, device="cuda")
     call("cst_mha_bwd", dev(qkv), dev(w), lse, dqkv, B, S, H, hd, *drop.args())
     close(dqkv.view(B, S, 3 * d), qkv_r.grad, 1e-3, 1e-4)
+    # the bf16 twins written next to the fp32 results (operands of the out-projection / in-projection products)
+    outb = torch.zeros(B * S, d, device="cuda", dtype=torch.int16)
+    dqb = torch.zeros(B * S, 3 * d, device="cuda", dtype=torch.int16)
+    out2, dq2 = torch.empty_like(out), torch.empty_like(dqkv)
+    call("cst_mha_fwd_b", dev(qkv), out2, lse, B, S, H, hd, *drop.args(), outb, d)
+    call("cst_mha_bwd_b", dev(qkv), dev(w), lse, dq2, B, S, H, hd, *drop.args(), dqb, 3 * d)
+    assert torch.equal(out2, out) and torch.equal(dq2, dqkv)
+    assert torch.equal(outb.view(torch.bfloat16), out.to(torch.bfloat16))
+    assert torch.equal(dqb.view(torch.bfloat16), dqkv.to(torch.bfloat16))
+
+
+def test_mha_rejects_unsupported_lengths(ops):
+    from consistent__style_transfer_amd._lib import call
+    B, S, H, hd = 1, 129, 2, 64
+    qkv = torch.zeros(B * S, 3 * H * hd, device="cuda")
+    with pytest.raises(RuntimeError, match="S=129 unsupported"):
+        call("cst_mha_fwd", qkv, torch.empty(B * S, H * hd, device="cuda"), torch.empty(B * H * S, device="cuda"), B, S, H, hd, *ops.NO_DROP.args())
+    with pytest.raises(RuntimeError, match="head dim 32 unsupported for S > 64"):
+        call("cst_mha_fwd", torch.zeros(100, 3 * 64, device="cuda"), torch.empty(100, 64, device="cuda"), torch.empty(2 * 100, device="cuda"),
+             1, 100, 2, 32, *ops.NO_DROP.args())
 
 
 @pytest.mark.parametrize("B,L,D", [(3, 5, 32), (7, 18, 512), (2, 30, 512), (2, 64, 96)])
