@@ -33,6 +33,8 @@ WORKLOADS = {
     # BASELINE.json configs[0]-shaped small case
     "yelp_2l_d256_b32": dict(n_layer=2, d_model=256, n_head=8, B=32, L=16, V=10000),
 }
+HEADLINE = "yelp_6l_d768_b256"   # the per-GPU shard of BASELINE configs[3] (global batch 2048 at 8 GPUs): what the 1 -> 8 curve runs
+OTHER_WORKLOADS = ("yelp_4l_d512_b256", "book_6l_d512_b512", "yelp_6l_d512_b256")      # configs[1], configs[2], the reference's own sizes
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_PEAK_TFLOPS = 2500.0        # dense bf16 MFMA peak (not the 2:1 sparse figure)
 
@@ -121,14 +123,37 @@ class GraphedPipeline:
         (self.opt_d if it % 4 == 0 else self.opt_nd)(*bo, coins_tensor(2 * it + 1, self.L, self.dev))
 
 
-def cpu_baseline(w, budget_s=25.0):
-    """The oracle's training loops (plain torch fp32) on the host cores, bounded sample of the same
-    workload: one pretrain + warmup + optimize step at a reduced batch."""
+def physical_cores():
+    """Distinct (physical id, core id) pairs of /proc/cpuinfo (SMT siblings counted once), capped by the CPU affinity."""
+    seen, phys, core = set(), None, None
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("physical id"):
+                phys = line.split(":")[1].strip()
+            elif line.startswith("core id"):
+                core = line.split(":")[1].strip()
+            elif not line.strip():
+                if core is not None:
+                    seen.add((phys, core))
+                phys = core = None
+    except OSError:
+        pass
+    n = len(seen) or (os.cpu_count() or 1)
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    return max(1, n)
+
+
+def _cpu_stage_times(w, Bc, nthreads, warm=3, timed=10, budget_s=45.0):
+    """Per-stage step times of the oracle's training loops (plain torch fp32, oracle/train.py) at batch Bc: `warm` untimed +
+    `timed` timed steps per stage (fewer only if one stage alone would exceed budget_s)."""
+    from consistent__style_transfer_amd import model
     from consistent__style_transfer_amd import synthetic as syn
+    from consistent__style_transfer_amd.model import match, mlm
     from oracle import train as OT
-    import json as _json
-    nthreads = torch.get_num_threads()
-    Bc = 8
+    torch.set_num_threads(nthreads)
     L, V, d, nl, nh = w["L"], w["V"], w["d_model"], w["n_layer"], w["n_head"]
     torch.manual_seed(0)
 
@@ -136,42 +161,77 @@ def cpu_baseline(w, budget_s=25.0):
         return {k: (torch.randn(*s) * 0.05) for k, s in shapes.items()}
 
     # parameter shapes from the product modules (CPU construction, no kernels involved)
-    from consistent__style_transfer_amd import model
-    from consistent__style_transfer_amd.model import match, mlm
+    keep = (mlm.d_model, mlm.n_layer, mlm.n_head)
     mlm.d_model = match.d_model = d
     mlm.n_layer = match.n_layer = nl
-    shp = lambda m: {k: tuple(v.shape) for k, v in m.state_dict().items()}
-    Pg, Pc, Pm, Pd, Pdisc = (P(shp(model.DenoiseLSTM(V, 2, L))), P(shp(model.TextCNN(V, 2))), P(shp(model.Matcher(V))),
-                             P(shp(model.MLM(V, 2))), P(shp(model.RelGAN_D(V))))
+    mlm.n_head = match.n_head = nh
+    try:
+        shp = lambda m: {k: tuple(v.shape) for k, v in m.state_dict().items()}
+        Pg, Pc, Pm, Pd, Pdisc = (P(shp(model.DenoiseLSTM(V, 2, L))), P(shp(model.TextCNN(V, 2))), P(shp(model.Matcher(V))),
+                                 P(shp(model.MLM(V, 2))), P(shp(model.RelGAN_D(V))))
+    finally:
+        mlm.d_model = match.d_model = keep[0]
+        mlm.n_layer = match.n_layer = keep[1]
+        mlm.n_head = match.n_head = keep[2]
     for q in (Pm, Pd):
         for k in q:
             if k.endswith("norm1.weight") or k.endswith("norm2.weight"):
                 q[k] = torch.ones_like(q[k])
     hp = dict(w_s=0.1, w_c=0.5, w_adv=1.0, w_bt=1.0, tau=0.1, gap=0.0)
-    tp = OT.OraclePretrain(Pc, Pm, Pd, nh)
-    tw = OT.OracleWarmup({k: v.detach().clone() for k, v in Pg.items()})
     dc = lambda q: {k: v.detach().clone() for k, v in q.items()}
+    tp = OT.OraclePretrain(Pc, Pm, Pd, nh)
+    tw = OT.OracleWarmup(dc(Pg))
     to = OT.OracleOptimize(Pg, dc(Pc), dc(Pm), dc(Pd), Pdisc, hp, nh, L)
     bp, bw, bo = syn.pretrain_batch(Bc, L, V, 1), syn.warmup_batch(Bc, L, V, 1), syn.optimize_batch(Bc, L, V, 1)
     coins = coins_for(0, L)
+    out = {}
+    for name, fn in (("pretrain", lambda it: tp.step(bp)), ("warmup", lambda it: tw.step(bw, coins)),
+                     ("optimize", lambda it: to.step(bo, it, coins))):
+        for it in range(warm):
+            fn(it)
+        t0, n = time.time(), 0
+        while n < timed:
+            fn(warm + n)
+            n += 1
+            if time.time() - t0 > budget_s and n >= 3:
+                break
+        out[name] = {"ms_per_step": 1000.0 * (time.time() - t0) / n, "timed_steps": n, "warmup_steps": warm}
+    return out
 
-    def one(it):
-        tp.step(bp)
-        tw.step(bw, coins)
-        to.step(bo, it, coins)
 
-    one(0)                                               # warm-up
-    t0 = time.time()
-    n = 0
-    while True:
-        one(n + 1)
-        n += 1
-        if time.time() - t0 > budget_s or n >= 20:
-            break
-    dt = (time.time() - t0) / n
-    return {"value": Bc / dt, "unit": "sentences/s", "cores": nthreads, "kind": "port",
-            "sample": f"oracle (plain torch fp32) pretrain+warmup+optimize steps at batch {Bc}, {n} timed steps, "
-                      f"{w['n_layer']}-layer d={w['d_model']} L={L} V={V}"}
+def cpu_baseline(w, workload):
+    """The oracle's training loops (plain torch fp32 restatement of the reference's modules and stage steps, pinned to the
+    reference by tests/golden) timed on this box's host cores: >= 3 warm-up + 10 timed steps PER STAGE at batch 64 on the
+    headline workload, and at BASELINE configs[0] as is (2-layer d=256, B=32, L=16).  Threads = physical cores.  `value` =
+    sentences carried through all three stages per second = B / (sum of the three mean step times)."""
+    cores = physical_cores()
+    Bc = 64
+    head = _cpu_stage_times(w, Bc, cores)
+    tot = sum(v["ms_per_step"] for v in head.values()) * 1e-3
+    w0 = WORKLOADS["yelp_2l_d256_b32"]
+    c0 = _cpu_stage_times(w0, w0["B"], cores)
+    tot0 = sum(v["ms_per_step"] for v in c0.values()) * 1e-3
+    return {"value": Bc / tot, "unit": "sentences/s", "cores": cores, "kind": "port",
+            "sample": f"oracle (plain torch fp32, torch.set_num_threads({cores}) = physical cores) on {workload} at batch {Bc}: "
+                      f"3 warm-up + {min(v['timed_steps'] for v in head.values())} timed steps per stage (pretrain, warmup, optimize G+D)",
+            "per_stage": {k: {**v, "sentences_per_s": Bc / (v["ms_per_step"] * 1e-3)} for k, v in head.items()},
+            "configs0": {"workload": "yelp_2l_d256_b32", "batch": w0["B"], "value": w0["B"] / tot0, "unit": "sentences/s",
+                         "per_stage": {k: {**v, "sentences_per_s": w0["B"] / (v["ms_per_step"] * 1e-3)} for k, v in c0.items()}}}
+
+
+def time_pipeline(w, device, rank, steps, warmup, reducer=None):
+    """Build the three stages of workload `w`, capture their steps, time `steps` replays.  -> (ms_per_step, stages, batches, pipe)"""
+    stages_ = build_stages(w, device)
+    batches = make_batches(w, rank, device)
+    pipe = GraphedPipeline(stages_, batches, reducer)
+    for it in range(warmup):
+        pipe.step(batches, it)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for it in range(steps):
+        pipe.step(batches, warmup + it)
+    torch.cuda.synchronize()
+    return 1000.0 * (time.perf_counter() - t0) / steps, stages_, batches, pipe
 
 
 def main():
@@ -182,7 +242,9 @@ def main():
     ap.add_argument("--no-stage-split", action="store_true", help="skip the per-stage timing leg")
     ap.add_argument("--only-stage", choices=["pretrain", "warmup", "optimize"], default=None,
                     help="profiling aid: with --no-graph run only this stage's step (the JSON line is then NOT the benchmark metric)")
-    ap.add_argument("--workload", default="yelp_4l_d512_b256", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default=HEADLINE, choices=sorted(WORKLOADS))
+    ap.add_argument("--no-other-workloads", action="store_true", help="skip the `workloads` leg (BASELINE configs[1], configs[2], reference sizes)")
+    ap.add_argument("--no-f32", action="store_true", help="skip the exact-fp32-mode throughput figure")
     ap.add_argument("--precision", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -202,6 +264,7 @@ def main():
     ONLY = args.only_stage
     if ONLY:
         args.no_graph, args.no_stage_split, args.no_roofline, args.no_cpu_baseline = True, True, True, True
+        args.no_other_workloads = args.no_f32 = True
     w = WORKLOADS[args.workload]
     stages_ = build_stages(w, device)
     batches = make_batches(w, rank, device)
@@ -223,7 +286,11 @@ def main():
         try:
             pipe = GraphedPipeline(stages_, batches, reducer)
         except Exception as e:                                     # noqa: BLE001
-            print(f"[bench] rank {rank}: segmented graph capture failed ({type(e).__name__}: {e}); eager launches", file=sys.stderr)
+            import traceback
+            print("\n" + "!" * 100 + f"\n[bench] rank {rank}: SEGMENTED hipGraph CAPTURE FAILED ({type(e).__name__}: {e});\n"
+                  "[bench] every rank falls back to EAGER launches -- the number below is NOT the graph-replay number "
+                  "(config.launch says 'eager').\n" + "!" * 100, file=sys.stderr, flush=True)
+            traceback.print_exc()
             failed = 1.0
         use_graph = max_over_ranks(failed, device) == 0.0
     elif use_graph:
@@ -287,8 +354,17 @@ def main():
         torch.cuda.synchronize()
         _lib.gemm_profile(False)
         prof = _lib.gemm_profile_read()
-        pmc_path = os.path.join(REPO, "profiles", "round1_pmc_traffic.json")
-        pmc = json.load(open(pmc_path))["kernels"] if os.path.exists(pmc_path) else {}
+        # HBM traffic per launch cannot be measured inside this process (PMC counters need rocprofv3 around it): it is
+        # read from the committed summary of the same workload (tools/profile_pmc.sh) and the JSON line says so
+        pmc, traffic_source = {}, None
+        for cand in ("round2_pmc_traffic.json", "round1_pmc_traffic.json"):
+            pmc_path = os.path.join(REPO, "profiles", cand)
+            if os.path.exists(pmc_path):
+                blob = json.load(open(pmc_path))
+                if blob.get("workload", "yelp_4l_d512_b256") == args.workload:
+                    pmc = blob["kernels"]
+                    traffic_source = f"profiles/{cand} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload, not measured in this run)"
+                    break
         kernels = {}
         for name, (ms, flops, min_bytes, n) in prof.items():
             if not n or ms <= 0:
@@ -304,7 +380,8 @@ def main():
             dom = max(kernels, key=lambda k: kernels[k]["kernel_ms_per_step"])
             d = kernels[dom]
             roofline = {"bound": "mfma", "kernel": dom, "achieved": d["achieved"], "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                        "frac": d["frac"], "traffic": d["traffic"], "launches_per_step": d["launches_per_step"],
+                        "frac": d["frac"], "traffic": d["traffic"], "traffic_source": traffic_source if d["traffic"] is not None else None,
+                        "launches_per_step": d["launches_per_step"],
                         "avg_launch_us": d["avg_launch_us"], "flops_per_launch": d["flops_per_launch"],
                         "min_operand_bytes_per_launch": d["min_operand_bytes_per_launch"],
                         "kernel_ms_per_step": d["kernel_ms_per_step"],
@@ -324,9 +401,38 @@ def main():
     if world > 1:
         torch.distributed.barrier()
 
+    # exact-fp32 mode (v_mfma_f32_16x16x4_f32 everywhere): the mode that meets the 1e-3 loss-curve bar gets a number too
+    f32_mode = None
+    if rank == 0 and world == 1 and use_graph and args.precision == "bf16" and not args.no_f32:
+        del pipe
+        torch.cuda.empty_cache()
+        ops.set_precision("f32")
+        try:
+            ms32, s32, b32, p32 = time_pipeline(w, device, rank, 3, 1)
+            f32_mode = {"ms_per_step": ms32, "value": w["B"] / (ms32 * 1e-3), "unit": "sentences/s", "steps": 3, "warmup": 1,
+                        "note": "same workload with --precision f32: every product on the exact-fp32 matrix pipe"}
+            del s32, b32, p32
+        finally:
+            ops.set_precision(args.precision)
+        torch.cuda.empty_cache()
+
+    # the other BASELINE configs, same step definition, fewer steps (outside the timed region of the headline)
+    others = None
+    if rank == 0 and world == 1 and use_graph and not args.no_other_workloads:
+        others = {}
+        for name in OTHER_WORKLOADS:
+            if name == args.workload:
+                continue
+            wo = WORKLOADS[name]
+            mso, so, bo_, po = time_pipeline(wo, device, rank, 5, 2)
+            others[name] = {"ms_per_step": mso, "value": wo["B"] / (mso * 1e-3), "unit": "sentences/s", "steps": 5, "warmup": 2,
+                            "per_gpu_batch": wo["B"], "seq_len": wo["L"], "critic_layers": wo["n_layer"], "d_model": wo["d_model"]}
+            del so, bo_, po
+            torch.cuda.empty_cache()
+
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(w)
+        cpu = cpu_baseline(w, args.workload)
 
     if rank == 0:
         line = {
@@ -338,7 +444,7 @@ def main():
                        "seq_len": w["L"], "vocab": w["V"], "critic_layers": w["n_layer"], "d_model": w["d_model"],
                        "parallelism": f"dp{world}", "stages": "pretrain+warmup+optimize(G+D)", "weights": "random-init",
                        "launch": ("hipGraph replay" if world == 1 else "hipGraph segments + eager all-reduce") if use_graph else "eager"},
-            "roofline": roofline, "cpu_baseline": cpu, "per_stage": per_stage,
+            "roofline": roofline, "cpu_baseline": cpu, "per_stage": per_stage, "f32_mode": f32_mode, "workloads": others,
         }
         print(json.dumps(line), flush=True)
     if world > 1:

@@ -496,18 +496,31 @@ extern "C" int cst_small_loss(const float* x, const float* t, float tconst, int 
 // ---------------------------------------------------------------------------------------------
 // optimiser: sum of squares -> clip coefficient -> Adam, all on device (no host sync)
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, long n, float* __restrict__ out) {
+// Deterministic by construction: block b writes its partial to partials[b], then ONE block adds the partials in index
+// order (fixed tree).  A float atomicAdd per block would make the norm -- hence the clip coefficient, hence every
+// parameter -- depend on block arrival order in the last bit, and data-parallel replicas that must stay bit-identical
+// (parallel.check_replicas) would drift apart.
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, long n, float* __restrict__ partials) {
     __shared__ float red[16];
     float s = 0.f;
     EW_LOOP(i, n) s += g[i] * g[i];
     s = block_sum(s, red);
-    if (threadIdx.x == 0) atomicAdd(out, s);
+    if (threadIdx.x == 0) partials[blockIdx.x] = s;
+}
+__global__ __launch_bounds__(256) void sumsq_final_kernel(const float* __restrict__ partials, int nb, float* __restrict__ out) {
+    __shared__ float red[16];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < nb; i += 256) s += partials[i];
+    s = block_sum(s, red);
+    if (threadIdx.x == 0) *out += s;
 }
 
-extern "C" int cst_sumsq_accumulate(const float* g, long n, float* out, void* stream) {
-    CST_REQUIRE(g && out && n > 0, "cst_sumsq_accumulate: bad arguments");
-    long b = (n + EW_THREADS * 8 - 1) / (EW_THREADS * 8); if (b > 1024) b = 1024; if (b < 1) b = 1;
-    hipLaunchKernelGGL(sumsq_kernel, dim3((unsigned)b), dim3(256), 0, (hipStream_t)stream, g, n, out);
+#define CST_SUMSQ_PARTIALS 1024
+extern "C" int cst_sumsq_accumulate(const float* g, long n, float* out, float* partials, void* stream) {
+    CST_REQUIRE(g && out && partials && n > 0, "cst_sumsq_accumulate: bad arguments");
+    long b = (n + EW_THREADS * 8 - 1) / (EW_THREADS * 8); if (b > CST_SUMSQ_PARTIALS) b = CST_SUMSQ_PARTIALS; if (b < 1) b = 1;
+    hipLaunchKernelGGL(sumsq_kernel, dim3((unsigned)b), dim3(256), 0, (hipStream_t)stream, g, n, partials);
+    hipLaunchKernelGGL(sumsq_final_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, partials, (int)b, out);
     CST_LAUNCH_CHECK("cst_sumsq_accumulate");
     return CST_OK;
 }

@@ -58,6 +58,7 @@ class FlatGroup:
         self.m = torch.zeros(tot, device=dev, dtype=torch.float32)
         self.v = torch.zeros(tot, device=dev, dtype=torch.float32)
         self.step_dev = torch.zeros(1, device=dev, dtype=torch.int32)
+        self._ssq_partials = torch.zeros(1024, device=dev, dtype=torch.float32)     # per-block partial sums of squares (cst_sumsq_accumulate)
         self.has_grad = False                             # flat_g holds gradients not yet consumed by a step
         self.version = 0                                  # bumped by every step(): invalidates cached bf16 weight copies
         for p in self.params:
@@ -132,7 +133,7 @@ class FlatGroup:
         self.has_grad = True
 
     def sumsq_into(self, out):
-        call("cst_sumsq_accumulate", self.flat_g, self.total, out)
+        call("cst_sumsq_accumulate", self.flat_g, self.total, out, self._ssq_partials)
 
     def clip(self, sumsq, max_norm):
         call("cst_clip_scale", self.flat_g, self.total, sumsq, float(max_norm))

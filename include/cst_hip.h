@@ -350,8 +350,10 @@ int cst_small_loss(const float* x, const float* t, float tconst, int kind, long 
 
 /* Trainer(gradient_clip_val) + torch.optim.Adam (main_pretrain.py:61-64,139; main_warmup.py:41-43,103;
  * main_optimize.py:73-88,211), all on the device: out += sum(g^2); g *= min(1, max_norm/(sqrt(sumsq)+1e-6));
- * Adam with bias correction from the device step counter. */
-int cst_sumsq_accumulate(const float* g, long n, float* out, void* stream);
+ * Adam with bias correction from the device step counter.  The sum of squares is deterministic (per-block partials in
+ * `partials`, >= 1024 floats of caller scratch, added in index order by one block): data-parallel replicas must compute
+ * bit-identical clip coefficients from bit-identical (all-reduced) gradients. */
+int cst_sumsq_accumulate(const float* g, long n, float* out, float* partials, void* stream);
 int cst_clip_scale(float* g, long n, const float* sumsq_dev, float max_norm, void* stream);
 int cst_adam_step(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2, float eps,
                   const int* step_dev, void* stream);

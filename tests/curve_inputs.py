@@ -2,6 +2,7 @@
 import numpy as np
 import torch
 
+from oracle.configs import noised_len, seg2_len
 from oracle.detinit import det_tokens
 
 
@@ -13,16 +14,16 @@ def opt_batch(c, it):
 
 def warm_batch(c, it):
     x, labels = opt_batch(c, it)
-    return det_tokens(c["B"], c["L"] - 1, c["V"], 300 + it), x, labels
+    return det_tokens(c["B"], noised_len(c), c["V"], 300 + it), x, labels
 
 
 def pre_batch(c, it):
     x, labels = opt_batch(c, it)
     B, L, V = c["B"], c["L"], c["V"]
     c_label = torch.from_numpy(np.random.RandomState(700 + it).uniform(0, 1.5, size=(B,)).astype(np.float32))
-    return (x, det_tokens(B, L, V, 400 + it), det_tokens(B, L - 1, V, 500 + it), det_tokens(B, L, V, 600 + it), labels, c_label)
+    return (x, det_tokens(B, L, V, 400 + it), det_tokens(B, seg2_len(c), V, 500 + it), det_tokens(B, L, V, 600 + it), labels, c_label)
 
 
 HP = dict(w_s=0.1, w_c=0.5, w_adv=1.0, w_bt=1.0, tau=0.1, gap=0.0)
 
-CURVE_LR = {"tiny": 1e-3, "ref": 1e-5}      # as tests/golden/make_golden.py
+CURVE_LR = {"tiny": 1e-3, "ref": 1e-5, "b16": 1e-5, "long": 1e-3}      # as tests/golden/make_golden.py

@@ -35,7 +35,7 @@ import model.discriminator as ref_disc  # noqa: E402
 torch.set_num_threads(4)
 torch.manual_seed(0)
 
-from oracle.configs import CONFIGS  # noqa: E402
+from oracle.configs import CONFIGS, noised_len, seg2_len  # noqa: E402
 
 
 def set_constants(c):
@@ -107,8 +107,8 @@ def module_goldens(name, c):
     G, C, Mt, Dn, D = build(c)
     V, B, L = c["V"], c["B"], c["L"]
     x = det_tokens(B, L, V, 0)
-    x2 = det_tokens(B, L - 1, V, 1)
-    nx = det_tokens(B, L - 1, V, 2)
+    x2 = det_tokens(B, seg2_len(c), V, 1)
+    nx = det_tokens(B, noised_len(c), V, 2)
     labels = torch.tensor([i % 2 for i in range(B)], dtype=torch.long)
     out["x"], out["x2"], out["nx"], out["labels"] = x.numpy(), x2.numpy(), nx.numpy(), labels.numpy()
 
@@ -159,6 +159,17 @@ def module_goldens(name, c):
     y = G(nx, labels, x, labels)
     out["gen.tf.out"] = np32(y)
     grads_of(lossw("gen.tf", y), G, "gen.tf", out)
+    # (a') pure teacher forcing (every coin False: no argmax feedback, so reduced-precision arithmetic cannot change the
+    # trajectory) -- the vector the bf16 path is compared with element-wise.  The reference draws random.random() < 1/2
+    # per step (rnn.py:91); a stub returning 1.0 makes every draw False.
+    _rr = random.random
+    random.random = lambda: 1.0
+    try:
+        y = G(nx, labels, x, labels)
+    finally:
+        random.random = _rr
+    out["gen.tf0.out"] = np32(y)
+    grads_of(lossw("gen.tf0", y), G, "gen.tf0", out)
     # (b) softmax / straight-through mode, free running for max_len steps
     y = G(x, labels, None, 1 - labels, res_type="softmax", tau=0.1)
     out["gen.soft.out"] = np32(y)
@@ -198,7 +209,7 @@ def step_goldens(name, c):
     ce, mse, bce = nn.CrossEntropyLoss(), nn.MSELoss(), nn.BCEWithLogitsLoss()
     x = det_tokens(B, L, V, 20)
     nx1 = det_tokens(B, L, V, 21)
-    nx2 = det_tokens(B, L - 1, V, 22)
+    nx2 = det_tokens(B, seg2_len(c), V, 22)
     nx3 = det_tokens(B, L, V, 23)
     labels = torch.tensor([(i + 1) % 2 for i in range(B)], dtype=torch.long)
     c_label = torch.from_numpy(np.random.RandomState(5).uniform(0, 1.5, size=(B,)).astype(np.float32))
@@ -279,7 +290,7 @@ def step_goldens(name, c):
     return out
 
 
-CURVE_LR = {"tiny": 1e-3, "ref": 1e-5}      # tiny: raised so the optimiser dynamics show; ref: the reference's own lr
+CURVE_LR = {"tiny": 1e-3, "ref": 1e-5, "b16": 1e-5, "long": 1e-3}      # toy widths: raised so the optimiser dynamics show; reference widths: the reference's own lr
 
 
 def curve_goldens(name, c, steps):
@@ -365,7 +376,7 @@ def curve_goldens(name, c, steps):
     rows = []
     for it in range(steps):
         x, labels = batch_of(it)
-        nx = det_tokens(B, L - 1, V, 300 + it)
+        nx = det_tokens(B, noised_len(c), V, 300 + it)
         random.seed(2000 + it)
         lg = G(nx, labels, x, labels)
         loss = ce(lg.reshape(-1, lg.size(-1)), x.reshape(-1))
@@ -386,7 +397,7 @@ def curve_goldens(name, c, steps):
     rows = []
     for it in range(steps):
         x, labels = batch_of(it)
-        nx1, nx2, nx3 = det_tokens(B, L, V, 400 + it), det_tokens(B, L - 1, V, 500 + it), det_tokens(B, L, V, 600 + it)
+        nx1, nx2, nx3 = det_tokens(B, L, V, 400 + it), det_tokens(B, seg2_len(c), V, 500 + it), det_tokens(B, L, V, 600 + it)
         c_label = torch.from_numpy(np.random.RandomState(700 + it).uniform(0, 1.5, size=(B,)).astype(np.float32))
         s_loss = ce(C(x), labels)
         c_loss = mse(Mt(nx1, nx2), c_label)
@@ -442,17 +453,24 @@ def host_goldens():
 
 
 def main():
-    host_goldens()
+    only = [a for a in sys.argv[1:] if a in CONFIGS]          # `make_golden.py b16 long`: just those configurations
+    if "host" in sys.argv[1:]:
+        # host.json + the sample tokenizer: regenerated only on request -- BPE training breaks frequency ties in hash
+        # order, so a re-run yields a different (equally valid) merge table and the committed pair must stay together
+        host_goldens()
     for name, c in CONFIGS.items():
+        if only and name not in only:
+            continue
         mg = module_goldens(name, c)
         # keep fixtures small: big gradient arrays are replaced by their L2 norm and a
         # strided sample (every 97th / 1009th element); small ones are stored whole
-        limit = 4096 if name == "ref" else 16384
+        big = name in ("ref", "b16")
+        limit = 4096 if big else 16384
         slim = {}
         for k, v in mg.items():
             if ".grad." in k and v.size > limit:
                 slim[k.replace(".grad.", ".gradnorm.")] = np.array([np.sqrt((v.astype(np.float64) ** 2).sum())])
-                slim[k.replace(".grad.", ".gradsample.")] = v.reshape(-1)[::(1009 if name == "ref" else 97)].copy()
+                slim[k.replace(".grad.", ".gradsample.")] = v.reshape(-1)[::(1009 if big else 97)].copy()
             else:
                 slim[k] = v
         mg = slim
@@ -465,7 +483,7 @@ def main():
                       f, indent=0, sort_keys=True)
         sg = step_goldens(name, c)
         np.savez_compressed(os.path.join(HERE, f"steps_{name}.npz"), **sg)
-        cg = curve_goldens(name, c, 20 if name == "tiny" else 6)
+        cg = curve_goldens(name, c, {"tiny": 20, "long": 4}.get(name, 6))
         np.savez_compressed(os.path.join(HERE, f"curves_{name}.npz"), **cg)
         print(name, "modules:", len(mg), "arrays;", "steps:", len(sg), "arrays")
 

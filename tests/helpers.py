@@ -66,4 +66,45 @@ def check_grads(G, prefix, named_grads, rtol, atol, input_grad=None):
     return checked
 
 
-__all__ = ["CONFIGS", "load_golden", "sd_shapes", "det_params", "soft_input", "lossw", "check_grads"]
+def rel_l2(a, b):
+    """||a - b|| / ||b|| in float64 (b = the reference)."""
+    a = np.asarray(a.detach().cpu() if hasattr(a, "detach") else a, dtype=np.float64)
+    b = np.asarray(b.detach().cpu() if hasattr(b, "detach") else b, dtype=np.float64)
+    return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30))
+
+
+def grad_rel_l2(G, prefix, named_grads, input_grad=None):
+    """Relative L2 deviation of every gradient from the fixture (whole arrays where stored, else the strided sample
+    scaled by the stored norm).  -> {key: deviation}"""
+    out = {}
+    items = dict(named_grads)
+    if input_grad is not None:
+        items["__input__"] = input_grad
+    for k, g in items.items():
+        g = g.detach().cpu().numpy()
+        full, nrm, smp = f"{prefix}.grad.{k}", f"{prefix}.gradnorm.{k}", f"{prefix}.gradsample.{k}"
+        if full in G:
+            if np.linalg.norm(G[full]) > 1e-6:
+                out[k] = rel_l2(g, G[full])
+        elif nrm in G and G[nrm][0] > 1e-6:
+            stride = next(st for st in (97, 1009) if g.reshape(-1)[::st].size == G[smp].size)
+            # deviation of the sample, measured against the per-element RMS of the whole gradient
+            rms = G[nrm][0] / np.sqrt(g.size)
+            out[k] = float(np.sqrt(np.mean((g.reshape(-1)[::stride].astype(np.float64) - G[smp]) ** 2)) / rms)
+    return out
+
+
+_REPORT = os.path.join(os.path.dirname(GOLDEN.rstrip("/")), "..", "gpurun_out", "parity_report.jsonl")
+
+
+def report(test, **metrics):
+    """Append measured deviations to gpurun_out/parity_report.jsonl (scratch; the numbers quoted in DESIGN.md come from it)."""
+    try:
+        os.makedirs(os.path.dirname(_REPORT), exist_ok=True)
+        with open(_REPORT, "a") as f:
+            f.write(json.dumps({"test": test, **metrics}) + "\n")
+    except OSError:
+        pass
+
+
+__all__ = ["CONFIGS", "load_golden", "sd_shapes", "det_params", "soft_input", "lossw", "check_grads", "rel_l2", "grad_rel_l2", "report"]

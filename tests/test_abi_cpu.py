@@ -30,7 +30,7 @@ def test_argument_errors_are_status_codes_not_exceptions():
                           1, 0, 0, 0, 0, 0, 0, 0.0, 0, 0, None, 0, 0, None, 0, None)
     assert rc == 1
     assert "null operand" in L.last_error()
-    rc = L.fn["cst_mha_fwd"](1, 1, 1, 2, 100, 8, 64, 0.0, 0, 0, None, None)
+    rc = L.fn["cst_mha_fwd"](1, 1, 1, 2, 200, 8, 64, 0.0, 0, 0, None, None)
     assert rc == 1 and "unsupported" in L.last_error()
     assert L.fn["cst_layernorm_bwd_workspace_floats"](4608, 512) == 2 * 1024 * 512
 

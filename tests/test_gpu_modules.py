@@ -2,16 +2,26 @@
 imported reference modules and (b) the CPU oracle on the same seeded inputs.
 
 Tolerances: 'f32' mode (exact-fp32 MFMA) must match the fp32 reference to rtol 2e-3 on outputs and
-5e-3 on gradients (different summation orders through 6 layers / 18 recurrent steps);
-'bf16' mode (bf16 operands, fp32 accumulate) to 5e-2 of the tensor's scale.  Greedy-decode token
-ids must be bit-exact in f32 mode."""
+5e-3 on gradients (different summation orders through 6 layers / 18 recurrent steps); greedy-decode
+token ids must be bit-exact in f32 mode.
+
+'bf16' mode (bf16 operands, fp32 accumulate) -- the mode the benchmark runs in -- is held to the SAME
+reference vectors through relative L2 deviations, ||got - ref|| / ||ref||: BF16_OUT for outputs,
+BF16_GRAD for every parameter / input gradient (for gradients stored as norm + strided sample: RMS
+deviation of the sample over the RMS of the whole gradient).  Decodes that feed their own argmax back
+(soft / greedy / scheduled-sampling coins) can legitimately flip a near-tie under bf16 rounding and then
+follow a different trajectory for that sentence: for those, at least BF16_ROWS of the sentences must
+reproduce the reference's token ids at EVERY step, and the outputs of exactly those sentences are held to
+BF16_OUT; the pure teacher-forced vector (gen.tf0, no feedback) is compared whole, gradients included.
+The measured deviations are appended to gpurun_out/parity_report.jsonl and quoted in DESIGN.md."""
 import numpy as np
 import pytest
 import torch
 
 pytestmark = pytest.mark.gpu
 
-from helpers import CONFIGS, check_grads, det_params, load_golden, lossw, sd_shapes, soft_input  # noqa: E402
+from helpers import CONFIGS, check_grads, det_params, grad_rel_l2, load_golden, lossw, rel_l2, report, sd_shapes, soft_input  # noqa: E402
+from oracle.configs import noised_len, seg2_len  # noqa: E402
 from oracle.detinit import det_state_dict  # noqa: E402
 from helpers import SEEDS  # noqa: E402
 
@@ -47,37 +57,70 @@ def build(model, name, which):
     return m
 
 
+NAMES = ["tiny", "ref", "b16", "long"]
+BF16_OUT = 2e-2           # relative L2 of an output tensor
+BF16_GRAD = 6e-2          # relative L2 of a gradient (6 encoder layers / 8-40 recurrent steps of bf16 products compound)
+BF16_ROWS = 0.75          # fraction of sentences whose fed-back token ids all agree with the reference
+
+
 def tols(prec):
     return (2e-3, 2e-4, 5e-3, 2e-3) if prec == "f32" else (5e-2, 5e-2, None, None)
 
 
-def cmp_out(y, ref, prec, scale_atol=True):
-    rt, at, _, _ = tols(prec)
+def cmp_out(y, ref, prec, scale_atol=True, tag=""):
     ref = np.asarray(ref)
+    if prec == "bf16":
+        dev = rel_l2(y, ref)
+        report("modules.out", tag=tag, dev=dev)
+        assert dev <= BF16_OUT, (tag, dev)
+        return
+    rt, at, _, _ = tols(prec)
     at = at * max(1.0, float(np.abs(ref).max())) if scale_atol else at
     np.testing.assert_allclose(y.detach().cpu().numpy(), ref, rtol=rt, atol=at)
+
+
+def cmp_rows(y, ref, tag, min_rows=BF16_ROWS):
+    """bf16 mode, decodes with argmax feedback: sentences whose ids agree with the reference at every step."""
+    y = y.detach().float().cpu().numpy()
+    ref = np.asarray(ref)
+    ok = (y.argmax(-1) == ref.argmax(-1)).all(1)
+    frac = float(ok.mean())
+    dev = rel_l2(y[ok], ref[ok]) if ok.any() else float("nan")
+    report("modules.rows", tag=tag, rows_agree=frac, dev=dev)
+    assert frac >= min_rows, (tag, frac)
+    assert dev <= BF16_OUT, (tag, dev)
+    return bool(ok.all())
 
 
 def named_grads(m):
     return {k: p.grad for k, p in m.named_parameters() if p.grad is not None}
 
 
-def run_grads(G, prefix, m, loss, prec, inp=None):
+def run_grads(G, prefix, m, loss, prec, inp=None, same_trajectory=True):
     m.zero_grad()
     loss.backward()
     if prec == "f32":
         check_grads(G, prefix, named_grads(m), 5e-3, 2e-3, None if inp is None else inp.grad)
+        return
+    devs = grad_rel_l2(G, prefix, named_grads(m), None if inp is None else inp.grad)
+    assert devs, f"no gradient of {prefix} was checked"
+    worst = max(devs, key=devs.get)
+    report("modules.grad", tag=prefix, worst=worst, dev=devs[worst], median=float(np.median(list(devs.values()))),
+           same_trajectory=same_trajectory)
+    if same_trajectory:
+        assert devs[worst] <= BF16_GRAD, (prefix, worst, devs[worst])
     else:
-        # bf16 operands: compare gradient norms (3 %) rather than element-wise
+        # some sentence followed a different token trajectory than the reference: element-wise comparison is void, the
+        # gradient norms still have to agree
         for k, g in named_grads(m).items():
             full, nrm = f"{prefix}.grad.{k}", f"{prefix}.gradnorm.{k}"
             ref = np.linalg.norm(G[full].astype(np.float64)) if full in G else (G[nrm][0] if nrm in G else None)
             if ref is not None and ref > 1e-3:
-                np.testing.assert_allclose(float(g.double().norm()), ref, rtol=5e-2, err_msg=k)
+                np.testing.assert_allclose(float(g.double().norm()), ref, rtol=1e-1, err_msg=k)
 
 
 @pytest.mark.parametrize("prec", ["f32", "bf16"])
-@pytest.mark.parametrize("name", ["tiny", "ref"])
+@pytest.mark.parametrize("name", NAMES)
 def test_textcnn(cst, name, prec):
     pkg, model, ops = cst
     ops.set_precision(prec)
@@ -85,34 +128,34 @@ def test_textcnn(cst, name, prec):
     m = build(model, name, "cls")
     x = torch.from_numpy(G["x"]).cuda()
     y = m(x)
-    cmp_out(y, G["cls.ids.out"], prec)
+    cmp_out(y, G["cls.ids.out"], prec, tag=f"{name}.cls.ids.out")
     run_grads(G, "cls.ids", m, lossw("cls.ids", y), prec)
     sp = soft_input(c["B"], c["L"], c["V"], 11, "cuda")
     y = m(sp)
-    cmp_out(y, G["cls.soft.out"], prec)
+    cmp_out(y, G["cls.soft.out"], prec, tag=f"{name}.cls.soft.out")
     run_grads(G, "cls.soft", m, lossw("cls.soft", y), prec, sp)
     ops.set_precision("bf16")
 
 
 @pytest.mark.parametrize("prec", ["f32", "bf16"])
-@pytest.mark.parametrize("name", ["tiny", "ref"])
+@pytest.mark.parametrize("name", NAMES)
 def test_mlm(cst, name, prec):
     pkg, model, ops = cst
     ops.set_precision(prec)
     c, G = CONFIGS[name], load_golden("modules", name)
     m = build(model, name, "dn")
     y = m(torch.from_numpy(G["x"]).cuda())
-    cmp_out(y, G["mlm.ids.out"], prec)
+    cmp_out(y, G["mlm.ids.out"], prec, tag=f"{name}.mlm.ids.out")
     run_grads(G, "mlm.ids", m, lossw("mlm.ids", y), prec)
     sp = soft_input(c["B"], c["L"], c["V"], 12, "cuda")
     y = m(sp)
-    cmp_out(y, G["mlm.soft.out"], prec)
+    cmp_out(y, G["mlm.soft.out"], prec, tag=f"{name}.mlm.soft.out")
     run_grads(G, "mlm.soft", m, lossw("mlm.soft", y), prec, sp)
     ops.set_precision("bf16")
 
 
 @pytest.mark.parametrize("prec", ["f32", "bf16"])
-@pytest.mark.parametrize("name", ["tiny", "ref"])
+@pytest.mark.parametrize("name", NAMES)
 def test_matcher(cst, name, prec):
     pkg, model, ops = cst
     ops.set_precision(prec)
@@ -120,17 +163,17 @@ def test_matcher(cst, name, prec):
     m = build(model, name, "mat")
     x, x2 = torch.from_numpy(G["x"]).cuda(), torch.from_numpy(G["x2"]).cuda()
     y = m(x, x2)
-    cmp_out(y, G["mat.ids.out"], prec)
+    cmp_out(y, G["mat.ids.out"], prec, tag=f"{name}.mat.ids.out")
     run_grads(G, "mat.ids", m, lossw("mat.ids", y), prec)
     sp = soft_input(c["B"], c["L"], c["V"], 13, "cuda")
     y = m(sp, x)
-    cmp_out(y, G["mat.soft.out"], prec)
+    cmp_out(y, G["mat.soft.out"], prec, tag=f"{name}.mat.soft.out")
     run_grads(G, "mat.soft", m, lossw("mat.soft", y), prec, sp)
     ops.set_precision("bf16")
 
 
 @pytest.mark.parametrize("prec", ["f32", "bf16"])
-@pytest.mark.parametrize("name", ["tiny", "ref"])
+@pytest.mark.parametrize("name", NAMES)
 def test_relgan_d(cst, name, prec):
     pkg, model, ops = cst
     ops.set_precision(prec)
@@ -138,53 +181,71 @@ def test_relgan_d(cst, name, prec):
     m = build(model, name, "disc")
     sp = soft_input(c["B"], c["L"], c["V"], 14, "cuda")
     y = m(sp)
-    cmp_out(y, G["disc.soft.out"], prec)
+    cmp_out(y, G["disc.soft.out"], prec, tag=f"{name}.disc.soft.out")
     run_grads(G, "disc.soft", m, lossw("disc.soft", y), prec, sp)
     x = torch.from_numpy(G["x"]).cuda()
     y = m(x)                                                    # ids fast path == dense one-hot
-    cmp_out(y, G["disc.onehot.out"], prec)
+    cmp_out(y, G["disc.onehot.out"], prec, tag=f"{name}.disc.onehot.out")
     run_grads(G, "disc.onehot", m, lossw("disc.onehot", y), prec)
     y = m(torch.nn.functional.one_hot(x, c["V"]).float())       # the reference's own calling convention
-    cmp_out(y, G["disc.onehot.out"], prec)
+    cmp_out(y, G["disc.onehot.out"], prec, tag=f"{name}.disc.onehot.out")
     ops.set_precision("bf16")
 
 
 @pytest.mark.parametrize("prec", ["f32", "bf16"])
-@pytest.mark.parametrize("name", ["tiny", "ref"])
+@pytest.mark.parametrize("name", NAMES)
 def test_generator(cst, name, prec):
+    """b16 in bf16 mode is the case that runs the whole-sequence encoder kernels (cst_lstm_seq_fwd/bwd), the 16-row
+    MFMA recurrent products, the fused cell + attention decoder step and the transposed-read weight gradients against
+    vectors recorded from the reference (rnn.py:55-98)."""
     pkg, model, ops = cst
     ops.set_precision(prec)
     c, G = CONFIGS[name], load_golden("modules", name)
     m = build(model, name, "G")
     x, nx, labels = (torch.from_numpy(G[k]).cuda() for k in ("x", "nx", "labels"))
-    # (a) teacher forcing with the recorded coins
+    bf = prec == "bf16"
+    # (a') pure teacher forcing: no feedback, compared whole in both modes (outputs and every gradient)
+    y = m(nx, labels, x, labels, coins=[0] * x.shape[1])
+    cmp_out(y, G["gen.tf0.out"], prec, tag=f"{name}.gen.tf0.out")
+    run_grads(G, "gen.tf0", m, lossw("gen.tf0", y), prec)
+    # (a) teacher forcing with the recorded coins (argmax fed back where the coin says so)
     y = m(nx, labels, x, labels, coins=G["gen.tf.coins"])
-    if prec == "f32":
+    if bf:
+        same = cmp_rows(y, G["gen.tf.out"], f"{name}.gen.tf")
+        run_grads(G, "gen.tf", m, lossw("gen.tf", y), prec, same_trajectory=same)
+    else:
         cmp_out(y, G["gen.tf.out"], prec)
         run_grads(G, "gen.tf", m, lossw("gen.tf", y), prec)
     # (b) softmax / straight-through, free running
     for tag, tau in (("gen.soft", 0.1), ("gen.soft1", 1.0)):
         y = m(x, labels, None, 1 - labels, res_type="softmax", tau=tau)
-        if prec == "f32":
+        np.testing.assert_allclose(y.detach().sum(-1).cpu().numpy(), 1.0, rtol=1e-4)
+        assert torch.equal(y.detach().argmax(-1), m.last_ids.t())          # the ids fed back are the argmax of what is returned
+        if bf:
+            same = cmp_rows(y, G[tag + ".out"], f"{name}.{tag}")
+            run_grads(G, tag, m, lossw(tag, y), prec, same_trajectory=same)
+        else:
             np.testing.assert_allclose(y.detach().cpu().numpy(), G[tag + ".out"], rtol=5e-3, atol=2e-5)
             run_grads(G, tag, m, lossw(tag, y), prec)
-        else:
-            assert y.shape == G[tag + ".out"].shape and torch.isfinite(y).all()
-            np.testing.assert_allclose(y.detach().sum(-1).cpu().numpy(), 1.0, rtol=1e-4)
     # (c) greedy decode: exact ids in f32 mode
     with torch.no_grad():
         y = m(x, labels, None, 1 - labels)
-    if prec == "f32":
+    if not bf:
         assert np.array_equal(y.argmax(-1).cpu().numpy(), G["gen.greedy.ids"])
         assert np.array_equal(m.last_ids.t().cpu().numpy(), G["gen.greedy.ids"])
         cmp_out(y, G["gen.greedy.out"], prec)
     else:
-        agree = (y.argmax(-1).cpu().numpy() == G["gen.greedy.ids"]).mean()
-        assert agree > 0.5, agree          # bf16 logits may flip near-ties; ids are pinned in f32 mode
+        cmp_rows(y, G["gen.greedy.out"], f"{name}.gen.greedy")
+        agree = float((y.argmax(-1).cpu().numpy() == G["gen.greedy.ids"]).mean())
+        report("modules.greedy", tag=name, token_agreement=agree)
+        assert agree >= 0.9, agree         # ids are pinned bit-exactly in f32 mode; bf16 logits may flip near-ties
     # (d) 3-D (soft) encoder input
     sp = soft_input(c["B"], c["L"], c["V"], 15, "cuda")
     y = m(sp, labels, x, labels, coins=G["gen.soft_in.coins"])
-    if prec == "f32":
+    if bf:
+        same = cmp_rows(y, G["gen.soft_in.out"], f"{name}.gen.soft_in")
+        run_grads(G, "gen.soft_in", m, lossw("gen.soft_in", y), prec, sp, same_trajectory=same)
+    else:
         cmp_out(y, G["gen.soft_in.out"], prec)
         run_grads(G, "gen.soft_in", m, lossw("gen.soft_in", y), prec, sp)
     ops.set_precision("bf16")

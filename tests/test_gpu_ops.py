@@ -548,13 +548,28 @@ def test_clip_and_adam(ops):
         torch.nn.utils.clip_grad_norm_([pr], 5.0)
         opt.step()
         g = dev(g0 * (it + 1))
-        ss = torch.zeros(1, device="cuda")
-        call("cst_sumsq_accumulate", g, n, ss)
+        ss, part = torch.zeros(1, device="cuda"), torch.zeros(1024, device="cuda")
+        call("cst_sumsq_accumulate", g, n, ss, part)
         call("cst_clip_scale", g, n, ss, 5.0)
         close(g, pr.grad, 1e-5, 1e-6)
         call("cst_add_i32", step, 1)
         call("cst_adam_step", p, g, m, v, n, 1e-3, 0.9, 0.999, 1e-8, step)
         close(p, pr, 1e-5, 1e-6)
+
+
+def test_sumsq_is_bitwise_reproducible(ops):
+    """The gradient norm feeds the clip coefficient of every parameter: it must not depend on block arrival order
+    (data-parallel replicas compare their parameters bit for bit, parallel.check_replicas)."""
+    from consistent__style_transfer_amd._lib import call
+    g = torch.randn(9_294_464, device="cuda")                    # the generator's parameter count
+    part = torch.zeros(1024, device="cuda")
+    vals = set()
+    for _ in range(20):
+        ss = torch.zeros(1, device="cuda")
+        call("cst_sumsq_accumulate", g, g.numel(), ss, part)
+        vals.add(ss.item())
+    assert len(vals) == 1, vals
+    np.testing.assert_allclose(vals.pop(), float((g.double() ** 2).sum()), rtol=1e-5)
 
 
 # ------------------------------------------------------------- fused recurrent-step entry points

@@ -2,8 +2,10 @@
 single-step losses and multi-step loss curves recorded from the reference modules.
 
 Tolerance: north_star asks for the main_optimize loss curve within 1e-3 of the reference; in the
-exact-fp32 MFMA mode every logged scalar of all 20 steps is held to atol 1e-3 (rtol 2e-3); in the
-bf16 MFMA mode to atol 3e-2."""
+exact-fp32 MFMA mode every logged scalar of all 20 steps is held to atol 1e-3 (rtol 2e-3).  In the
+bf16 MFMA mode (the benchmarked one) single-step losses are held to BF16_LOSS (relative) and gradient
+norms to BF16_GNORM against the same reference numbers, the 20-step curve to atol / rtol BF16_CURVE;
+the measured deviations go to gpurun_out/parity_report.jsonl and are quoted in DESIGN.md."""
 import numpy as np
 import pytest
 import torch
@@ -11,7 +13,11 @@ import torch
 pytestmark = pytest.mark.gpu
 
 from curve_inputs import CURVE_LR, HP, opt_batch, pre_batch, warm_batch  # noqa: E402
-from helpers import CONFIGS, SEEDS, load_golden  # noqa: E402
+from helpers import CONFIGS, SEEDS, load_golden, report  # noqa: E402
+
+BF16_LOSS = 1e-2          # relative deviation of a single-step loss
+BF16_GNORM = 5e-2         # relative deviation of a post-backward gradient norm
+BF16_CURVE = 1e-2         # atol and rtol of every scalar of the multi-step curves
 from oracle.detinit import det_state_dict  # noqa: E402
 from test_gpu_modules import set_constants  # noqa: E402
 
@@ -37,10 +43,20 @@ def make_opt(name, lr=1e-3):
     return st
 
 
-@pytest.mark.parametrize("name", ["tiny", "ref"])
-def test_single_step_losses(name):
+def _close(got, ref, prec, f32_rtol, bf_rtol, tag, atol=0.0):
+    got, ref = np.asarray(got, dtype=np.float64), np.asarray(ref, dtype=np.float64)
+    dev = float(np.max(np.abs(got - ref) / np.maximum(np.abs(ref), 1e-6)))
+    if prec == "bf16":
+        report("stages.step", tag=tag, rel_dev=dev)
+    np.testing.assert_allclose(got, ref, rtol=f32_rtol if prec == "f32" else bf_rtol, atol=atol if prec == "f32" else max(atol, 1e-3), err_msg=tag)
+
+
+@pytest.mark.parametrize("prec", ["f32", "bf16"])
+@pytest.mark.parametrize("name", ["tiny", "ref", "b16", "long"])
+def test_single_step_losses(name, prec):
     from consistent__style_transfer_amd import model, ops, stages
-    ops.set_precision("f32")
+    ops.set_precision(prec)
+    bf = prec == "bf16"
     c, G = CONFIGS[name], load_golden("steps", name)
     x, nx1, nx2, nx3 = (torch.from_numpy(G[k]).cuda() for k in ("x", "nx1", "nx2", "nx3"))
     labels, c_label = torch.from_numpy(G["labels"]).cuda(), torch.from_numpy(G["c_label"]).cuda()
@@ -51,25 +67,32 @@ def test_single_step_losses(name):
         _load(getattr(pre, attr), which)
     pre = pre.cuda().eval()
     s, cl, dn = pre.losses((x, nx1, nx2, nx3, labels, c_label))
-    np.testing.assert_allclose([s.item(), cl.item(), dn.item()], G["pretrain.losses"], rtol=1e-3)
+    _close([s.item(), cl.item(), dn.item()], G["pretrain.losses"], prec, 1e-3, BF16_LOSS, f"{name}.pretrain.losses")
     (s + cl + dn).backward()
     gn = [float(torch.sqrt(sum((p.grad.double() ** 2).sum() for p in m.parameters()))) for m in (pre.classifier, pre.matcher, pre.denoiser)]
-    np.testing.assert_allclose(gn, G["pretrain.gnorm"], rtol=5e-3)
+    _close(gn, G["pretrain.gnorm"], prec, 5e-3, BF16_GNORM, f"{name}.pretrain.gnorm")
     # warmup
     wu = stages.WarmupStage(c["V"], 2, c["max_len"])
     _load(wu.generator, "G")
     wu = wu.cuda().eval()
     w = wu.loss((nx2, x, labels), coins=G["warmup.coins"])
-    np.testing.assert_allclose(w.item(), G["warmup.loss"][0], rtol=1e-3)
+    _close(w.item(), G["warmup.loss"][0], prec, 1e-3, BF16_LOSS, f"{name}.warmup.loss")
     w.backward()
     gn = float(torch.sqrt(sum((p.grad.double() ** 2).sum() for p in wu.generator.parameters())))
-    np.testing.assert_allclose(gn, G["warmup.gnorm"][0], rtol=5e-3)
+    _close(gn, G["warmup.gnorm"][0], prec, 5e-3, BF16_GNORM, f"{name}.warmup.gnorm")
     # optimize: generator and discriminator steps, validation, greedy ids
     st = make_opt(name, lr=1e-5)
     r = st.g_losses((x, labels), coins=G["optimize.coins"])
     got = [r["loss"].item(), r["G"].item(), r["STI"].item(), r["CP_logits"].mean().item(), r["BK"].item()]
-    np.testing.assert_allclose(got, G["optimize.g.losses"], rtol=2e-3, atol=1e-4)
-    assert np.array_equal(r["sample_ids"].cpu().numpy(), G["optimize.g.sample_ids"])
+    ids_ok = np.array_equal(r["sample_ids"].cpu().numpy(), G["optimize.g.sample_ids"])
+    if bf:
+        agree = float((r["sample_ids"].cpu().numpy() == G["optimize.g.sample_ids"]).mean())
+        report("stages.sample_ids", tag=name, token_agreement=agree)
+        assert agree >= 0.9, agree
+    else:
+        assert ids_ok
+    if ids_ok:                                            # a flipped sample token changes every downstream loss
+        _close(got, G["optimize.g.losses"], prec, 2e-3, BF16_LOSS, f"{name}.optimize.g.losses", atol=1e-4)
     for p in st.parameters():
         p.requires_grad_(False)
     for p in st.generator.parameters():
@@ -77,24 +100,29 @@ def test_single_step_losses(name):
     r = st.g_losses((x, labels), coins=G["optimize.coins"])
     r["loss"].backward()
     gn = float(torch.sqrt(sum((p.grad.double() ** 2).sum() for p in st.generator.parameters())))
-    np.testing.assert_allclose(gn, G["optimize.g.gnorm"][0], rtol=1e-2)
-    np.testing.assert_allclose(st.generator.fn_1.bias.grad.cpu().numpy(), G["optimize.g.grad.fn_1.bias"], rtol=2e-2, atol=1e-4)
+    if ids_ok:
+        _close(gn, G["optimize.g.gnorm"][0], prec, 1e-2, BF16_GNORM, f"{name}.optimize.g.gnorm")
+    if not bf:
+        np.testing.assert_allclose(st.generator.fn_1.bias.grad.cpu().numpy(), G["optimize.g.grad.fn_1.bias"], rtol=2e-2, atol=1e-4)
     for p in st.parameters():
         p.requires_grad_(False)
         p.grad = None
     for p in st.disc.parameters():
         p.requires_grad_(True)
     d = st.d_losses((x, labels))
-    np.testing.assert_allclose(d["D"].item(), G["optimize.d.losses"][0], rtol=1e-3)
+    if ids_ok:
+        _close(d["D"].item(), G["optimize.d.losses"][0], prec, 1e-3, BF16_LOSS, f"{name}.optimize.d.losses")
     d["loss"].backward()
     gn = float(torch.sqrt(sum((p.grad.double() ** 2).sum() for p in st.disc.parameters())))
-    np.testing.assert_allclose(gn, G["optimize.d.gnorm"][0], rtol=5e-3)
+    if ids_ok:
+        _close(gn, G["optimize.d.gnorm"][0], prec, 5e-3, BF16_GNORM, f"{name}.optimize.d.gnorm")
     v = st.val_loss((x, labels))
-    np.testing.assert_allclose(v.item(), G["optimize.val"][0], rtol=2e-3)
+    if ids_ok:
+        _close(v.item(), G["optimize.val"][0], prec, 2e-3, BF16_LOSS, f"{name}.optimize.val")
     ops.set_precision("bf16")
 
 
-@pytest.mark.parametrize("prec,atol", [("f32", 1e-3), ("bf16", 3e-2)])
+@pytest.mark.parametrize("prec,atol", [("f32", 1e-3), ("bf16", BF16_CURVE)])
 def test_optimize_loss_curve(prec, atol):
     from consistent__style_transfer_amd import ops
     ops.set_precision(prec)
@@ -106,7 +134,8 @@ def test_optimize_loss_curve(prec, atol):
         lg = st.train_step(cu(opt_batch(c, it)), it, coins=G["optimize.coins"][it])
         rows.append([lg["g_total"].item(), lg["G"].item(), lg["STI"].item(), lg["CP_logits"].mean().item(),
                      lg["BK"].item(), lg["D"].item()])
-    np.testing.assert_allclose(np.array(rows), G["optimize.curve"], rtol=2e-3 if prec == "f32" else 3e-2, atol=atol)
+    report("stages.curve", tag=f"{name}.optimize.{prec}", max_abs_dev=float(np.abs(np.array(rows) - G["optimize.curve"]).max()))
+    np.testing.assert_allclose(np.array(rows), G["optimize.curve"], rtol=2e-3 if prec == "f32" else BF16_CURVE, atol=atol)
     if prec == "f32":
         np.testing.assert_allclose(st.generator.fn_1.bias.detach().cpu().numpy(), G["optimize.final.fn_1.bias"], rtol=2e-3, atol=1e-4)
         np.testing.assert_allclose(st.disc.out2logits.weight.detach().cpu().numpy(), G["optimize.final.out2logits.weight"],
@@ -114,10 +143,15 @@ def test_optimize_loss_curve(prec, atol):
     ops.set_precision("bf16")
 
 
-def test_optimize_loss_curve_ref_config():
+@pytest.mark.parametrize("name,prec", [("ref", "f32"), ("b16", "f32"), ("long", "f32"), ("ref", "bf16"), ("b16", "bf16"), ("long", "bf16")])
+def test_optimize_loss_curve_other_configs(name, prec):
+    """Reference widths (ref, B = 2), the fast-path shapes (b16: B = 16, critics of width 768 / head dim 96) and book
+    lengths (long: 40 decode steps, Matcher over 79 positions), at the reference's own learning rate where the widths
+    are the reference's.  bf16 rows are compared only while the sampled token ids still agree with the reference run
+    (the curve fixture cannot say; a flipped token shows as a jump far above the tolerance and fails the test, which is
+    the intended reading: BF16_CURVE holds as long as the trajectory is the reference's)."""
     from consistent__style_transfer_amd import ops
-    ops.set_precision("f32")
-    name = "ref"
+    ops.set_precision(prec)
     c, G = CONFIGS[name], load_golden("curves", name)
     st = make_opt(name, lr=CURVE_LR[name])
     rows = []
@@ -125,23 +159,31 @@ def test_optimize_loss_curve_ref_config():
         lg = st.train_step(cu(opt_batch(c, it)), it, coins=G["optimize.coins"][it])
         rows.append([lg["g_total"].item(), lg["G"].item(), lg["STI"].item(), lg["CP_logits"].mean().item(),
                      lg["BK"].item(), lg["D"].item()])
-    np.testing.assert_allclose(np.array(rows), G["optimize.curve"], rtol=2e-3, atol=1e-3)
+    dev = np.abs(np.array(rows) - G["optimize.curve"])
+    report("stages.curve", tag=f"{name}.optimize.{prec}", max_abs_dev=float(dev.max()), per_column=[float(v) for v in dev.max(0)])
+    if prec == "f32":
+        np.testing.assert_allclose(np.array(rows), G["optimize.curve"], rtol=2e-3, atol=1e-3)
+    else:
+        np.testing.assert_allclose(np.array(rows), G["optimize.curve"], rtol=BF16_CURVE, atol=BF16_CURVE)
     ops.set_precision("bf16")
 
 
-def test_warmup_and_pretrain_curves():
+@pytest.mark.parametrize("name,prec", [("tiny", "f32"), ("long", "f32"), ("b16", "f32"), ("tiny", "bf16"), ("long", "bf16"), ("b16", "bf16")])
+def test_warmup_and_pretrain_curves(name, prec):
     from consistent__style_transfer_amd import model, ops, stages
-    ops.set_precision("f32")
-    name = "tiny"
+    ops.set_precision(prec)
     c, G = CONFIGS[name], load_golden("curves", name)
+    lr = CURVE_LR[name]
+    rt, at = (2e-3, 1e-3) if prec == "f32" else (BF16_CURVE, BF16_CURVE)
     set_constants(model, c)
-    wu = stages.WarmupStage(c["V"], 2, c["max_len"], lr=1e-3)
+    wu = stages.WarmupStage(c["V"], 2, c["max_len"], lr=lr)
     _load(wu.generator, "G")
     wu = wu.cuda().eval()
     wu.setup_optim()
     rows = [wu.train_step(cu(warm_batch(c, it)), coins=G["warmup.coins"][it])["loss"].item() for it in range(G["warmup.curve"].shape[0])]
-    np.testing.assert_allclose(rows, G["warmup.curve"], rtol=1e-3, atol=1e-3)
-    pre = stages.PretrainStage(c["V"], 2, lr=1e-3)
+    report("stages.curve", tag=f"{name}.warmup.{prec}", max_abs_dev=float(np.abs(np.array(rows) - G["warmup.curve"]).max()))
+    np.testing.assert_allclose(rows, G["warmup.curve"], rtol=rt, atol=at)
+    pre = stages.PretrainStage(c["V"], 2, lr=lr)
     for attr, which in (("classifier", "cls"), ("matcher", "mat"), ("denoiser", "dn")):
         _load(getattr(pre, attr), which)
     pre = pre.cuda().eval()
@@ -150,7 +192,8 @@ def test_warmup_and_pretrain_curves():
     for it in range(G["pretrain.curve"].shape[0]):
         r = pre.train_step(cu(pre_batch(c, it)))
         rows.append([r["s_loss"].item(), r["c_loss"].item(), r["dn_loss"].item()])
-    np.testing.assert_allclose(np.array(rows), G["pretrain.curve"], rtol=2e-3, atol=1e-3)
+    report("stages.curve", tag=f"{name}.pretrain.{prec}", max_abs_dev=float(np.abs(np.array(rows) - G["pretrain.curve"]).max()))
+    np.testing.assert_allclose(np.array(rows), G["pretrain.curve"], rtol=rt, atol=at)
     ops.set_precision("bf16")
 
 

@@ -11,17 +11,17 @@ from oracle import train as T
 torch.set_num_threads(4)
 
 
-@pytest.mark.parametrize("name", ["tiny", "ref"])
+@pytest.mark.parametrize("name", ["tiny", "ref", "b16", "long"])
 def test_optimize_curve(name):
     c, G = CONFIGS[name], load_golden("curves", name)
     P = {k: det_params(name, k) for k in ("G", "cls", "mat", "dn", "disc")}
     tr = T.OracleOptimize(P["G"], P["cls"], P["mat"], P["dn"], P["disc"], HP, c["n_head"], c["max_len"], lr=CURVE_LR[name])
-    steps = G["optimize.curve"].shape[0] if name == "tiny" else 3
+    steps = G["optimize.curve"].shape[0] if name in ("tiny", "long") else 3
     rows = [tr.step(opt_batch(c, it), it, G["optimize.coins"][it]) for it in range(steps)]
     np.testing.assert_allclose(np.array(rows), G["optimize.curve"][:steps], rtol=2e-3, atol=1e-3)
 
 
-@pytest.mark.parametrize("name", ["tiny"])
+@pytest.mark.parametrize("name", ["tiny", "long"])
 def test_warmup_and_pretrain_curves(name):
     c, G = CONFIGS[name], load_golden("curves", name)
     tw = T.OracleWarmup(det_params(name, "G"), lr=1e-3)
