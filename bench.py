@@ -123,8 +123,28 @@ class GraphedPipeline:
         (self.opt_d if it % 4 == 0 else self.opt_nd)(*bo, coins_tensor(2 * it + 1, self.L, self.dev))
 
 
+def _cgroup_cpu_quota():
+    """CPUs this process may use at once according to its cgroup (v2 cpu.max, v1 cfs quota), or None."""
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            return max(1, int(int(q) / int(per)))
+    except (OSError, ValueError):
+        pass
+    try:
+        q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        if q > 0:
+            return max(1, q // per)
+    except (OSError, ValueError):
+        pass
+    return None
+
+
 def physical_cores():
-    """Distinct (physical id, core id) pairs of /proc/cpuinfo (SMT siblings counted once), capped by the CPU affinity."""
+    """Host cores this job may actually use: distinct (physical id, core id) pairs of /proc/cpuinfo (SMT siblings counted
+    once), capped by the CPU affinity mask, by the cgroup CPU quota and by CST_CPU_THREADS (default 16: the CPU share of a
+    one-GPU box in this pool -- more threads than that share made the round-2 baseline 2-3x SLOWER, not faster)."""
     seen, phys, core = set(), None, None
     try:
         for line in open("/proc/cpuinfo"):
@@ -143,10 +163,14 @@ def physical_cores():
         n = min(n, len(os.sched_getaffinity(0)))
     except (AttributeError, OSError):
         pass
+    q = _cgroup_cpu_quota()
+    if q:
+        n = min(n, q)
+    n = min(n, int(os.environ.get("CST_CPU_THREADS", "16")))
     return max(1, n)
 
 
-def _cpu_stage_times(w, Bc, nthreads, warm=3, timed=10, budget_s=45.0):
+def _cpu_stage_times(w, Bc, nthreads, warm=3, timed=10, budget_s=30.0):
     """Per-stage step times of the oracle's training loops (plain torch fp32, oracle/train.py) at batch Bc: `warm` untimed +
     `timed` timed steps per stage (fewer only if one stage alone would exceed budget_s)."""
     from consistent__style_transfer_amd import model

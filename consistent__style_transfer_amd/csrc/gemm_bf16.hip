@@ -526,6 +526,245 @@ __global__ __launch_bounds__(256) void cst_gemm_bf16_reduce(BGemmArgs g) {
 extern bool cst_prof_on();
 extern void cst_prof_push(hipEvent_t a, hipEvent_t b, double flops, double bytes, int which);
 
+// =============================================================================================
+// 256 x 256 tile, 8 waves, four phases per K-tile (after cdna_hip_programming.md section 5, "The 256^2 8-phase template"):
+// the encoder-layer products with N >= 1536 (packed QKV, FFN1, and the dgrad of FFN2).
+//
+// Why: the 64x128 / 128x128 tiles above read 0.5-0.75 KB of LDS per MFMA and, two workgroups per CU, keep the LDS pipe as
+// busy as the matrix pipe (reads + the DMA's own LDS writes: 576 LDS cycles per 512 MFMA cycles at 64x128) -- they level
+// off at 20-25 % of the bf16 peak.  Here a wave owns 128 x 64 of the tile (64 MFMAs per K-tile against 24 fragment reads,
+// 0.375 KB per MFMA, half the LDS duty), one workgroup per CU, and the K-loop is cut into phases of 16 MFMAs so that every
+// phase overlaps three things: the fragment reads of the NEXT phase (register double buffer), two global_load_lds pieces
+// of the tile after next, and its own MFMAs.
+//
+//   LDS: 2 K-tile buffers x (A [256][128 B] + B [256][128 B]) = 128 KiB, 16-byte-slot XOR swizzle as above.
+//   phase (kh, mh) = k half kh (32 of the tile's 64) x row half mh of the wave tile: 4 row tiles x 4 column tiles x 1 MFMA.
+//   Fragments: A (kh, mh) 4 x b128, two register sets alternating per phase; B (kh) 4 x b128, one set per k half.
+//   A K-tile arrives in four groups of 128 rows (2 DMA instructions per wave each), issued in the order of first use:
+//     A1st (rows of the wave tiles' upper halves), B1st, B2nd (column halves)   first read in P3 of the tile before
+//     A2nd (lower halves)                                                        first read in P0
+//   phase:  s_waitcnt vmcnt(4)  -> the group this phase's fragment reads need has landed (this wave's pieces)
+//           s_barrier           -> ... and everyone else's; also: every read of the region overwritten next has completed
+//           2 x global_load_lds -> P0: B2nd(t+1)  P1: A2nd(t+1)  P2: A1st(t+2)  P3: B1st(t+2)   (each >= 3 phases before use)
+//           ds_read_b128 x 4/8 (fragments of the NEXT phase, other register set) ; 16 x MFMA ; s_waitcnt lgkmcnt(0)
+//   No vmcnt(0) inside the loop, one barrier per phase, up to three groups (6 pieces per wave) in flight across barriers.
+// Requires M % 256 == 0, N % 256 == 0, no split-K; everything else stays on the kernels above.
+// =============================================================================================
+constexpr int GB_T = 256;                 // tile edge
+constexpr int GB_ABYTES = GB_T * BROW;    // 32 KiB per operand per K-tile
+constexpr int GB_STAGE = 2 * GB_ABYTES;   // 64 KiB per K-tile
+
+template <int OFF>
+__device__ __forceinline__ u32x4_t lds_read128_off(unsigned addr) {
+    u32x4_t v;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF) : "memory");
+    return v;
+}
+
+struct GbFrag {
+    u32x4_t a[2][4];       // [set][row tile]
+    u32x4_t b[2][4];       // [k half][column tile]
+};
+
+template <int SET, int MH>
+__device__ __forceinline__ void gb_read_a(GbFrag& f, unsigned ad) {
+    f.a[SET][0] = lds_read128_off<(MH * 64 + 0) * BROW>(ad);
+    f.a[SET][1] = lds_read128_off<(MH * 64 + 16) * BROW>(ad);
+    f.a[SET][2] = lds_read128_off<(MH * 64 + 32) * BROW>(ad);
+    f.a[SET][3] = lds_read128_off<(MH * 64 + 48) * BROW>(ad);
+}
+template <int KH>
+__device__ __forceinline__ void gb_read_b(GbFrag& f, unsigned ad) {
+    f.b[KH][0] = lds_read128_off<0 * BROW>(ad);
+    f.b[KH][1] = lds_read128_off<16 * BROW>(ad);
+    f.b[KH][2] = lds_read128_off<32 * BROW>(ad);
+    f.b[KH][3] = lds_read128_off<48 * BROW>(ad);
+}
+template <int SA, int KH, int MH>
+__device__ __forceinline__ void gb_mfma(const GbFrag& f, f32x4_t (&acc)[8][4]) {
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            acc[MH * 4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, f.a[SA][i]),
+                                                                         __builtin_bit_cast(bf16x8_t, f.b[KH][j]), acc[MH * 4 + i][j], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+}
+
+__global__ __launch_bounds__(512, 2) void cst_gemm_bf16_big_kernel(BGemmArgs g) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tilesM = g.M / GB_T, tilesN = g.N / GB_T;
+    int id;
+    {
+        const int nblk = gridDim.x, q = nblk >> 3, r = nblk & 7, xcd = blockIdx.x & 7;
+        id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (blockIdx.x >> 3);
+    }
+    constexpr int GN = 2;                                  // two tile columns per group: neighbours on an XCD share A panels
+    const int grp = id / (GN * tilesM);
+    const int gw = min(GN, tilesN - grp * GN);
+    const int local = id - grp * GN * tilesM;
+    const int tm = local / gw, tn = grp * GN + local % gw;
+    const int m0 = tm * GB_T, n0 = tn * GB_T;
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+    const int lr = lane & 15, lq = lane >> 4;
+    const int lrow = lane >> 3, lps = lane & 7;
+
+    // DMA sources: lane l of a piece lands at (row r0 + l/8, physical slot l%8), so it fetches logical slot (l%8) ^ ((r0 + l/8) & 7)
+    // = (l%8) ^ (l/8) (r0 is a multiple of 8): one per-lane base per operand, pieces differ by wave-uniform row offsets.
+    const bf16_t* abase = g.A + (long)(m0 + lrow) * g.lda + ((lps ^ lrow) << 3);
+    const bf16_t* bbase = g.B + (long)(n0 + lrow) * g.ldb + ((lps ^ lrow) << 3);
+    // piece ci (0..15) of a group; this wave moves pieces 2 wave, 2 wave + 1
+    //   A group half h: rows (ci >> 3) * 128 + h * 64 + (ci & 7) * 8      (upper / lower halves of the two wave rows)
+    //   B group half h: rows h * 128 + ci * 8
+    auto issue_a = [&](int t, int h) {
+        char* st = smem + (t & 1) * GB_STAGE;
+        const long k = (long)t * BBK;
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const int ci = 2 * wave + c;
+            const int r0 = (ci >> 3) * 128 + h * 64 + (ci & 7) * 8;
+            __builtin_amdgcn_global_load_lds((gbl_ptr_t)(abase + (long)r0 * g.lda + k), (lds_ptr_t)(st + r0 * BROW), 16, 0, 0);
+        }
+    };
+    auto issue_b = [&](int t, int h) {
+        char* st = smem + (t & 1) * GB_STAGE + GB_ABYTES;
+        const long k = (long)t * BBK;
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const int r0 = h * 128 + (2 * wave + c) * 8;
+            __builtin_amdgcn_global_load_lds((gbl_ptr_t)(bbase + (long)r0 * g.ldb + k), (lds_ptr_t)(st + r0 * BROW), 16, 0, 0);
+        }
+    };
+    const int nk = g.K / BBK;
+
+    f32x4_t acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    GbFrag f;
+
+    // fragment read addresses (buffer 0): row (wr * 128 + lr) resp. (wc * 64 + lr), slot (kh * 4 + lq) ^ (lr & 7); the row half and
+    // the row / column tile go into the instruction's offset field
+    const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+    unsigned a_ad[2], b_ad[2];
+#pragma unroll
+    for (int kh = 0; kh < 2; ++kh) {
+        a_ad[kh] = lds_base + (wr * 128 + lr) * BROW + (((kh * 4 + lq) ^ (lr & 7)) << 4);
+        b_ad[kh] = lds_base + GB_ABYTES + (wc * 64 + lr) * BROW + (((kh * 4 + lq) ^ (lr & 7)) << 4);
+    }
+
+    // prologue: all of tile 0 and the first two groups of tile 1; the first three groups must have landed
+    issue_a(0, 0); issue_b(0, 0); issue_b(0, 1); issue_a(0, 1);
+    if (nk > 1) { issue_a(1, 0); issue_b(1, 0); asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); }
+    else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    gb_read_a<0, 0>(f, a_ad[0]);
+    gb_read_b<0>(f, b_ad[0]);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+
+#define GB_PHASE_END()                                      \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      \
+    __builtin_amdgcn_sched_barrier(0);
+    for (int t = 0; t < nk; ++t) {
+        const bool more = t + 1 < nk, more2 = t + 2 < nk;
+        const unsigned cur = (t & 1) * GB_STAGE, nxt = ((t + 1) & 1) * GB_STAGE;
+        // ---- P0 (kh 0, mh 0): A2nd(t) must have landed; younger in flight: A1st(t+1), B1st(t+1)
+        if (more) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (more) issue_b(t + 1, 1);                      // B2nd(t+1)
+        gb_read_a<1, 1>(f, a_ad[0] + cur);
+        gb_mfma<0, 0, 0>(f, acc);
+        GB_PHASE_END()
+        // ---- P1 (kh 0, mh 1)
+        __builtin_amdgcn_s_barrier();
+        if (more) issue_a(t + 1, 1);                      // A2nd(t+1)
+        gb_read_a<0, 0>(f, a_ad[1] + cur);
+        gb_read_b<1>(f, b_ad[1] + cur);
+        gb_mfma<1, 0, 1>(f, acc);
+        GB_PHASE_END()
+        // ---- P2 (kh 1, mh 0)
+        __builtin_amdgcn_s_barrier();
+        if (more2) issue_a(t + 2, 0);                     // A1st(t+2)
+        gb_read_a<1, 1>(f, a_ad[1] + cur);
+        gb_mfma<0, 1, 0>(f, acc);
+        GB_PHASE_END()
+        // ---- P3 (kh 1, mh 1): A1st, B1st, B2nd of tile t+1 must have landed; younger in flight: A2nd(t+1), A1st(t+2)
+        if (more2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");          // (nothing is outstanding on the last tile: a no-op there)
+        __builtin_amdgcn_s_barrier();
+        if (more2) issue_b(t + 2, 0);                     // B1st(t+2)
+        if (more) {
+            gb_read_a<0, 0>(f, a_ad[0] + nxt);
+            gb_read_b<0>(f, b_ad[0] + nxt);
+        }
+        gb_mfma<1, 1, 1>(f, acc);
+        GB_PHASE_END()
+    }
+#undef GB_PHASE_END
+    __syncthreads();                                  // every fragment read is done before the ring becomes C staging
+
+    // epilogue: the wave tile's two 64 x 64 halves through LDS (8 x 16 KiB), whole 256-byte row segments per store
+    const uint32_t dseed = g.drop.p > 0.f ? cst_drop_seed(g.drop) : 0u;
+    constexpr int CLD = 64, C4 = 16;
+    float* Cs = reinterpret_cast<float*>(smem) + wave * 64 * CLD;
+    const bool vec = bgemm_vec_ok(g);
+#pragma unroll
+    for (int mh = 0; mh < 2; ++mh) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) Cs[(i * 16 + lq * 4 + r) * CLD + j * 16 + lr] = acc[mh * 4 + i][j][r];
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll 4
+        for (int it = 0; it < 64 * C4 / 64; ++it) {
+            const int idx = lane + 64 * it;
+            const int rr = idx / C4, cc = (idx % C4) * 4;
+            const int m = m0 + wr * 128 + mh * 64 + rr, n = n0 + wc * 64 + cc;
+            const float4 a4 = *reinterpret_cast<const float4*>(&Cs[rr * CLD + cc]);
+            const float av[4] = {a4.x, a4.y, a4.z, a4.w};
+            if (vec) bgemm_store4(g, dseed, m, n, av);
+            else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) bgemm_store(g, dseed, m, n + e, av[e]);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+static bool bgemm_big_ok(const BGemmArgs& g) {
+    return g.M % GB_T == 0 && g.N % GB_T == 0 && g.K % BBK == 0 && g.splits == 1 && !g.slab_only && !g.A2;
+}
+
+static int bgemm_big_launch(const BGemmArgs& g, hipStream_t st) {
+    const size_t lds = 2 * GB_STAGE;
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void*)cst_gemm_bf16_big_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_done = true;
+    }
+    dim3 grid((g.M / GB_T) * (g.N / GB_T), 1, 1), block(512);
+    if (cst_prof_on()) {
+        hipEvent_t ea, eb;
+        (void)hipEventCreate(&ea); (void)hipEventCreate(&eb);
+        cst_prof_push(ea, eb, 2.0 * g.M * g.N * g.K, 2.0 * ((double)g.M * g.K + (double)g.N * g.K) + (g.C ? 4.0 : 0.0) * g.M * g.N + (g.Cb ? 2.0 : 0.0) * g.M * g.N, 1);
+        hipExtLaunchKernelGGL(cst_gemm_bf16_big_kernel, grid, block, lds, st, ea, eb, 0, g);
+    } else {
+        hipLaunchKernelGGL(cst_gemm_bf16_big_kernel, grid, block, lds, st, g);
+    }
+    return 0;
+}
+
+
 template <int BM, int BN, int NSTAGE, bool TT = false>
 static int bgemm_launch(const BGemmArgs& g, hipStream_t st) {
     const size_t lds = (size_t)NSTAGE * (BM + BN) * BROW;
@@ -593,6 +832,20 @@ extern "C" int cst_gemm_bf16(const void* A, long lda, const void* B, long ldb,
     CST_REQUIRE(splits == 1 || workspace, "cst_gemm_bf16: split-K needs a workspace");
     g.splits = splits; g.slab = workspace;
     hipStream_t st = (hipStream_t)stream;
+    // 256 x 256 / 8-wave kernel: tile code 256 forces it; by itself it takes the products whose 256^2 tiles fill at least
+    // half the chip and at most one round of it, or several rounds (measured rule, tools/gemm_bench.py bf16nt)
+    {
+        static const int big_mode = getenv("CST_GEMM_BIG") ? atoi(getenv("CST_GEMM_BIG")) : 1;      // 0 never, 1 auto, 2 whenever legal
+        const long t256 = (long)(M / GB_T) * (N / GB_T);
+        const bool want = tile == 256 || (tile == 0 && splitk <= 1 && big_mode == 2) ||
+                          (tile == 0 && splitk <= 1 && big_mode == 1 && N >= 1024 && K >= 256 && t256 >= 128);
+        if (want && splits == 1 && bgemm_big_ok(g)) {
+            bgemm_big_launch(g, st);
+            CST_LAUNCH_CHECK("cst_gemm_bf16 (256x256)");
+            return CST_OK;
+        }
+        if (tile == 256) { tile = 0; }
+    }
     if (ring == 0 && getenv("CST_RING4") && !use_big && tiles * splits <= 256 && g.k_per_split >= 256) ring = 2;
     if (use_big) { if (ring == 1) bgemm_launch<128, 128, 3>(g, st); else bgemm_launch<128, 128, 2>(g, st); }
     else { if (ring == 2) bgemm_launch<64, 128, 4>(g, st); else if (ring == 1) bgemm_launch<64, 128, 3>(g, st); else bgemm_launch<64, 128, 2>(g, st); }

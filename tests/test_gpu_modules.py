@@ -60,6 +60,8 @@ def build(model, name, which):
 NAMES = ["tiny", "ref", "b16", "long"]
 BF16_OUT = 2e-2           # relative L2 of an output tensor
 BF16_GRAD = 6e-2          # relative L2 of a gradient (6 encoder layers / 8-40 recurrent steps of bf16 products compound)
+BF16_GRAD_Q90 = 3e-2      # ... and, where a max-pool routes gradients (below), the 90th percentile of |got - ref| / rms(ref)
+BF16_GRAD_ROUTED = 0.35   # whole-tensor bound for those: a flipped arg-max moves one feature's whole gradient to another position
 BF16_ROWS = 0.75          # fraction of sentences whose fed-back token ids all agree with the reference
 
 
@@ -96,7 +98,24 @@ def named_grads(m):
     return {k: p.grad for k, p in m.named_parameters() if p.grad is not None}
 
 
-def run_grads(G, prefix, m, loss, prec, inp=None, same_trajectory=True):
+def grad_q90(G, prefix, named, input_grad=None):
+    out = {}
+    items = dict(named)
+    if input_grad is not None:
+        items["__input__"] = input_grad
+    for k, g in items.items():
+        g = g.detach().cpu().numpy().astype(np.float64)
+        full, nrm, smp = f"{prefix}.grad.{k}", f"{prefix}.gradnorm.{k}", f"{prefix}.gradsample.{k}"
+        if full in G and np.linalg.norm(G[full]) > 1e-6:
+            ref = G[full].astype(np.float64)
+            out[k] = float(np.quantile(np.abs(g - ref), 0.9) / np.sqrt(np.mean(ref ** 2)))
+        elif nrm in G and G[nrm][0] > 1e-6:
+            stride = next(st for st in (97, 1009) if g.reshape(-1)[::st].size == G[smp].size)
+            out[k] = float(np.quantile(np.abs(g.reshape(-1)[::stride] - G[smp]), 0.9) / (G[nrm][0] / np.sqrt(g.size)))
+    return out
+
+
+def run_grads(G, prefix, m, loss, prec, inp=None, same_trajectory=True, routed=False):
     m.zero_grad()
     loss.backward()
     if prec == "f32":
@@ -107,7 +126,16 @@ def run_grads(G, prefix, m, loss, prec, inp=None, same_trajectory=True):
     worst = max(devs, key=devs.get)
     report("modules.grad", tag=prefix, worst=worst, dev=devs[worst], median=float(np.median(list(devs.values()))),
            same_trajectory=same_trajectory)
-    if same_trajectory:
+    if same_trajectory and routed:
+        # TextCNN / RelGAN_D (max over time, classifier.py:32, discriminator.py:42) and the Matcher (max over the sequence,
+        # match.py:41): bf16 rounding can flip a near-tie of the arg-max, which moves that feature's gradient to another
+        # position wholesale (at B = 2 one flip is 1/256 of a filter bank).  Most elements must still agree closely.
+        q90 = grad_q90(G, prefix, named_grads(m), None if inp is None else inp.grad)
+        wq = max(q90, key=q90.get)
+        report("modules.grad_q90", tag=prefix, worst=wq, q90=q90[wq])
+        assert q90[wq] <= BF16_GRAD_Q90, (prefix, wq, q90[wq])
+        assert devs[worst] <= BF16_GRAD_ROUTED, (prefix, worst, devs[worst])
+    elif same_trajectory:
         assert devs[worst] <= BF16_GRAD, (prefix, worst, devs[worst])
     else:
         # some sentence followed a different token trajectory than the reference: element-wise comparison is void, the
@@ -129,11 +157,11 @@ def test_textcnn(cst, name, prec):
     x = torch.from_numpy(G["x"]).cuda()
     y = m(x)
     cmp_out(y, G["cls.ids.out"], prec, tag=f"{name}.cls.ids.out")
-    run_grads(G, "cls.ids", m, lossw("cls.ids", y), prec)
+    run_grads(G, "cls.ids", m, lossw("cls.ids", y), prec, routed=True)
     sp = soft_input(c["B"], c["L"], c["V"], 11, "cuda")
     y = m(sp)
     cmp_out(y, G["cls.soft.out"], prec, tag=f"{name}.cls.soft.out")
-    run_grads(G, "cls.soft", m, lossw("cls.soft", y), prec, sp)
+    run_grads(G, "cls.soft", m, lossw("cls.soft", y), prec, sp, routed=True)
     ops.set_precision("bf16")
 
 
@@ -164,11 +192,11 @@ def test_matcher(cst, name, prec):
     x, x2 = torch.from_numpy(G["x"]).cuda(), torch.from_numpy(G["x2"]).cuda()
     y = m(x, x2)
     cmp_out(y, G["mat.ids.out"], prec, tag=f"{name}.mat.ids.out")
-    run_grads(G, "mat.ids", m, lossw("mat.ids", y), prec)
+    run_grads(G, "mat.ids", m, lossw("mat.ids", y), prec, routed=True)
     sp = soft_input(c["B"], c["L"], c["V"], 13, "cuda")
     y = m(sp, x)
     cmp_out(y, G["mat.soft.out"], prec, tag=f"{name}.mat.soft.out")
-    run_grads(G, "mat.soft", m, lossw("mat.soft", y), prec, sp)
+    run_grads(G, "mat.soft", m, lossw("mat.soft", y), prec, sp, routed=True)
     ops.set_precision("bf16")
 
 
@@ -182,11 +210,11 @@ def test_relgan_d(cst, name, prec):
     sp = soft_input(c["B"], c["L"], c["V"], 14, "cuda")
     y = m(sp)
     cmp_out(y, G["disc.soft.out"], prec, tag=f"{name}.disc.soft.out")
-    run_grads(G, "disc.soft", m, lossw("disc.soft", y), prec, sp)
+    run_grads(G, "disc.soft", m, lossw("disc.soft", y), prec, sp, routed=True)
     x = torch.from_numpy(G["x"]).cuda()
     y = m(x)                                                    # ids fast path == dense one-hot
     cmp_out(y, G["disc.onehot.out"], prec, tag=f"{name}.disc.onehot.out")
-    run_grads(G, "disc.onehot", m, lossw("disc.onehot", y), prec)
+    run_grads(G, "disc.onehot", m, lossw("disc.onehot", y), prec, routed=True)
     y = m(torch.nn.functional.one_hot(x, c["V"]).float())       # the reference's own calling convention
     cmp_out(y, G["disc.onehot.out"], prec, tag=f"{name}.disc.onehot.out")
     ops.set_precision("bf16")

@@ -128,6 +128,26 @@ def test_gemm_bf16(ops, shape, tile):
     close(Cb3.view(torch.bfloat16).float()[:, :N], torch.relu(ref + bias) * mask, 1e-2, 1e-2 * math.sqrt(K))
 
 
+@pytest.mark.parametrize("shape", [(256, 256, 64), (256, 256, 128), (512, 256, 192), (256, 768, 320), (4608, 2304, 768), (9216, 2048, 512),
+                                   (4608, 2048, 768), (1024, 512, 2304)])
+def test_gemm_bf16_256_tile(ops, shape):
+    """The 256 x 256 / 8-wave kernel (tile code 256): one, two, odd and many K-tiles; every epilogue of the small-tile kernel."""
+    test_gemm_bf16(ops, shape, 256)
+    M, N, K = shape
+    # identity check with an asymmetric B: C = I[:, :K] B^T must reproduce B^T exactly (catches a transposed C map, a symmetric
+    # operand would not) -- cdna_hip_programming.md section 3
+    A = torch.zeros(M, K)
+    A[torch.arange(min(M, K)), torch.arange(min(M, K))] = 1.0
+    B = (torch.arange(N * K, dtype=torch.float32).reshape(N, K) % 251) - 125.0          # exactly representable in bf16
+    Ab, _ = ops.cast_bf16(dev(A), want_t=False)
+    Bb, _ = ops.cast_bf16(dev(B), want_t=False)
+    C = torch.full((M, N), float("nan"), device="cuda")
+    ops.gemm_bf16(Ab, Bb, M, N, C=C, tile=256)
+    ref = torch.zeros(M, N)
+    ref[:min(M, K)] = B.t()[:min(M, K)]
+    assert torch.equal(C.cpu(), ref)
+
+
 @pytest.mark.parametrize("tile", [64, 128])
 def test_gemm_epilogues(ops, tile):
     ops.set_precision("f32")

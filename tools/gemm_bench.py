@@ -52,24 +52,36 @@ def main():
               + f"   best {fl / best / 1e6:7.1f} TF/s  {by / best / 1e6:5.2f} TB/s(min-traffic)")
 
 
-def main_bf16():
-    print("---- bf16-operand NT GEMM (global_load_lds ring); tile codes: 0 auto, 64/128 3-stage, 65/129 2-stage")
-    for M, N, K, akm, bkm, note in SHAPES:
+ENC_SHAPES = [  # the encoder-layer products of the bench workloads (T = 4608 MLM / 9216 Matcher; d = 512 / 768; F = 2048)
+    (4608, 2304, 768, 1, 1, "QKV fwd d768 MLM"), (9216, 2304, 768, 1, 1, "QKV fwd d768 Mat"), (4608, 2048, 768, 1, 1, "FFN1 fwd d768"),
+    (9216, 2048, 768, 1, 1, "FFN1 fwd d768 Mat"), (4608, 768, 2048, 1, 1, "FFN2 fwd d768"), (9216, 768, 2048, 1, 1, "FFN2 fwd d768 Mat"),
+    (4608, 768, 768, 1, 1, "out fwd d768"), (9216, 768, 768, 1, 1, "out fwd d768 Mat"), (4608, 768, 2304, 1, 1, "QKV dgrad d768"),
+    (4608, 1536, 512, 1, 1, "QKV fwd d512"), (4608, 2048, 512, 1, 1, "FFN1 fwd d512"), (9216, 2048, 512, 1, 1, "FFN1 fwd d512 Mat"),
+    (9216, 1536, 512, 1, 1, "QKV fwd d512 Mat"), (9216, 512, 2048, 1, 1, "FFN2 fwd d512 Mat"), (15360, 2048, 512, 1, 1, "FFN1 book MLM"),
+    (30720, 2048, 512, 1, 1, "FFN1 book Mat"), (4608, 10000, 768, 1, 1, "vocab fwd d768"),
+]
+
+
+def main_bf16(shapes=None, out_bf16=False):
+    print("---- bf16-operand NT GEMM (global_load_lds ring); tile codes: 0 auto, 64/128 2-stage ring, +1 3-stage, +2 4-stage, 256 = 8-wave 256x256"
+          + ("; bf16-only C" if out_bf16 else "; fp32 C"))
+    for M, N, K, akm, bkm, note in (shapes or SHAPES):
         A, B = torch.randn(M, K, device="cuda"), torch.randn(N, K, device="cuda")
         Ab, _ = ops.cast_bf16(A, want_t=False)
         Bb, _ = ops.cast_bf16(B, want_t=False)
-        C = torch.empty(M, N, device="cuda")
+        C = torch.empty(M, N, device="cuda") if not out_bf16 else None
+        Cb = torch.empty(M, (N + 63) // 64 * 64, device="cuda", dtype=torch.int16) if out_bf16 else None
         res = []
-        tiles = [0, 64, 65, 128, 129]
+        tiles = [0, 64, 65, 128, 129, 130, 256]
         for tile in tiles:
             for _ in range(3):
-                ops.gemm_bf16(Ab, Bb, M, N, C=C, tile=tile)
+                ops.gemm_bf16(Ab, Bb, M, N, C=C, Cb=Cb, tile=tile)
             torch.cuda.synchronize()
             n = 20
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
                 for _ in range(n):
-                    ops.gemm_bf16(Ab, Bb, M, N, C=C, tile=tile)
+                    ops.gemm_bf16(Ab, Bb, M, N, C=C, Cb=Cb, tile=tile)
             g.replay()
             torch.cuda.synchronize()
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -86,5 +98,9 @@ def main_bf16():
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "bf16nt":
         main_bf16()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "enc":
+        main_bf16(ENC_SHAPES)
+        main_bf16(ENC_SHAPES[:6], out_bf16=True)
         sys.exit(0)
     main()
