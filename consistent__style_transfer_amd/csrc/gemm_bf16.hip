@@ -527,32 +527,34 @@ extern bool cst_prof_on();
 extern void cst_prof_push(hipEvent_t a, hipEvent_t b, double flops, double bytes, int which);
 
 // =============================================================================================
-// 256 x 256 tile, 8 waves, four phases per K-tile (after cdna_hip_programming.md section 5, "The 256^2 8-phase template"):
-// the encoder-layer products with N >= 1536 (packed QKV, FFN1, and the dgrad of FFN2).
+// 256 x 256 tile, 8 waves, K-tiles of 32 in a 4-stage ring (after cdna_hip_programming.md section 5, "The 256^2 8-phase
+// template"): the encoder-layer products with N >= 1536 (packed QKV, FFN1, and the dgrad of FFN2).
 //
-// Why: the 64x128 / 128x128 tiles above read 0.5-0.75 KB of LDS per MFMA and, two workgroups per CU, keep the LDS pipe as
-// busy as the matrix pipe (reads + the DMA's own LDS writes: 576 LDS cycles per 512 MFMA cycles at 64x128) -- they level
-// off at 20-25 % of the bf16 peak.  Here a wave owns 128 x 64 of the tile (64 MFMAs per K-tile against 24 fragment reads,
-// 0.375 KB per MFMA, half the LDS duty), one workgroup per CU, and the K-loop is cut into phases of 16 MFMAs so that every
-// phase overlaps three things: the fragment reads of the NEXT phase (register double buffer), two global_load_lds pieces
-// of the tile after next, and its own MFMAs.
+// Why: measured on these shapes (tools/gemm_bench.py enc) every tile of the small-tile kernel above, and a first 256^2
+// version with two 64-deep K-tile buffers, sits at 20-40 GB/s of operand bytes per CU: the CUs of an XCD walk K in
+// lockstep, so each K-tile is a first touch served at Infinity-Cache / HBM latency (~1.5-2.5 us under load), and the rate
+// is (bytes in flight) / latency.  What can be raised is (a) FLOP per operand byte -- 128 at 256 x 256 against 43-64 at
+// 64 x 128 / 128 x 128 -- and (b) bytes in flight per CU: four 32 KiB stages keep up to ~80 KiB in flight (a 64-deep
+// double buffer caps it at 48), which is what the 32-deep K-tile buys.  A wave owns 128 x 64 of the tile: 32 MFMAs per
+// K-tile against 12 fragment reads.
 //
-//   LDS: 2 K-tile buffers x (A [256][128 B] + B [256][128 B]) = 128 KiB, 16-byte-slot XOR swizzle as above.
-//   phase (kh, mh) = k half kh (32 of the tile's 64) x row half mh of the wave tile: 4 row tiles x 4 column tiles x 1 MFMA.
-//   Fragments: A (kh, mh) 4 x b128, two register sets alternating per phase; B (kh) 4 x b128, one set per k half.
-//   A K-tile arrives in four groups of 128 rows (2 DMA instructions per wave each), issued in the order of first use:
-//     A1st (rows of the wave tiles' upper halves), B1st, B2nd (column halves)   first read in P3 of the tile before
-//     A2nd (lower halves)                                                        first read in P0
-//   phase:  s_waitcnt vmcnt(4)  -> the group this phase's fragment reads need has landed (this wave's pieces)
-//           s_barrier           -> ... and everyone else's; also: every read of the region overwritten next has completed
-//           2 x global_load_lds -> P0: B2nd(t+1)  P1: A2nd(t+1)  P2: A1st(t+2)  P3: B1st(t+2)   (each >= 3 phases before use)
-//           ds_read_b128 x 4/8 (fragments of the NEXT phase, other register set) ; 16 x MFMA ; s_waitcnt lgkmcnt(0)
-//   No vmcnt(0) inside the loop, one barrier per phase, up to three groups (6 pieces per wave) in flight across barriers.
-// Requires M % 256 == 0, N % 256 == 0, no split-K; everything else stays on the kernels above.
+//   LDS: 4 stages x (A [256 rows][64 B] + B [256][64 B]) = 128 KiB.  A DMA piece (1 KiB) is 16 rows of 64 bytes; the four
+//   16-byte slots of a row are XOR-ed with g((row >> 2) & 3), g = {0, 3, 2, 1}, which makes every ds_read_b128 lane group
+//   ({0-3, 12-15, 20-27}, ... -- MI355X_MICROARCH.md LDS table) hit 16 distinct positions of the 256-byte bank line.
+//   K-tile t, two phases of 16 MFMAs (row halves mh = 0, 1 of the wave tile), ONE barrier:
+//     P0(t): DMA B(t+3) ; read A(mh 1, t) into the other A set               ; 16 MFMA on A(mh 0) x B
+//     P1(t): vmcnt(6) -> tile t+1 landed ; barrier ; DMA A(t+3) ;
+//            read A(mh 0, t+1) and B(t+1) into the other sets                 ; 16 MFMA on A(mh 1) x B
+//   Stage (t+3) % 4 held tile t-1, whose last fragment read completed before the barrier of P1(t-1): both DMA issues are
+//   WAR-safe without a barrier of their own.  Never vmcnt(0) inside the loop.
+// Requires M % 256 == 0, N % 256 == 0, K % 32 == 0 (K % 64 == 0 as everywhere), no split-K.
 // =============================================================================================
 constexpr int GB_T = 256;                 // tile edge
-constexpr int GB_ABYTES = GB_T * BROW;    // 32 KiB per operand per K-tile
-constexpr int GB_STAGE = 2 * GB_ABYTES;   // 64 KiB per K-tile
+constexpr int GB_K = 32;                  // K-tile
+constexpr int GB_ROW = 64;                // bytes per LDS row
+constexpr int GB_ABYTES = GB_T * GB_ROW;  // 16 KiB per operand per K-tile
+constexpr int GB_STAGE = 2 * GB_ABYTES;   // 32 KiB per K-tile
+constexpr int GB_NST = 4;
 
 template <int OFF>
 __device__ __forceinline__ u32x4_t lds_read128_off(unsigned addr) {
@@ -563,24 +565,24 @@ __device__ __forceinline__ u32x4_t lds_read128_off(unsigned addr) {
 
 struct GbFrag {
     u32x4_t a[2][4];       // [set][row tile]
-    u32x4_t b[2][4];       // [k half][column tile]
+    u32x4_t b[2][4];       // [set][column tile]
 };
 
 template <int SET, int MH>
 __device__ __forceinline__ void gb_read_a(GbFrag& f, unsigned ad) {
-    f.a[SET][0] = lds_read128_off<(MH * 64 + 0) * BROW>(ad);
-    f.a[SET][1] = lds_read128_off<(MH * 64 + 16) * BROW>(ad);
-    f.a[SET][2] = lds_read128_off<(MH * 64 + 32) * BROW>(ad);
-    f.a[SET][3] = lds_read128_off<(MH * 64 + 48) * BROW>(ad);
+    f.a[SET][0] = lds_read128_off<(MH * 64 + 0) * GB_ROW>(ad);
+    f.a[SET][1] = lds_read128_off<(MH * 64 + 16) * GB_ROW>(ad);
+    f.a[SET][2] = lds_read128_off<(MH * 64 + 32) * GB_ROW>(ad);
+    f.a[SET][3] = lds_read128_off<(MH * 64 + 48) * GB_ROW>(ad);
 }
-template <int KH>
+template <int SET>
 __device__ __forceinline__ void gb_read_b(GbFrag& f, unsigned ad) {
-    f.b[KH][0] = lds_read128_off<0 * BROW>(ad);
-    f.b[KH][1] = lds_read128_off<16 * BROW>(ad);
-    f.b[KH][2] = lds_read128_off<32 * BROW>(ad);
-    f.b[KH][3] = lds_read128_off<48 * BROW>(ad);
+    f.b[SET][0] = lds_read128_off<0 * GB_ROW>(ad);
+    f.b[SET][1] = lds_read128_off<16 * GB_ROW>(ad);
+    f.b[SET][2] = lds_read128_off<32 * GB_ROW>(ad);
+    f.b[SET][3] = lds_read128_off<48 * GB_ROW>(ad);
 }
-template <int SA, int KH, int MH>
+template <int SA, int SB, int MH>
 __device__ __forceinline__ void gb_mfma(const GbFrag& f, f32x4_t (&acc)[8][4]) {
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -588,11 +590,11 @@ __device__ __forceinline__ void gb_mfma(const GbFrag& f, f32x4_t (&acc)[8][4]) {
 #pragma unroll
         for (int j = 0; j < 4; ++j)
             acc[MH * 4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, f.a[SA][i]),
-                                                                         __builtin_bit_cast(bf16x8_t, f.b[KH][j]), acc[MH * 4 + i][j], 0, 0, 0);
+                                                                         __builtin_bit_cast(bf16x8_t, f.b[SB][j]), acc[MH * 4 + i][j], 0, 0, 0);
     __builtin_amdgcn_s_setprio(0);
 }
 
-__global__ __launch_bounds__(512, 2) void cst_gemm_bf16_big_kernel(BGemmArgs g) {
+__global__ __launch_bounds__(512, 2) void cst_gemm_bf16_big_kernel(BGemmArgs g, int gn) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tilesM = g.M / GB_T, tilesN = g.N / GB_T;
     int id;
@@ -600,46 +602,44 @@ __global__ __launch_bounds__(512, 2) void cst_gemm_bf16_big_kernel(BGemmArgs g) 
         const int nblk = gridDim.x, q = nblk >> 3, r = nblk & 7, xcd = blockIdx.x & 7;
         id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (blockIdx.x >> 3);
     }
-    constexpr int GN = 2;                                  // two tile columns per group: neighbours on an XCD share A panels
-    const int grp = id / (GN * tilesM);
-    const int gw = min(GN, tilesN - grp * GN);
-    const int local = id - grp * GN * tilesM;
-    const int tm = local / gw, tn = grp * GN + local % gw;
+    // gn tile columns per group: an XCD (consecutive ids) works on a gn-wide strip, sharing few A and B panels
+    const int grp = id / (gn * tilesM);
+    const int gw = min(gn, tilesN - grp * gn);
+    const int local = id - grp * gn * tilesM;
+    const int tm = local / gw, tn = grp * gn + local % gw;
     const int m0 = tm * GB_T, n0 = tn * GB_T;
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wr = wave >> 2, wc = wave & 3;
     const int lr = lane & 15, lq = lane >> 4;
-    const int lrow = lane >> 3, lps = lane & 7;
 
-    // DMA sources: lane l of a piece lands at (row r0 + l/8, physical slot l%8), so it fetches logical slot (l%8) ^ ((r0 + l/8) & 7)
-    // = (l%8) ^ (l/8) (r0 is a multiple of 8): one per-lane base per operand, pieces differ by wave-uniform row offsets.
-    const bf16_t* abase = g.A + (long)(m0 + lrow) * g.lda + ((lps ^ lrow) << 3);
-    const bf16_t* bbase = g.B + (long)(n0 + lrow) * g.ldb + ((lps ^ lrow) << 3);
-    // piece ci (0..15) of a group; this wave moves pieces 2 wave, 2 wave + 1
-    //   A group half h: rows (ci >> 3) * 128 + h * 64 + (ci & 7) * 8      (upper / lower halves of the two wave rows)
-    //   B group half h: rows h * 128 + ci * 8
-    auto issue_a = [&](int t, int h) {
-        char* st = smem + (t & 1) * GB_STAGE;
-        const long k = (long)t * BBK;
+    // DMA sources: lane l of a piece lands at (row r0 + l/4, physical slot l%4); r0 is a multiple of 16, so the row's swizzle
+    // key ((r0 + l/4) >> 2) & 3 is l >> 4 and the lane fetches logical slot (l%4) ^ g(l >> 4): one per-lane base per operand.
+    const int gsw = (0x1230 >> (4 * (lane >> 4))) & 3;                 // g = {0, 3, 2, 1}
+    const int src_slot = (lane & 3) ^ gsw;
+    const bf16_t* abase = g.A + (long)(m0 + (lane >> 2)) * g.lda + (src_slot << 3);
+    const bf16_t* bbase = g.B + (long)(n0 + (lane >> 2)) * g.ldb + (src_slot << 3);
+    // this wave moves pieces 2 wave, 2 wave + 1 of an operand's 16: rows 32 wave .. 32 wave + 31
+    auto issue_a = [&](int t) {
+        char* st = smem + (t & (GB_NST - 1)) * GB_STAGE;
+        const long k = (long)t * GB_K;
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
-            const int ci = 2 * wave + c;
-            const int r0 = (ci >> 3) * 128 + h * 64 + (ci & 7) * 8;
-            __builtin_amdgcn_global_load_lds((gbl_ptr_t)(abase + (long)r0 * g.lda + k), (lds_ptr_t)(st + r0 * BROW), 16, 0, 0);
+            const int r0 = (2 * wave + c) * 16;
+            __builtin_amdgcn_global_load_lds((gbl_ptr_t)(abase + (long)r0 * g.lda + k), (lds_ptr_t)(st + r0 * GB_ROW), 16, 0, 0);
         }
     };
-    auto issue_b = [&](int t, int h) {
-        char* st = smem + (t & 1) * GB_STAGE + GB_ABYTES;
-        const long k = (long)t * BBK;
+    auto issue_b = [&](int t) {
+        char* st = smem + (t & (GB_NST - 1)) * GB_STAGE + GB_ABYTES;
+        const long k = (long)t * GB_K;
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
-            const int r0 = h * 128 + (2 * wave + c) * 8;
-            __builtin_amdgcn_global_load_lds((gbl_ptr_t)(bbase + (long)r0 * g.ldb + k), (lds_ptr_t)(st + r0 * BROW), 16, 0, 0);
+            const int r0 = (2 * wave + c) * 16;
+            __builtin_amdgcn_global_load_lds((gbl_ptr_t)(bbase + (long)r0 * g.ldb + k), (lds_ptr_t)(st + r0 * GB_ROW), 16, 0, 0);
         }
     };
-    const int nk = g.K / BBK;
+    const int nk = g.K / GB_K;
 
     f32x4_t acc[8][4];
 #pragma unroll
@@ -648,65 +648,58 @@ __global__ __launch_bounds__(512, 2) void cst_gemm_bf16_big_kernel(BGemmArgs g) 
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
     GbFrag f;
 
-    // fragment read addresses (buffer 0): row (wr * 128 + lr) resp. (wc * 64 + lr), slot (kh * 4 + lq) ^ (lr & 7); the row half and
-    // the row / column tile go into the instruction's offset field
+    // fragment read addresses (stage 0): row (wr * 128 + lr) resp. (wc * 64 + lr), slot lq ^ g((lr >> 2) & 3); the row half and the
+    // row / column tile go into the instruction's offset field (they are multiples of 16 rows: the swizzle key is unchanged)
     const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
-    unsigned a_ad[2], b_ad[2];
-#pragma unroll
-    for (int kh = 0; kh < 2; ++kh) {
-        a_ad[kh] = lds_base + (wr * 128 + lr) * BROW + (((kh * 4 + lq) ^ (lr & 7)) << 4);
-        b_ad[kh] = lds_base + GB_ABYTES + (wc * 64 + lr) * BROW + (((kh * 4 + lq) ^ (lr & 7)) << 4);
-    }
+    const int fsw = (0x1230 >> (4 * ((lr >> 2) & 3))) & 3;
+    const unsigned a_ad = lds_base + (wr * 128 + lr) * GB_ROW + ((lq ^ fsw) << 4);
+    const unsigned b_ad = lds_base + GB_ABYTES + (wc * 64 + lr) * GB_ROW + ((lq ^ fsw) << 4);
 
-    // prologue: all of tile 0 and the first two groups of tile 1; the first three groups must have landed
-    issue_a(0, 0); issue_b(0, 0); issue_b(0, 1); issue_a(0, 1);
-    if (nk > 1) { issue_a(1, 0); issue_b(1, 0); asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); }
-    else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    // prologue: tiles 0, 1, 2 in flight; tile 0 must have landed
+    issue_a(0); issue_b(0);
+    if (nk > 1) { issue_b(1); issue_a(1); }
+    if (nk > 2) { issue_b(2); issue_a(2); }
+    if (nk > 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (nk > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    gb_read_a<0, 0>(f, a_ad[0]);
-    gb_read_b<0>(f, b_ad[0]);
+    gb_read_a<0, 0>(f, a_ad);
+    gb_read_b<0>(f, b_ad);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
 
 #define GB_PHASE_END()                                      \
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      \
     __builtin_amdgcn_sched_barrier(0);
-    for (int t = 0; t < nk; ++t) {
-        const bool more = t + 1 < nk, more2 = t + 2 < nk;
-        const unsigned cur = (t & 1) * GB_STAGE, nxt = ((t + 1) & 1) * GB_STAGE;
-        // ---- P0 (kh 0, mh 0): A2nd(t) must have landed; younger in flight: A1st(t+1), B1st(t+1)
-        if (more) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        if (more) issue_b(t + 1, 1);                      // B2nd(t+1)
-        gb_read_a<1, 1>(f, a_ad[0] + cur);
-        gb_mfma<0, 0, 0>(f, acc);
-        GB_PHASE_END()
-        // ---- P1 (kh 0, mh 1)
-        __builtin_amdgcn_s_barrier();
-        if (more) issue_a(t + 1, 1);                      // A2nd(t+1)
-        gb_read_a<0, 0>(f, a_ad[1] + cur);
-        gb_read_b<1>(f, b_ad[1] + cur);
-        gb_mfma<1, 0, 1>(f, acc);
-        GB_PHASE_END()
-        // ---- P2 (kh 1, mh 0)
-        __builtin_amdgcn_s_barrier();
-        if (more2) issue_a(t + 2, 0);                     // A1st(t+2)
-        gb_read_a<1, 1>(f, a_ad[1] + cur);
-        gb_mfma<0, 1, 0>(f, acc);
-        GB_PHASE_END()
-        // ---- P3 (kh 1, mh 1): A1st, B1st, B2nd of tile t+1 must have landed; younger in flight: A2nd(t+1), A1st(t+2)
-        if (more2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");          // (nothing is outstanding on the last tile: a no-op there)
-        __builtin_amdgcn_s_barrier();
-        if (more2) issue_b(t + 2, 0);                     // B1st(t+2)
-        if (more) {
-            gb_read_a<0, 0>(f, a_ad[0] + nxt);
-            gb_read_b<0>(f, b_ad[0] + nxt);
-        }
-        gb_mfma<1, 1, 1>(f, acc);
-        GB_PHASE_END()
+    // one K-tile; SB = the B register set holding tile t (tile t+1 goes to the other one)
+#define GB_TILE(SB)                                                                                             \
+    {                                                                                                           \
+        const unsigned cur = (t & (GB_NST - 1)) * GB_STAGE, nxt = ((t + 1) & (GB_NST - 1)) * GB_STAGE;          \
+        if (t + 3 < nk) issue_b(t + 3);                                                                         \
+        gb_read_a<1, 1>(f, a_ad + cur);                                                                         \
+        gb_mfma<0, SB, 0>(f, acc);                                                                              \
+        GB_PHASE_END()                                                                                          \
+        if (t + 3 < nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");                                        \
+        else if (t + 2 < nk) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                                   \
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                   \
+        __builtin_amdgcn_s_barrier();                                                                           \
+        if (t + 3 < nk) issue_a(t + 3);                                                                         \
+        if (t + 1 < nk) {                                                                                       \
+            gb_read_a<0, 0>(f, a_ad + nxt);                                                                     \
+            gb_read_b<1 - SB>(f, b_ad + nxt);                                                                   \
+        }                                                                                                       \
+        gb_mfma<1, SB, 1>(f, acc);                                                                              \
+        GB_PHASE_END()                                                                                          \
     }
+    int t = 0;
+    for (; t + 1 < nk; t += 2) {
+        GB_TILE(0)
+        ++t;
+        GB_TILE(1)
+        --t;
+    }
+    if (t < nk) GB_TILE(0)
+#undef GB_TILE
 #undef GB_PHASE_END
     __syncthreads();                                  // every fragment read is done before the ring becomes C staging
 
@@ -742,11 +735,12 @@ __global__ __launch_bounds__(512, 2) void cst_gemm_bf16_big_kernel(BGemmArgs g) 
 }
 
 static bool bgemm_big_ok(const BGemmArgs& g) {
-    return g.M % GB_T == 0 && g.N % GB_T == 0 && g.K % BBK == 0 && g.splits == 1 && !g.slab_only && !g.A2;
+    return g.M % GB_T == 0 && g.N % GB_T == 0 && g.K % GB_K == 0 && g.splits == 1 && !g.slab_only && !g.A2;
 }
 
 static int bgemm_big_launch(const BGemmArgs& g, hipStream_t st) {
-    const size_t lds = 2 * GB_STAGE;
+    const size_t lds = GB_NST * GB_STAGE;
+    static const int gn = getenv("CST_GB_GN") ? atoi(getenv("CST_GB_GN")) : 2;        // tile columns per XCD strip (A/B panel sharing)
     static bool attr_done = false;
     if (!attr_done) {
         (void)hipFuncSetAttribute((const void*)cst_gemm_bf16_big_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -757,9 +751,9 @@ static int bgemm_big_launch(const BGemmArgs& g, hipStream_t st) {
         hipEvent_t ea, eb;
         (void)hipEventCreate(&ea); (void)hipEventCreate(&eb);
         cst_prof_push(ea, eb, 2.0 * g.M * g.N * g.K, 2.0 * ((double)g.M * g.K + (double)g.N * g.K) + (g.C ? 4.0 : 0.0) * g.M * g.N + (g.Cb ? 2.0 : 0.0) * g.M * g.N, 1);
-        hipExtLaunchKernelGGL(cst_gemm_bf16_big_kernel, grid, block, lds, st, ea, eb, 0, g);
+        hipExtLaunchKernelGGL(cst_gemm_bf16_big_kernel, grid, block, lds, st, ea, eb, 0, g, gn);
     } else {
-        hipLaunchKernelGGL(cst_gemm_bf16_big_kernel, grid, block, lds, st, g);
+        hipLaunchKernelGGL(cst_gemm_bf16_big_kernel, grid, block, lds, st, g, gn);
     }
     return 0;
 }
@@ -835,7 +829,7 @@ extern "C" int cst_gemm_bf16(const void* A, long lda, const void* B, long ldb,
     // 256 x 256 / 8-wave kernel: tile code 256 forces it; by itself it takes the products whose 256^2 tiles fill at least
     // half the chip and at most one round of it, or several rounds (measured rule, tools/gemm_bench.py bf16nt)
     {
-        static const int big_mode = getenv("CST_GEMM_BIG") ? atoi(getenv("CST_GEMM_BIG")) : 1;      // 0 never, 1 auto, 2 whenever legal
+        static const int big_mode = getenv("CST_GEMM_BIG") ? atoi(getenv("CST_GEMM_BIG")) : 0;      // 0 only on request, 1 auto, 2 whenever legal
         const long t256 = (long)(M / GB_T) * (N / GB_T);
         const bool want = tile == 256 || (tile == 0 && splitk <= 1 && big_mode == 2) ||
                           (tile == 0 && splitk <= 1 && big_mode == 1 && N >= 1024 && K >= 256 && t256 >= 128);

@@ -1,7 +1,8 @@
 """Dataset + collate functions (reference: src/loader.py), re-batched for data parallelism.
 
 `StyleDataset` tokenises and truncates every line at load (loader.py:19-26) -- here through one
-batched call into the tokenizer -- and can cache the token lists as a binary file next to the data.
+batched call into the tokenizer -- and can keep the result as a binary token cache next to the data
+(`--token_cache`; format: TokenCache below), so later runs and every data-parallel rank skip tokenisation.
 The collate functions return exactly the reference's tuples (CPU int64 / float32 tensors):
   collate_pretrain -> (x, nx_1, nx_2, nx_3, label, c_label)      loader.py:46-70
   collate_warmup   -> (nx, x, label)                             loader.py:72-82
@@ -15,9 +16,10 @@ Data parallelism: `GlobalBatchSampler` + a collate function build the GLOBAL bat
 from the same seed (the noise functions mix tokens across the whole batch, so noise is applied
 before sharding), pad to the global maximum length, and `parallel.shard_batch` takes this rank's rows.
 """
+import json
 import os
-import pickle
 import random
+import struct
 
 import numpy as np
 import torch
@@ -25,6 +27,62 @@ from torch.utils.data import Dataset
 
 from .data_util import align, pth_tensor, rand_perm, transfer_noise
 from .vocab import BOS_ID, EOS_ID, PAD_ID, BPETokenizer  # noqa: F401
+
+
+class TokenCache:
+    """Binary token cache of one data file, `<file>.tok<max_len>.cstt`:
+
+        bytes 0-7    magic  b"CSTTOK1\0"
+        int64        n            number of sentences (empty lines already dropped, loader.py:37-39)
+        int64        max_len      truncation applied (loader.py:25-26)
+        int64        vocab_size   len(vocab) the ids were produced with (a different tokenizer invalidates the cache)
+        int32[n]     label        from the file suffix (loader.py:36)
+        int64[n+1]   offset       sentence i = tokens[offset[i] : offset[i+1]]
+        int32[...]   tokens       BPE ids, already truncated to max_len
+
+    Little endian, no padding.  Valid while its mtime is not older than the text file's."""
+    MAGIC = b"CSTTOK1\0"
+
+    @staticmethod
+    def path(file, max_len):
+        return f"{file}.tok{max_len}.cstt"
+
+    @classmethod
+    def write(cls, path, samples, max_len, vocab_size):
+        lab = np.array([l for _, l in samples], dtype="<i4")
+        off = np.zeros(len(samples) + 1, dtype="<i8")
+        np.cumsum([len(t) for t, _ in samples], out=off[1:])
+        tok = np.fromiter((i for t, _ in samples for i in t), dtype="<i4", count=int(off[-1]))
+        tmp = f"{path}.tmp{os.getpid()}"
+        with open(tmp, "wb") as f:
+            f.write(cls.MAGIC)
+            f.write(struct.pack("<qqq", len(samples), max_len, vocab_size))
+            f.write(lab.tobytes())
+            f.write(off.tobytes())
+            f.write(tok.tobytes())
+        os.replace(tmp, path)                              # atomic: ranks racing to write the same cache never see half a file
+
+    @classmethod
+    def read(cls, path, max_len, vocab_size):
+        """-> list of (token list, label), or None when the file is missing / for another max_len or vocabulary."""
+        try:
+            with open(path, "rb") as f:
+                blob = f.read()
+        except OSError:
+            return None
+        if blob[:8] != cls.MAGIC or len(blob) < 32:
+            return None
+        n, ml, vs = struct.unpack_from("<qqq", blob, 8)
+        if ml != max_len or vs != vocab_size:
+            return None
+        p = 32
+        lab = np.frombuffer(blob, dtype="<i4", count=n, offset=p)
+        p += 4 * n
+        off = np.frombuffer(blob, dtype="<i8", count=n + 1, offset=p)
+        p += 8 * (n + 1)
+        tok = np.frombuffer(blob, dtype="<i4", count=int(off[-1]), offset=p)
+        tl = tok.tolist()
+        return [(tl[off[i]:off[i + 1]], int(lab[i])) for i in range(n)]
 
 
 class StyleDataset(Dataset):
@@ -40,16 +98,16 @@ class StyleDataset(Dataset):
     def _load(self):
         samples = []
         for file in self.files:
-            cpath = f"{file}.tok{self.max_len}.pkl"
+            cpath = TokenCache.path(file, self.max_len)
             if self.cache and os.path.exists(cpath) and os.path.getmtime(cpath) >= os.path.getmtime(file):
-                with open(cpath, "rb") as f:
-                    samples += pickle.load(f)
-                continue
+                part = TokenCache.read(cpath, self.max_len, len(self.vocab))
+                if part is not None:
+                    samples += part
+                    continue
             part = self.load_func(file, self.truncate, self.vocab, self.max_len) if self.load_func is load_s2l \
                 else self.load_func(file, self.truncate)
             if self.cache:
-                with open(cpath, "wb") as f:
-                    pickle.dump(part, f)
+                TokenCache.write(cpath, part, self.max_len, len(self.vocab))
             samples += part
         return samples
 
@@ -84,11 +142,60 @@ def overlap_distance_label(noised_1, noised_2, vocab=None):
     return out
 
 
-def collate_pretrain(vocab, w2v=None, label_fn=None):
-    if label_fn is None:
-        label_fn = w2v.cal_wmd_label if w2v is not None else overlap_distance_label
+class LabelCache:
+    """Content-distance labels of a SEEDED pretrain run, `--label_cache <file>` (numpy .npz container):
 
-    def collate_func(batch_samples):
+        meta            JSON string: {"format": "CSTLBL1", "seed", "global_batch", "n_sentences", "noise_p", "label_fn"}
+        e<epoch>_b<bi>  float32 [rows of that global batch]    for every batch the producing run saw
+
+    Every batch of a run is seeded by (seed, epoch, batch index) (iterate_batches), so the noised sentences -- hence their
+    labels -- are reproducible: `tools/make_label_cache.py` replays the sampler + noise of a run and stores what
+    `label_fn` (the WMD of wmd.py) returns; training then reads the labels back instead of solving 256 transportation
+    problems per batch on the training thread.  A missing key, or a cache made for another seed / batch size / corpus,
+    raises: silently training the Matcher on stale targets would be worse than stopping."""
+
+    def __init__(self, path=None, meta=None):
+        self.tables, self.meta, self.path = {}, dict(meta or {}), path
+        if path is not None and os.path.exists(path):
+            z = np.load(path, allow_pickle=False)
+            self.meta = json.loads(str(z["meta"]))
+            if self.meta.get("format") != "CSTLBL1":
+                raise ValueError(f"{path}: not a CSTLBL1 label cache")
+            self.tables = {k: z[k] for k in z.files if k != "meta"}
+
+    def check(self, seed, global_batch, n_sentences):
+        want = {"seed": seed, "global_batch": global_batch, "n_sentences": n_sentences}
+        bad = {k: (self.meta.get(k), v) for k, v in want.items() if self.meta.get(k) != v}
+        if bad:
+            raise ValueError(f"label cache {self.path} was made for another run (cache value, this run): {bad}")
+
+    @staticmethod
+    def key(epoch, bi):
+        return f"e{epoch}_b{bi}"
+
+    def put(self, epoch, bi, labels):
+        self.tables[self.key(epoch, bi)] = np.asarray(labels, dtype=np.float32)
+
+    def get(self, epoch, bi, rows):
+        t = self.tables.get(self.key(epoch, bi))
+        if t is None or len(t) != rows:
+            raise KeyError(f"label cache {self.path}: no labels for epoch {epoch} batch {bi} with {rows} rows")
+        return t.tolist()
+
+    def save(self, path=None):
+        meta = dict(self.meta, format="CSTLBL1")
+        np.savez_compressed(path or self.path, meta=np.array(json.dumps(meta)), **self.tables)
+
+
+class PretrainCollate:
+    """loader.py:46-70 as a picklable callable (PrefetchBatches ships it to worker processes).  `position` = (epoch, batch
+    index) of the batch being built; iterate_batches / the prefetch workers set it, the label cache reads it."""
+
+    def __init__(self, vocab, label_fn, label_cache=None):
+        self.vocab, self.label_fn, self.label_cache = vocab, label_fn, label_cache
+        self.position = (0, 0)
+
+    def __call__(self, batch_samples):
         sentences, labels = zip(*batch_samples)
         noised_1 = transfer_noise(sentences, p=0.15)
         noised_2 = transfer_noise(sentences, p=0.15)
@@ -97,10 +204,20 @@ def collate_pretrain(vocab, w2v=None, label_fn=None):
         nx_1, _, _ = align(noised_1, PAD_ID)
         nx_2, _, _ = align(noised_2, PAD_ID)
         nx_3, _, _ = align(noised_3, PAD_ID)
-        c_label = label_fn(noised_1, noised_2, vocab)
+        if self.label_cache is not None:
+            c_label = self.label_cache.get(*self.position, len(sentences))
+        else:
+            c_label = self.label_fn(noised_1, noised_2, self.vocab)
         return (pth_tensor(x, torch.long), pth_tensor(nx_1, torch.long), pth_tensor(nx_2, torch.long),
                 pth_tensor(nx_3, torch.long), pth_tensor(labels, torch.long), pth_tensor(c_label, torch.float))
-    return collate_func
+
+
+def collate_pretrain(vocab, w2v=None, label_fn=None, label_cache=None):
+    """`w2v`: an object with the reference's `cal_wmd_label(xs1, xs2, tokenizer)` (wmd.WMDdistance); `label_fn`: any
+    function of (noised_1, noised_2, vocab); `label_cache` (a LabelCache): labels are read from it instead of computed."""
+    if label_fn is None:
+        label_fn = w2v.cal_wmd_label if w2v is not None else overlap_distance_label
+    return PretrainCollate(vocab, label_fn, label_cache)
 
 
 def collate_warmup(batch_samples):
@@ -142,11 +259,65 @@ class GlobalBatchSampler:
         return (self.n + self.bs - 1) // self.bs
 
 
+def _build_batch(dataset, collate, idx, seed, epoch, bi):
+    s = (seed + 7919 * epoch + bi) % (2 ** 31 - 1)
+    np.random.seed(s)
+    random.seed(s)
+    if hasattr(collate, "position"):
+        collate.position = (epoch, bi)
+    return collate([dataset[i] for i in idx])
+
+
 def iterate_batches(dataset, sampler, collate, seed=0):
     """Yields (batch_idx, collated global batch).  Seeds numpy/random per batch so that every rank
     draws the same noise for the same global batch."""
     for bi, idx in enumerate(sampler):
-        s = (seed + 7919 * sampler.epoch + bi) % (2 ** 31 - 1)
-        np.random.seed(s)
-        random.seed(s)
-        yield bi, collate([dataset[i] for i in idx])
+        yield bi, _build_batch(dataset, collate, idx, seed, sampler.epoch, bi)
+
+
+_PF = {}
+
+
+def _pf_init(dataset, collate):
+    _PF["dataset"], _PF["collate"] = dataset, collate
+    torch.set_num_threads(1)
+
+
+def _pf_work(job):
+    idx, seed, epoch, bi = job
+    return bi, _build_batch(_PF["dataset"], _PF["collate"], idx, seed, epoch, bi)
+
+
+class PrefetchBatches:
+    """iterate_batches with the batch construction (token noise, padding, and for pretrain the content-distance labels
+    -- the reference's host hot spot, loader.py:60) moved to `workers` forked processes that run `depth` batches ahead of
+    the consumer.  Same batches, same order, bit for bit: a batch depends only on (dataset, indices, seed, epoch, batch
+    index).  The workers never touch the GPU (numpy / Python / scipy on CPU tensors only); forking a process that has
+    initialised HIP is not safe, so the pool uses the 'spawn' start method and receives the dataset once at start-up."""
+
+    def __init__(self, dataset, sampler, collate, seed=0, workers=4, depth=8):
+        self.dataset, self.sampler, self.collate, self.seed = dataset, sampler, collate, seed
+        self.workers, self.depth = max(1, workers), max(1, depth)
+        self.pool = None
+
+    def _pool(self):
+        if self.pool is None:
+            import multiprocessing as mp
+            self.pool = mp.get_context("spawn").Pool(self.workers, initializer=_pf_init, initargs=(self.dataset, self.collate))
+        return self.pool
+
+    def __iter__(self):
+        pool = self._pool()
+        jobs = ((idx, self.seed, self.sampler.epoch, bi) for bi, idx in enumerate(self.sampler))
+        pending = []
+        for job in jobs:
+            pending.append(pool.apply_async(_pf_work, (job,)))
+            if len(pending) >= self.depth:
+                yield pending.pop(0).get()
+        while pending:
+            yield pending.pop(0).get()
+
+    def close(self):
+        if self.pool is not None:
+            self.pool.terminate()
+            self.pool = None

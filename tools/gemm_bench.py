@@ -72,7 +72,7 @@ def main_bf16(shapes=None, out_bf16=False):
         C = torch.empty(M, N, device="cuda") if not out_bf16 else None
         Cb = torch.empty(M, (N + 63) // 64 * 64, device="cuda", dtype=torch.int16) if out_bf16 else None
         res = []
-        tiles = [0, 64, 65, 128, 129, 130, 256]
+        tiles = [int(x) for x in os.environ.get("CST_BENCH_TILES", "0,64,65,128,129,130,256").split(",")]
         for tile in tiles:
             for _ in range(3):
                 ops.gemm_bf16(Ab, Bb, M, N, C=C, Cb=Cb, tile=tile)
