@@ -51,6 +51,8 @@ def build_parser():
                         help="keep / reuse the binary token cache next to each data file (loader.TokenCache)")
     parser.add_argument('--label_cache', type=str, default=None,
                         help="pretrain: file of precomputed content-distance labels (loader.LabelCache format)")
+    parser.add_argument('--prefetch_workers', type=int, default=0,
+                        help="build batches (token noise, padding, WMD labels) in this many worker processes ahead of the GPU")
     return parser
 
 

@@ -594,9 +594,19 @@ __device__ __forceinline__ void gb_mfma(const GbFrag& f, f32x4_t (&acc)[8][4]) {
     __builtin_amdgcn_s_setprio(0);
 }
 
-__global__ __launch_bounds__(512, 2) void cst_gemm_bf16_big_kernel(BGemmArgs g, int gn) {
+// WR = wave rows: 2 -> 256 x 256 tile, 8 waves, one workgroup per CU (NST = 4 stages of 32 KiB);
+//                 1 -> 128 x 256 tile, 4 waves, TWO workgroups per CU (NST = 3 stages of 24 KiB): the two run out of phase, so one's
+//                      prologue / C write-out (32-75 MB of fp32 per launch, the largest HBM stream of these products) overlaps the
+//                      other's K-loop -- at 256 x 256 every CU computes, then every CU writes.
+template <int WR, int NST>
+__global__ __launch_bounds__(256 * WR, 2) void cst_gemm_bf16_big_kernel(BGemmArgs g, int gn) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tilesM = g.M / GB_T, tilesN = g.N / GB_T;
+    constexpr int BM = 128 * WR, NW = 4 * WR;
+    constexpr int A_BYTES = BM * GB_ROW, B_BYTES = GB_T * GB_ROW, STAGE = A_BYTES + B_BYTES;
+    constexpr int PA = BM / 16 / NW, PB = GB_T / 16 / NW;      // DMA pieces (16 rows) per wave per K-tile
+    constexpr int D = NST - 1;                                  // prefetch distance in K-tiles
+    static_assert(D == 2 || D == 3, "wait counts below are written out for prefetch distances 2 and 3");
+    const int tilesM = g.M / BM, tilesN = g.N / GB_T;
     int id;
     {
         const int nblk = gridDim.x, q = nblk >> 3, r = nblk & 7, xcd = blockIdx.x & 7;
@@ -607,7 +617,7 @@ __global__ __launch_bounds__(512, 2) void cst_gemm_bf16_big_kernel(BGemmArgs g, 
     const int gw = min(gn, tilesN - grp * gn);
     const int local = id - grp * gn * tilesM;
     const int tm = local / gw, tn = grp * gn + local % gw;
-    const int m0 = tm * GB_T, n0 = tn * GB_T;
+    const int m0 = tm * BM, n0 = tn * GB_T;
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -620,22 +630,21 @@ __global__ __launch_bounds__(512, 2) void cst_gemm_bf16_big_kernel(BGemmArgs g, 
     const int src_slot = (lane & 3) ^ gsw;
     const bf16_t* abase = g.A + (long)(m0 + (lane >> 2)) * g.lda + (src_slot << 3);
     const bf16_t* bbase = g.B + (long)(n0 + (lane >> 2)) * g.ldb + (src_slot << 3);
-    // this wave moves pieces 2 wave, 2 wave + 1 of an operand's 16: rows 32 wave .. 32 wave + 31
     auto issue_a = [&](int t) {
-        char* st = smem + (t & (GB_NST - 1)) * GB_STAGE;
+        char* st = smem + (t % NST) * STAGE;
         const long k = (long)t * GB_K;
 #pragma unroll
-        for (int c = 0; c < 2; ++c) {
-            const int r0 = (2 * wave + c) * 16;
+        for (int c = 0; c < PA; ++c) {
+            const int r0 = (PA * wave + c) * 16;
             __builtin_amdgcn_global_load_lds((gbl_ptr_t)(abase + (long)r0 * g.lda + k), (lds_ptr_t)(st + r0 * GB_ROW), 16, 0, 0);
         }
     };
     auto issue_b = [&](int t) {
-        char* st = smem + (t & (GB_NST - 1)) * GB_STAGE + GB_ABYTES;
+        char* st = smem + (t % NST) * STAGE + A_BYTES;
         const long k = (long)t * GB_K;
 #pragma unroll
-        for (int c = 0; c < 2; ++c) {
-            const int r0 = (2 * wave + c) * 16;
+        for (int c = 0; c < PB; ++c) {
+            const int r0 = (PB * wave + c) * 16;
             __builtin_amdgcn_global_load_lds((gbl_ptr_t)(bbase + (long)r0 * g.ldb + k), (lds_ptr_t)(st + r0 * GB_ROW), 16, 0, 0);
         }
     };
@@ -653,15 +662,18 @@ __global__ __launch_bounds__(512, 2) void cst_gemm_bf16_big_kernel(BGemmArgs g, 
     const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
     const int fsw = (0x1230 >> (4 * ((lr >> 2) & 3))) & 3;
     const unsigned a_ad = lds_base + (wr * 128 + lr) * GB_ROW + ((lq ^ fsw) << 4);
-    const unsigned b_ad = lds_base + GB_ABYTES + (wc * 64 + lr) * GB_ROW + ((lq ^ fsw) << 4);
+    const unsigned b_ad = lds_base + A_BYTES + (wc * 64 + lr) * GB_ROW + ((lq ^ fsw) << 4);
 
-    // prologue: tiles 0, 1, 2 in flight; tile 0 must have landed
+    // prologue: tiles 0 .. D-1 in flight; tile 0 must have landed
     issue_a(0); issue_b(0);
     if (nk > 1) { issue_b(1); issue_a(1); }
-    if (nk > 2) { issue_b(2); issue_a(2); }
-    if (nk > 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else if (nk > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (D > 2 && nk > 2) { issue_b(2); issue_a(2); }
+    {
+        const int younger = min(nk, D) - 1;                // whole tiles issued after tile 0
+        if (younger >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (PA + PB)) : "memory");
+        else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PA + PB) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     __builtin_amdgcn_s_barrier();
     gb_read_a<0, 0>(f, a_ad);
     gb_read_b<0>(f, b_ad);
@@ -671,19 +683,27 @@ __global__ __launch_bounds__(512, 2) void cst_gemm_bf16_big_kernel(BGemmArgs g, 
 #define GB_PHASE_END()                                      \
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      \
     __builtin_amdgcn_sched_barrier(0);
+    // P1's wait: tile t+1 has landed; younger pieces of this wave still in flight: the whole tiles t+2 .. t+D-1 and B(t+D)
+#define GB_WAIT_NEXT()                                                                                          \
+    if constexpr (D == 3) {                                                                                     \
+        if (t + 3 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PA + 2 * PB) : "memory");                      \
+        else if (t + 2 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PA + PB) : "memory");                     \
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                   \
+    } else {                                                                                                    \
+        if (t + 2 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PB) : "memory");                               \
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                   \
+    }
     // one K-tile; SB = the B register set holding tile t (tile t+1 goes to the other one)
 #define GB_TILE(SB)                                                                                             \
     {                                                                                                           \
-        const unsigned cur = (t & (GB_NST - 1)) * GB_STAGE, nxt = ((t + 1) & (GB_NST - 1)) * GB_STAGE;          \
-        if (t + 3 < nk) issue_b(t + 3);                                                                         \
+        const unsigned cur = (t % NST) * STAGE, nxt = ((t + 1) % NST) * STAGE;                                  \
+        if (t + D < nk) issue_b(t + D);                                                                         \
         gb_read_a<1, 1>(f, a_ad + cur);                                                                         \
         gb_mfma<0, SB, 0>(f, acc);                                                                              \
         GB_PHASE_END()                                                                                          \
-        if (t + 3 < nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");                                        \
-        else if (t + 2 < nk) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                                   \
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                   \
+        GB_WAIT_NEXT()                                                                                          \
         __builtin_amdgcn_s_barrier();                                                                           \
-        if (t + 3 < nk) issue_a(t + 3);                                                                         \
+        if (t + D < nk) issue_a(t + D);                                                                         \
         if (t + 1 < nk) {                                                                                       \
             gb_read_a<0, 0>(f, a_ad + nxt);                                                                     \
             gb_read_b<1 - SB>(f, b_ad + nxt);                                                                   \
@@ -700,12 +720,14 @@ __global__ __launch_bounds__(512, 2) void cst_gemm_bf16_big_kernel(BGemmArgs g, 
     }
     if (t < nk) GB_TILE(0)
 #undef GB_TILE
+#undef GB_WAIT_NEXT
 #undef GB_PHASE_END
     __syncthreads();                                  // every fragment read is done before the ring becomes C staging
 
-    // epilogue: the wave tile's two 64 x 64 halves through LDS (8 x 16 KiB), whole 256-byte row segments per store
+    // epilogue: the wave tile's two 64 x 64 halves through LDS (16 KiB per wave), whole 256-byte row segments per store
     const uint32_t dseed = g.drop.p > 0.f ? cst_drop_seed(g.drop) : 0u;
     constexpr int CLD = 64, C4 = 16;
+    static_assert(NW * 64 * CLD * 4 <= NST * STAGE, "C staging must fit the ring");
     float* Cs = reinterpret_cast<float*>(smem) + wave * 64 * CLD;
     const bool vec = bgemm_vec_ok(g);
 #pragma unroll
@@ -734,26 +756,27 @@ __global__ __launch_bounds__(512, 2) void cst_gemm_bf16_big_kernel(BGemmArgs g, 
     }
 }
 
-static bool bgemm_big_ok(const BGemmArgs& g) {
-    return g.M % GB_T == 0 && g.N % GB_T == 0 && g.K % GB_K == 0 && g.splits == 1 && !g.slab_only && !g.A2;
+static bool bgemm_big_ok(const BGemmArgs& g, int wr) {
+    return g.M % (128 * wr) == 0 && g.N % GB_T == 0 && g.K % GB_K == 0 && g.splits == 1 && !g.slab_only && !g.A2;
 }
 
-static int bgemm_big_launch(const BGemmArgs& g, hipStream_t st) {
-    const size_t lds = GB_NST * GB_STAGE;
+template <int WR, int NST>
+static int bgemm_big_launch_t(const BGemmArgs& g, hipStream_t st) {
+    const size_t lds = (size_t)NST * (128 * WR + GB_T) * GB_ROW;
     static const int gn = getenv("CST_GB_GN") ? atoi(getenv("CST_GB_GN")) : 2;        // tile columns per XCD strip (A/B panel sharing)
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)cst_gemm_bf16_big_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)cst_gemm_bf16_big_kernel<WR, NST>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_done = true;
     }
-    dim3 grid((g.M / GB_T) * (g.N / GB_T), 1, 1), block(512);
+    dim3 grid((g.M / (128 * WR)) * (g.N / GB_T), 1, 1), block(256 * WR);
     if (cst_prof_on()) {
         hipEvent_t ea, eb;
         (void)hipEventCreate(&ea); (void)hipEventCreate(&eb);
         cst_prof_push(ea, eb, 2.0 * g.M * g.N * g.K, 2.0 * ((double)g.M * g.K + (double)g.N * g.K) + (g.C ? 4.0 : 0.0) * g.M * g.N + (g.Cb ? 2.0 : 0.0) * g.M * g.N, 1);
-        hipExtLaunchKernelGGL(cst_gemm_bf16_big_kernel, grid, block, lds, st, ea, eb, 0, g, gn);
+        hipExtLaunchKernelGGL((cst_gemm_bf16_big_kernel<WR, NST>), grid, block, lds, st, ea, eb, 0, g, gn);
     } else {
-        hipLaunchKernelGGL(cst_gemm_bf16_big_kernel, grid, block, lds, st, g, gn);
+        hipLaunchKernelGGL((cst_gemm_bf16_big_kernel<WR, NST>), grid, block, lds, st, g, gn);
     }
     return 0;
 }
@@ -830,15 +853,18 @@ extern "C" int cst_gemm_bf16(const void* A, long lda, const void* B, long ldb,
     // half the chip and at most one round of it, or several rounds (measured rule, tools/gemm_bench.py bf16nt)
     {
         static const int big_mode = getenv("CST_GEMM_BIG") ? atoi(getenv("CST_GEMM_BIG")) : 0;      // 0 only on request, 1 auto, 2 whenever legal
+        // tile code 256: 256 x 256 / 8 waves; 252 (= 256 - 4, ring bits clear): 128 x 256 / 4 waves, two workgroups per CU
         const long t256 = (long)(M / GB_T) * (N / GB_T);
-        const bool want = tile == 256 || (tile == 0 && splitk <= 1 && big_mode == 2) ||
+        const bool want = tile == 256 || tile == 252 || (tile == 0 && splitk <= 1 && big_mode == 2) ||
                           (tile == 0 && splitk <= 1 && big_mode == 1 && N >= 1024 && K >= 256 && t256 >= 128);
-        if (want && splits == 1 && bgemm_big_ok(g)) {
-            bgemm_big_launch(g, st);
-            CST_LAUNCH_CHECK("cst_gemm_bf16 (256x256)");
+        const int wr = tile == 256 ? 2 : 1;
+        if (want && splits == 1 && bgemm_big_ok(g, wr)) {
+            if (wr == 2) bgemm_big_launch_t<2, 4>(g, st);
+            else bgemm_big_launch_t<1, 3>(g, st);
+            CST_LAUNCH_CHECK("cst_gemm_bf16 (256-wide tiles)");
             return CST_OK;
         }
-        if (tile == 256) { tile = 0; }
+        if (tile == 256 || tile == 252) { tile = 0; }
     }
     if (ring == 0 && getenv("CST_RING4") && !use_big && tiles * splits <= 256 && g.k_per_split >= 256) ring = 2;
     if (use_big) { if (ring == 1) bgemm_launch<128, 128, 3>(g, st); else bgemm_launch<128, 128, 2>(g, st); }

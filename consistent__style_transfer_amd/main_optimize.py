@@ -14,7 +14,7 @@ import torch
 
 from . import ops
 from .arguments import apply_model_constants, fetch_args
-from .loader import GlobalBatchSampler, StyleDataset, collate_optimize, iterate_batches, load_s2l
+from .loader import StyleDataset, collate_optimize, load_s2l
 from .stages import OptimizeStage
 from .trainer import StepCache, Trainer
 from .vocab import BPETokenizer
@@ -64,22 +64,59 @@ class OptimizeAdapter(OptimizeStage):
 
     @torch.no_grad()
     def write_transfers(self, trainer, dataset, split):
+        """main_optimize.py:157-174 as a bulk path: every rank greedy-decodes its rows of each global batch and writes them,
+        tagged with the sentence's position in the data set, to a part file; rank 0 then merges the parts in data-set order
+        into `style.<split>.{0,1}.tsf` (routed by the SOURCE label).  Nothing is dropped: the last batch is padded to a
+        multiple of the world size by repeating its last sentence and the repeats are not written.  Runs in exact-fp32
+        mode unless --precision was given (main()): the greedy ids are then the ones pinned bit for bit against the
+        reference (tests/golden gen.greedy.ids)."""
         self.eval()
-        out_dir = self.hparams.out_dir
-        if trainer.rank == 0:
+        out_dir, world, rank = self.hparams.out_dir, trainer.world, trainer.rank
+        if rank == 0:
             print(f"Writing outputs to {out_dir}/")
-        sampler = GlobalBatchSampler(len(dataset), self.hparams.batch_size, shuffle=False)
-        with open(f"{out_dir}/style.{split}.0.tsf", "w+", encoding="utf-8") as f0, \
-                open(f"{out_dir}/style.{split}.1.tsf", "w+", encoding="utf-8") as f1:
-            for _, (x, labels) in iterate_batches(dataset, sampler, collate_optimize):
-                ids = self.transfer((x.to(trainer.device), labels.to(trainer.device))).cpu().tolist()
-                for tsf, label in zip(ids, labels.tolist()):
-                    (f0 if label == 0 else f1).write(self.vocab.decode(tsf) + "\n")
+        n, bs = len(dataset), self.hparams.batch_size
+        part = f"{out_dir}/style.{split}.part{rank}"
+        with open(part, "w", encoding="utf-8") as fp:
+            for s in range(0, n, bs):
+                idx = list(range(s, min(n, s + bs)))
+                real = len(idx)
+                while len(idx) % world:
+                    idx.append(idx[-1])
+                x, labels = collate_optimize([dataset[i] for i in idx])
+                per = len(idx) // world
+                lo = rank * per
+                xs, ls = x[lo:lo + per].to(trainer.device), labels[lo:lo + per].to(trainer.device)
+                ids = self.transfer((xs, ls)).cpu().tolist()
+                for j, (tsf, label) in enumerate(zip(ids, ls.tolist())):
+                    if lo + j < real:
+                        fp.write(f"{idx[lo + j]}\t{label}\t{self.vocab.decode(tsf)}\n")
+        if world > 1:
+            torch.distributed.barrier()
+        if rank == 0:
+            rows = []
+            for r in range(world):
+                with open(f"{out_dir}/style.{split}.part{r}", encoding="utf-8") as fp:
+                    for line in fp:
+                        i, label, text = line.rstrip("\n").split("\t", 2)
+                        rows.append((int(i), int(label), text))
+                os.remove(f"{out_dir}/style.{split}.part{r}")
+            rows.sort()
+            assert [i for i, _, _ in rows] == list(range(n)), "transfer writer: missing or duplicated sentences"
+            with open(f"{out_dir}/style.{split}.0.tsf", "w+", encoding="utf-8") as f0, \
+                    open(f"{out_dir}/style.{split}.1.tsf", "w+", encoding="utf-8") as f1:
+                for _, label, text in rows:
+                    (f0 if label == 0 else f1).write(text + "\n")
+        if world > 1:
+            torch.distributed.barrier()
 
 
 def main(argv=None):
+    import sys
+    raw = sys.argv[1:] if argv is None else list(argv)
     args = fetch_args(argv)
     apply_model_constants(args)
+    if args.mode == "test" and not any(a.startswith("--precision") for a in raw):
+        args.precision = "f32"                                # bulk transfer: the bit-exact-ids mode unless told otherwise
     ops.set_precision(args.precision)
     torch.manual_seed(args.seed)                              # identical random-init weights on every rank (then broadcast anyway)
     os.makedirs(f"{args.dump_dir}/{args.dataset}/{STAGE}-{args.ver}", exist_ok=True)
@@ -97,12 +134,12 @@ def main(argv=None):
         stage.setup_optim()
         trainer.sync_replicas(stage)
         stage._steps = StepCache(trainer.use_graph, [stage], trainer.reducer)
-        train_ds = StyleDataset([f"{data_dir}/style.train.0", f"{data_dir}/style.train.1"], vocab, args.max_len, load_s2l)
-        val_ds = StyleDataset([f"{data_dir}/style.dev.0", f"{data_dir}/style.dev.1"], vocab, args.max_len, load_s2l)
+        train_ds = StyleDataset([f"{data_dir}/style.train.0", f"{data_dir}/style.train.1"], vocab, args.max_len, load_s2l, cache=args.token_cache)
+        val_ds = StyleDataset([f"{data_dir}/style.dev.0", f"{data_dir}/style.dev.1"], vocab, args.max_len, load_s2l, cache=args.token_cache)
         trainer.fit(stage, train_ds, val_ds, collate_optimize, args.batch_size)
     elif args.mode == "test":
         for split in ("train", "test"):
-            ds = StyleDataset([f"{data_dir}/style.{split}.0", f"{data_dir}/style.{split}.1"], vocab, args.max_len, load_s2l)
+            ds = StyleDataset([f"{data_dir}/style.{split}.0", f"{data_dir}/style.{split}.1"], vocab, args.max_len, load_s2l, cache=args.token_cache)
             stage.write_transfers(trainer, ds, split)
     return stage
 

@@ -14,7 +14,7 @@ import torch
 
 from . import ops
 from .arguments import apply_model_constants, fetch_args
-from .loader import StyleDataset, collate_pretrain, load_s2l
+from .loader import LabelCache, StyleDataset, collate_pretrain, load_s2l
 from .stages import PretrainStage
 from .trainer import StepCache, Trainer
 from .vocab import BPETokenizer
@@ -75,9 +75,23 @@ def main(argv=None, label_fn=None):
     trainer.sync_replicas(stage)
     stage._steps = StepCache(trainer.use_graph, [stage], trainer.reducer)
     data_dir = f"{args.data_dir}/{args.dataset}"
-    train_ds = StyleDataset([f"{data_dir}/style.train.0", f"{data_dir}/style.train.1"], vocab, args.max_len, load_s2l)
-    val_ds = StyleDataset([f"{data_dir}/style.dev.0", f"{data_dir}/style.dev.1"], vocab, args.max_len, load_s2l)
-    trainer.fit(stage, train_ds, val_ds, collate_pretrain(vocab, label_fn=label_fn), args.batch_size)
+    train_ds = StyleDataset([f"{data_dir}/style.train.0", f"{data_dir}/style.train.1"], vocab, args.max_len, load_s2l, cache=args.token_cache)
+    val_ds = StyleDataset([f"{data_dir}/style.dev.0", f"{data_dir}/style.dev.1"], vocab, args.max_len, load_s2l, cache=args.token_cache)
+    # content-distance labels (main_pretrain.py:29-30 loads `<ds>-w2v.bin` with gensim): word vectors in this build's container
+    # format `<ds>-w2v.npz` (wmd.py), an explicit label_fn, or -- with neither -- the documented stand-in.  A label cache of a
+    # seeded run replaces the per-batch transportation solves altogether.
+    w2v = None
+    w2v_path = f"{args.dump_dir}/{args.dataset}/{args.dataset}-w2v.npz"
+    if label_fn is None and os.path.exists(w2v_path):
+        from .wmd import WMDdistance
+        w2v = WMDdistance.load(w2v_path)
+    elif label_fn is None and trainer.rank == 0:
+        print(f"[pretrain] {w2v_path} not found: Matcher labels fall back to loader.overlap_distance_label (NOT the reference's WMD)", flush=True)
+    cache = None
+    if args.label_cache:
+        cache = LabelCache(args.label_cache)
+        cache.check(args.seed, args.batch_size, len(train_ds))
+    trainer.fit(stage, train_ds, val_ds, collate_pretrain(vocab, w2v=w2v, label_fn=label_fn, label_cache=cache), args.batch_size)
     return stage
 
 

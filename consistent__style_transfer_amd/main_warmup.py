@@ -67,8 +67,8 @@ def main(argv=None):
     trainer.sync_replicas(stage)
     stage._steps = StepCache(trainer.use_graph, [stage], trainer.reducer)
     data_dir = f"{args.data_dir}/{args.dataset}"
-    train_ds = StyleDataset([f"{data_dir}/style.train.0", f"{data_dir}/style.train.1"], vocab, args.max_len, load_s2l)
-    val_ds = StyleDataset([f"{data_dir}/style.dev.0", f"{data_dir}/style.dev.1"], vocab, args.max_len, load_s2l)
+    train_ds = StyleDataset([f"{data_dir}/style.train.0", f"{data_dir}/style.train.1"], vocab, args.max_len, load_s2l, cache=args.token_cache)
+    val_ds = StyleDataset([f"{data_dir}/style.dev.0", f"{data_dir}/style.dev.1"], vocab, args.max_len, load_s2l, cache=args.token_cache)
     trainer.fit(stage, train_ds, val_ds, collate_warmup, args.batch_size)
     return stage
 

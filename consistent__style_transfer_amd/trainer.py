@@ -26,7 +26,7 @@ import time
 import torch
 
 from .graphs import GraphedStep
-from .loader import GlobalBatchSampler, iterate_batches
+from .loader import GlobalBatchSampler, PrefetchBatches, iterate_batches
 from .parallel import GradReducer, broadcast_tensors, check_replicas, init_distributed, shard_batch
 
 
@@ -137,10 +137,12 @@ class Trainer:
         validate(limit=self.sanity_batches)                     # sanity check, side effects included
         t_last, n_last = time.time(), 0
         done = False
+        workers = int(getattr(args, "prefetch_workers", 0) or 0)
+        prefetch = PrefetchBatches(train_ds, train_sampler, collate, seed=args.seed, workers=workers) if workers > 0 else None
         for epoch in range(args.epochs):
             self.current_epoch = epoch
             train_sampler.set_epoch(epoch)
-            for bi, batch in iterate_batches(train_ds, train_sampler, collate, seed=args.seed):
+            for bi, batch in (prefetch if prefetch is not None else iterate_batches(train_ds, train_sampler, collate, seed=args.seed)):
                 scalars = stage.train_batch(self, self.put(batch), bi)
                 n_last += batch[0].shape[0]
                 self.global_step += 1
@@ -163,6 +165,8 @@ class Trainer:
                 print(f"epoch {epoch}: val_loss {val_loss:.6f}", flush=True)
             if done or self.early.should_stop(val_loss):
                 break
+        if prefetch is not None:
+            prefetch.close()
         torch.cuda.synchronize()
 
 

@@ -47,6 +47,8 @@ def test_three_stages_cli(tmp_path, graph):
               "--n_head", "4", "--batch_size", "32", "--max_steps", "6", "--val_batches", "2", "--epochs", "1"]
     if not graph:
         common.append("--no_graph")
+    else:
+        common += ["--token_cache", "--prefetch_workers", "2"]      # binary token cache + batches built ahead in workers
     _small_constants()
     try:
         pre = main_pretrain.main(common + ["--ver", "0"])
@@ -60,11 +62,17 @@ def test_three_stages_cli(tmp_path, graph):
         saved = os.listdir(dump / "optimize-v0")
         assert len(saved) == 1 and saved[0].startswith("G_epoch_")
         assert all(torch.isfinite(p).all() for p in opt.generator.parameters())
+        from consistent__style_transfer_amd import ops as _ops
         main_optimize.main(common + ["--ver", "v0", "--mode", "test"])
+        assert _ops.get_precision() == "f32"                       # bulk transfer defaults to the mode whose ids are pinned
+        _ops.set_precision("bf16")
         for split in ("train", "test"):
             for lab in (0, 1):
                 lines = open(root / "output" / "yelp-v0" / f"style.{split}.{lab}.tsf", encoding="utf-8").read().split("\n")
                 assert len(lines) - 1 == 150
+            assert not [f for f in os.listdir(root / "output" / "yelp-v0") if ".part" in f]
+        if graph:
+            assert os.path.exists(str(data / "style.train.0") + ".tok18.cstt")
         # scalar stream with the reference's names
         log = root / "log" / "yelp" / "optimize-v0"
         ver = sorted(os.listdir(log))[0]

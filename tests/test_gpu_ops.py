@@ -130,9 +130,11 @@ def test_gemm_bf16(ops, shape, tile):
 
 @pytest.mark.parametrize("shape", [(256, 256, 64), (256, 256, 128), (512, 256, 192), (256, 768, 320), (4608, 2304, 768), (9216, 2048, 512),
                                    (4608, 2048, 768), (1024, 512, 2304)])
-def test_gemm_bf16_256_tile(ops, shape):
-    """The 256 x 256 / 8-wave kernel (tile code 256): one, two, odd and many K-tiles; every epilogue of the small-tile kernel."""
-    test_gemm_bf16(ops, shape, 256)
+@pytest.mark.parametrize("tile", [256, 252])
+def test_gemm_bf16_256_tile(ops, shape, tile):
+    """The 256-wide kernels (tile code 256: 256 x 256 / 8 waves / 4-stage ring; 252: 128 x 256 / 4 waves / 3-stage ring, two
+    workgroups per CU): two, four, odd and many 32-deep K-tiles; every epilogue of the small-tile kernel."""
+    test_gemm_bf16(ops, shape, tile)
     M, N, K = shape
     # identity check with an asymmetric B: C = I[:, :K] B^T must reproduce B^T exactly (catches a transposed C map, a symmetric
     # operand would not) -- cdna_hip_programming.md section 3
@@ -142,7 +144,7 @@ def test_gemm_bf16_256_tile(ops, shape):
     Ab, _ = ops.cast_bf16(dev(A), want_t=False)
     Bb, _ = ops.cast_bf16(dev(B), want_t=False)
     C = torch.full((M, N), float("nan"), device="cuda")
-    ops.gemm_bf16(Ab, Bb, M, N, C=C, tile=256)
+    ops.gemm_bf16(Ab, Bb, M, N, C=C, tile=tile)
     ref = torch.zeros(M, N)
     ref[:min(M, K)] = B.t()[:min(M, K)]
     assert torch.equal(C.cpu(), ref)

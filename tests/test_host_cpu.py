@@ -99,3 +99,130 @@ def test_flop_counter_reproduces_survey_table():
         got = stage_gflop_per_sentence(n_layer, d, L, 10000)
         for k, w in zip(("pretrain", "warmup", "optimize_g", "optimize_d"), want):
             assert abs(got[k] - w) <= 0.02 * w + 0.006, (n_layer, d, L, k, got[k], w)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# content-distance labels (wmd.py), token cache, label cache, prefetching batch builder
+# ---------------------------------------------------------------------------------------------------------------------
+def _sample_vocab_and_data():
+    import os
+    from consistent__style_transfer_amd.loader import StyleDataset, load_s2l
+    from consistent__style_transfer_amd.vocab import BPETokenizer
+    g = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    vocab = BPETokenizer.load(os.path.join(g, "yelp_sample-vocab.json"), os.path.join(g, "yelp_sample-merges.txt"))
+    files = [os.path.join(g, "yelp_dev_sample.0"), os.path.join(g, "yelp_dev_sample.1")]
+    return vocab, files, StyleDataset(files, vocab, 18, load_s2l)
+
+
+def test_wmd_algorithm_known_answers_and_metric_properties():
+    """gensim's wmdistance (third party, unpinned: gensim ~3.8, 2020) restated in wmd.py: hand-solvable transportation
+    problems, the special cases, symmetry, the triangle inequality, and agreement with an independent LP formulation."""
+    import itertools
+    import numpy as np
+    from scipy.optimize import linprog
+    from consistent__style_transfer_amd.wmd import WordVectors, emd, wmdistance
+    wv = WordVectors(["a", "b", "c", "d"], np.array([[1, 0], [0, 1], [-1, 0], [0, -1.0]]))
+    assert abs(wmdistance(wv, ["a"], ["b"]) - 2 ** 0.5) < 1e-12
+    assert wmdistance(wv, ["a", "b"], ["b", "a"]) == 0.0
+    assert abs(wmdistance(wv, ["a", "a", "b"], ["c"]) - (2 * 2 + 2 ** 0.5) / 3) < 1e-9        # all mass moves to c
+    assert wmdistance(wv, ["a", "zzz"], ["qqq"]) == float("inf")                               # one side all out of vocabulary
+    assert wmdistance(wv, ["a"], ["a"]) == 0.0                                                 # a single distinct token
+    # vectors are L2-normalised on load (wmd.py:54 init_sims(replace=True))
+    wv2 = WordVectors(["a", "b"], np.array([[3.0, 0], [0, 0.5]]))
+    assert abs(wmdistance(wv2, ["a"], ["b"]) - 2 ** 0.5) < 1e-12
+    rs = np.random.RandomState(0)
+    toks = [f"t{i}" for i in range(12)]
+    wvr = WordVectors(toks, rs.randn(12, 5))
+    docs = [[toks[i] for i in rs.randint(0, 12, size=n)] for n in (3, 5, 7, 4)]
+    for x, y in itertools.combinations(docs, 2):
+        dxy = wmdistance(wvr, x, y)
+        assert abs(dxy - wmdistance(wvr, y, x)) < 1e-9
+        for z in docs:
+            assert dxy <= wmdistance(wvr, x, z) + wmdistance(wvr, z, y) + 1e-9
+    # independent formulation: full (unreduced) LP with inequality-free constraints over ALL bins
+    w1, w2 = rs.dirichlet(np.ones(6)), rs.dirichlet(np.ones(6))
+    P = rs.randn(6, 3)
+    D = np.sqrt(((P[:, None] - P[None]) ** 2).sum(-1))
+    n = 6
+    A = np.zeros((2 * n, n * n))
+    for i in range(n):
+        A[i, i * n:(i + 1) * n] = 1
+        A[n + i, i::n] = 1
+    ref = linprog(D.reshape(-1), A_eq=A, b_eq=np.concatenate([w1, w2]), bounds=(0, None), method="highs-ipm").fun
+    assert abs(emd(w1, w2, D) - ref) < 1e-7
+
+
+def test_cal_wmd_label_follows_the_reference_special_cases():
+    """src/wmd.py:33-45: an empty sentence -> the longer length; infinite distance -> the mean length; else the distance."""
+    import numpy as np
+    from consistent__style_transfer_amd.wmd import WMDdistance, WordVectors
+
+    class Tok:
+        def ids_to_tokens(self, ids):
+            return [f"w{i}" for i in ids]
+
+    w = WMDdistance(WordVectors(["w1", "w2", "w3"], np.eye(3)))
+    lab = w.cal_wmd_label([[], [1, 2], [9, 9, 9], [1]], [[4, 5, 6], [2, 1], [1], [3]], Tok())
+    assert lab[0] == 3.0                       # empty first sentence
+    assert lab[1] == 0.0                       # same bag of words
+    assert lab[2] == 2.0                       # first sentence entirely out of vocabulary -> inf -> (3 + 1) / 2
+    assert abs(lab[3] - 2 ** 0.5) < 1e-12
+
+
+def test_token_cache_round_trip_and_invalidation(tmp_path):
+    import shutil
+    from consistent__style_transfer_amd.loader import StyleDataset, TokenCache, load_s2l
+    vocab, files, ds = _sample_vocab_and_data()
+    local = []
+    for f in files:
+        dst = tmp_path / ("style.train." + f[-1])
+        shutil.copy(f, dst)
+        local.append(str(dst))
+    a = StyleDataset(local, vocab, 18, load_s2l, cache=True)                   # writes the caches
+    for f in local:
+        assert open(TokenCache.path(f, 18), "rb").read(8) == TokenCache.MAGIC
+    b = StyleDataset(local, vocab, 18, load_s2l, cache=True)                   # reads them
+    assert a.samples == b.samples == ds.samples
+    assert TokenCache.read(TokenCache.path(local[0], 18), 17, len(vocab)) is None          # other max_len
+    assert TokenCache.read(TokenCache.path(local[0], 18), 18, len(vocab) + 1) is None      # other vocabulary
+    c = StyleDataset(local, vocab, 12, load_s2l, cache=True)                   # a different truncation gets its own file
+    assert max(len(t) for t, _ in c.samples) <= 12 and len(c) == len(a)
+
+
+def test_prefetched_batches_equal_inline_batches_and_label_cache_replays_them(tmp_path):
+    import torch
+    from consistent__style_transfer_amd.loader import (GlobalBatchSampler, LabelCache, PrefetchBatches, collate_pretrain,
+                                                      iterate_batches)
+    from consistent__style_transfer_amd.wmd import WMDdistance
+    vocab, files, ds = _sample_vocab_and_data()
+    w2v = WMDdistance.train(files, vocab, dim=8)
+    sampler = GlobalBatchSampler(len(ds), 64, shuffle=True, seed=3)
+    sampler.set_epoch(1)
+    collate = collate_pretrain(vocab, w2v=w2v)
+    inline = list(iterate_batches(ds, sampler, collate, seed=3))
+    pf = PrefetchBatches(ds, sampler, collate, seed=3, workers=2, depth=3)
+    try:
+        ahead = list(pf)
+    finally:
+        pf.close()
+    assert [bi for bi, _ in ahead] == [bi for bi, _ in inline] == list(range(len(inline)))
+    for (_, a), (_, b) in zip(inline, ahead):
+        assert all(torch.equal(x, y) for x, y in zip(a, b))
+    labels = torch.cat([b[5] for _, b in inline])
+    assert torch.isfinite(labels).all() and float(labels.min()) >= 0.0 and float(labels.max()) > 0.1
+    # label cache: store the labels of this seeded run, read them back through the collate function
+    path = str(tmp_path / "labels.npz")
+    cache = LabelCache(meta={"seed": 3, "global_batch": 64, "n_sentences": len(ds)})
+    for bi, b in inline:
+        cache.put(1, bi, b[5].numpy())
+    cache.save(path)
+    back = LabelCache(path)
+    back.check(3, 64, len(ds))
+    with pytest.raises(ValueError):
+        back.check(4, 64, len(ds))
+    cached = collate_pretrain(vocab, label_fn=lambda *a: (_ for _ in ()).throw(AssertionError("label_fn must not run")), label_cache=back)
+    replay = list(iterate_batches(ds, sampler, cached, seed=3))
+    for (_, a), (_, b) in zip(inline, replay):
+        assert all(torch.equal(x, y) for x, y in zip(a, b))
+    with pytest.raises(KeyError):
+        back.get(7, 0, 64)

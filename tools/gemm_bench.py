@@ -95,7 +95,25 @@ def main_bf16(shapes=None, out_bf16=False):
         print(f"{note:18s} {M:6d}x{N:5d}x{K:5d}  " + "  ".join(f"t{t}:{u:7.1f}us" for t, u in zip(tiles, res)) + f"   best {fl / best / 1e6:7.1f} TF/s")
 
 
+def main_pmc():
+    """A few eager launches per (shape, tile) for rocprofv3 --pmc (tools/profile_gemm_pmc.sh): kernels are told apart by name +
+    grid size in the counter CSV."""
+    shapes = [(9216, 2048, 768), (4608, 2304, 768), (9216, 768, 2048)]
+    for M, N, K in shapes:
+        A, B = torch.randn(M, K, device="cuda"), torch.randn(N, K, device="cuda")
+        Ab, _ = ops.cast_bf16(A, want_t=False)
+        Bb, _ = ops.cast_bf16(B, want_t=False)
+        C = torch.empty(M, N, device="cuda")
+        for tile in (64, 128, 256):
+            for _ in range(6):
+                ops.gemm_bf16(Ab, Bb, M, N, C=C, tile=tile)
+            torch.cuda.synchronize()
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "pmc":
+        main_pmc()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "bf16nt":
         main_bf16()
         sys.exit(0)

@@ -60,8 +60,32 @@ def pmc(fetch, write, out):
     json.dump(res, open(out, "w"), indent=1)
 
 
+def gemmpmc(out_dir):
+    """Per (kernel, grid) averages of every counter in sq.csv / mem1.csv / mem2.csv, plus dispatch duration."""
+    import os
+    table = collections.defaultdict(lambda: collections.defaultdict(list))
+    for name in ("sq", "mem1", "mem2"):
+        path = os.path.join(out_dir, name + ".csv")
+        if not os.path.exists(path):
+            continue
+        for r in csv.DictReader(open(path)):
+            k = short(r["Kernel_Name"])
+            if "gemm_bf16" not in k or "reduce" in k:
+                continue
+            key = (k.replace("cst_gemm_bf16_", ""), r.get("Grid_Size", "?"))
+            table[key][r["Counter_Name"]].append(float(r["Counter_Value"]))
+            if name == "sq" and r["Counter_Name"] == "SQ_WAVE_CYCLES":
+                table[key]["dur_us"].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+    for key in sorted(table):
+        t = table[key]
+        avg = {c: sum(v[2:]) / max(1, len(v[2:])) for c, v in t.items()}      # skip the first two (cold) launches
+        print(f"{key[0]:40s} grid {key[1]:>8s}  " + "  ".join(f"{c}={avg[c]:.4g}" for c in sorted(avg)))
+
+
 if __name__ == "__main__":
-    if sys.argv[1] == "stats":
+    if sys.argv[1] == "gemmpmc":
+        gemmpmc(sys.argv[2])
+    elif sys.argv[1] == "stats":
         stats(sys.argv[2], int(sys.argv[3]), sys.argv[4])
     else:
         pmc(sys.argv[2], sys.argv[3], sys.argv[4])
