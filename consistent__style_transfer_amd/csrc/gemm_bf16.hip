@@ -832,7 +832,18 @@ extern "C" int cst_gemm_bf16(const void* A, long lda, const void* B, long ldb,
     int use_big, splits = 1;
     if (tile == 128) use_big = 1;
     else if (tile == 64) use_big = 0;
-    else use_big = (mid < 256 && K >= 2048);
+    else {
+        use_big = (mid < 256 && K >= 2048);
+        // Round quantisation (measured, tools/gemm_bench.py enc): 64x128 tiles run 3 workgroups per CU (768 slots), 128x128 tiles 2
+        // (512 slots).  At equal round efficiency the smaller tile wins (more independent workgroups hide the first-touch latency of
+        // each K-tile); when the 128x128 grid fills its slots markedly better -- 9216 x 768 (432 of 512 against 864 of 1536),
+        // 4608 x 1536 -- it is 15-30 % faster.
+        if (!use_big && splitk <= 1 && mid >= 256 && big >= 256) {
+            const double e64 = (double)mid / (double)(cst_div_up(mid, 768) * 768);
+            const double e128 = (double)big / (double)(cst_div_up(big, 512) * 512);
+            if (e128 > e64 + 0.15) use_big = 1;
+        }
+    }
     const long tiles = use_big ? big : mid;
     if (splitk > 1) splits = splitk;
     else if (splitk == 0 && workspace && tiles < 192 && K >= 512) {
