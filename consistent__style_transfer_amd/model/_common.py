@@ -70,10 +70,19 @@ class EncoderStack(nn.Module):
         for l in self.layers[1:]:
             l.load_state_dict(first.state_dict())
         self.n_head = n_head
+        self.taps = None           # set to a list to record [input of layer 0, output of layer 0, ..., output of the last layer]
 
     def run(self, x2d, B, S, drop):
+        """`taps` (stages.bucketed_backward): the tensors at the layer seams, recorded so that the backward pass can be driven
+        one encoder layer at a time from Python -- each layer's gradients are complete, and their all-reduce can start, while
+        the layers below are still being back-propagated."""
         from ..ops import EncoderLayerBf16Fn, EncoderLayerFn, get_precision
         fn = EncoderLayerFn if get_precision() == "f32" else EncoderLayerBf16Fn
+        if self.taps is not None:
+            self.taps.clear()
+            self.taps.append(x2d)
         for i, l in enumerate(self.layers):
             x2d = fn.apply(x2d, *l.flat(), B, S, self.n_head, drop, i)
+            if self.taps is not None:
+                self.taps.append(x2d)
         return x2d

@@ -515,6 +515,13 @@ class EncoderLayerFn(torch.autograd.Function):
                 None, None, None, None, None)
 
 
+def _gout(W):
+    """Where the weight gradient of W should be written: its slot in the owning group's flat gradient buffer while a bucketed
+    backward is in progress (optim.FlatGroup.direct), else None (a fresh tensor)."""
+    grp = getattr(W, "_cst_group", None)
+    return grp.grad_view(W) if (grp is not None and grp.direct) else None
+
+
 class EncoderLayerBf16Fn(torch.autograd.Function):
     """The same layer as EncoderLayerFn on the bf16-operand GEMMs (cst_gemm_bf16 / cst_gemm_bf16_tt, direct-to-LDS
     ring).  Forward and dgrad products read K-contiguous bf16 copies (activations cast once, weights cached per
@@ -577,6 +584,7 @@ class EncoderLayerBf16Fn(torch.autograd.Function):
         wx, watt, wy1, wh = (xb, attb, y1b, hb) if tt else (xt, attt, y1t, ht)
         ctx.save_for_backward(wx, watt, wy1, wh, hb, inw_t, outw_t, l1_t, l2_t, n1_w, n2_w, qkv, lse, z1, m1, r1, z2, m2, r2)
         ctx.cfg = (B, S, H, drop, sb, T, d, F, wg, tt, fuse_b)
+        ctx.wrefs = (in_w, out_w, l1_w, l2_w)             # parameters (not saved tensors): only to find their gradient slots
         return y2
 
     @staticmethod
@@ -615,10 +623,11 @@ class EncoderLayerBf16Fn(torch.autograd.Function):
         dinw = dinb = doutw = doutb = dl1w = dl1b = dl2w = dl2b = None
         if wg:
             if tt:                                        # dW = dY^T X from the row-major copies
-                dl2w = gemm_bf16_tt(dfb, wh, d, F)
-                dl1w = gemm_bf16_tt(dhb, wy1, F, d)
-                doutw = gemm_bf16_tt(dob, watt, d, d)
-                dinw = gemm_bf16_tt(dqb, wx, 3 * d, d)
+                in_w, out_w, l1_w, l2_w = ctx.wrefs
+                dl2w = gemm_bf16_tt(dfb, wh, d, F, C=_gout(l2_w))
+                dl1w = gemm_bf16_tt(dhb, wy1, F, d, C=_gout(l1_w))
+                doutw = gemm_bf16_tt(dob, watt, d, d, C=_gout(out_w))
+                dinw = gemm_bf16_tt(dqb, wx, 3 * d, d, C=_gout(in_w))
             else:
                 dht = cast_bf16(dhb[:, :F], want_rm=False)[1]
                 dl2w = gemm_bf16(dft, wh, d, F, C=new(d, F))

@@ -34,6 +34,15 @@ class CaptureRecord:
         self.tables = []
 
 
+class FlatSlice:
+    """A contiguous range of a group's flat gradient buffer: the unit parallel.GradReducer all-reduces when the backward pass
+    hands over gradients bucket by bucket."""
+
+    def __init__(self, group, lo, hi, tag=""):
+        self.group, self.lo, self.hi, self.tag = group, lo, hi, tag
+        self.flat_g = group.flat_g[lo:hi]
+
+
 class FlatGroup:
     _live = weakref.WeakSet()       # every group alive in this process (graphs.GraphedStep tops up their table pools)
     _record = None                  # the CaptureRecord of the capture in progress, if any
@@ -60,6 +69,7 @@ class FlatGroup:
         self.step_dev = torch.zeros(1, device=dev, dtype=torch.int32)
         self._ssq_partials = torch.zeros(1024, device=dev, dtype=torch.float32)     # per-block partial sums of squares (cst_sumsq_accumulate)
         self.has_grad = False                             # flat_g holds gradients not yet consumed by a step
+        self.direct = False                               # ops may write weight gradients straight into grad_view() (bucketed backward only)
         self.version = 0                                  # bumped by every step(): invalidates cached bf16 weight copies
         for p in self.params:
             p._cst_group = self
@@ -131,6 +141,42 @@ class FlatGroup:
         for p in self.params:
             p.grad = None
         self.has_grad = True
+
+    def _index_of(self, p):
+        idx = getattr(self, "_pindex", None)
+        if idx is None:
+            idx = self._pindex = {id(q): k for k, q in enumerate(self.params)}
+        return idx[id(p)]
+
+    def grad_view(self, p):
+        """The slot of parameter p in the flat gradient buffer, shaped like p."""
+        i = self._index_of(p)
+        return self.flat_g[self.offsets[i]:self.offsets[i] + self.sizes[i]].view(p.shape)
+
+    def put_grads(self, params, grads):
+        """Bucketed backward (stages.bucketed_backward): the gradients of `params`, just returned by torch.autograd.grad, go
+        into their flat slots.  A gradient that a kernel already wrote THERE (ops: weight gradients of the encoder layers
+        take their slot as the GEMM's output while `direct` is on) costs nothing; the rest (biases, LayerNorm
+        parameters, embeddings) move with one multi-tensor copy.  flat_g is zero when a step starts (zero_grad), every
+        parameter is produced once per step on this path, so slots are written, not accumulated."""
+        dst, src = [], []
+        for p, g in zip(params, grads):
+            if g is None:
+                continue
+            v = self.grad_view(p)
+            if g.data_ptr() != v.data_ptr():
+                dst.append(v)
+                src.append(g.reshape(p.shape))
+        if dst:
+            torch._foreach_copy_(dst, src)
+        self.has_grad = True
+
+    def span(self, params):
+        """(lo, hi) of the flat range covered by `params`, which must be adjacent in the group's order."""
+        ks = sorted(self._index_of(p) for p in params)
+        assert ks == list(range(ks[0], ks[-1] + 1)), "bucket parameters must be adjacent in the flat order"
+        hi = self.offsets[ks[-1] + 1] if ks[-1] + 1 < len(self.offsets) else self.total
+        return self.offsets[ks[0]], hi
 
     def sumsq_into(self, out):
         call("cst_sumsq_accumulate", self.flat_g, self.total, out, self._ssq_partials)

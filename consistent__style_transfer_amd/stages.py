@@ -19,7 +19,7 @@ import torch.nn as nn
 
 from . import ops
 from .model import MLM, DenoiseLSTM, Matcher, RelGAN_D, TextCNN
-from .optim import FlatGroup, clip_groups
+from .optim import FlatGroup, FlatSlice, clip_groups
 
 
 class Fork:
@@ -53,6 +53,43 @@ class Fork:
         return outs
 
 
+def bucketed_backward(loss, stack, group, head_params, embed_params, reducer, last=False, tag=""):
+    """Backward pass of a transformer critic (MLM / Matcher) driven one encoder layer at a time, so that the all-reduce of a
+    layer's gradients runs while the layers below it are still being back-propagated (north_star: "gradient RCCL all-reduce
+    over xGMI overlapped with backward"; the reference has no distributed code).
+
+    `stack.taps` holds the tensors at the layer seams of this forward pass.  Buckets, in the order their gradients
+    complete: the head (everything after the last layer), layer n-1, ..., layer 0, the embeddings -- each a contiguous
+    range of the group's flat gradient buffer (optim.FlatGroup.span), handed to `reducer(bucket, defer=True)` as soon as
+    torch.autograd.grad has returned its gradients; only the last bucket of the last critic is reduced with defer=False,
+    which makes the stream wait for every collective outstanding.  Under hipGraph capture every reducer call is a
+    segment boundary (graphs.GraphedStep), so the collectives run on RCCL's stream between segment replays."""
+    taps = stack.taps
+    n = len(stack.layers)
+    assert taps is not None and len(taps) == n + 1, "EncoderStack.taps was not recorded for this forward pass"
+    group.direct = True
+    try:
+        grads = torch.autograd.grad(loss, [taps[n]] + head_params)
+        g = grads[0]
+        group.put_grads(head_params, grads[1:])
+        reducer([FlatSlice(group, *group.span(head_params), tag=f"{tag}.head")], True)
+        for i in range(n - 1, -1, -1):
+            lp = list(stack.layers[i].parameters())
+            grads = torch.autograd.grad(taps[i + 1], [taps[i]] + lp, grad_outputs=g)
+            g = grads[0]
+            group.put_grads(lp, grads[1:])
+            reducer([FlatSlice(group, *group.span(lp), tag=f"{tag}.layer{i}")], True)
+        grads = torch.autograd.grad(taps[0], embed_params, grad_outputs=g, allow_unused=True)
+        group.put_grads(embed_params, grads)
+        if last:
+            reducer([FlatSlice(group, *group.span(embed_params), tag=f"{tag}.embed")])
+        else:
+            reducer([FlatSlice(group, *group.span(embed_params), tag=f"{tag}.embed")], True)
+    finally:
+        group.direct = False
+        taps.clear()
+
+
 def _set_requires_grad(params, flag):
     for p in params:
         p.requires_grad_(flag)
@@ -77,6 +114,7 @@ class PretrainStage(nn.Module):
         self.best_eval = {name: float("inf") for name in self.flags}
         self.lr = lr
         self.groups = None
+        self.bucketed = True          # data parallel: per-layer gradient buckets, all-reduce overlapped with the backward pass
 
     def setup_optim(self):
         dev = next(self.parameters()).device
@@ -115,9 +153,16 @@ class PretrainStage(nn.Module):
         parallelism, its all-reduce is started right away (deferred) while the next critic computes; only the last
         reducer call waits for all of them before the global-norm clip."""
         x, nx_1, nx_2, nx, label, c_label = batch
-        order = [k for k in ("dn", "mat", "cls") if self.flags[k]]            # largest gradient buffers first
+        # data parallel: the small classifier first (its all-reduce hides under the MLM), then the two transformer critics
+        # with their backward passes cut into per-layer buckets (bucketed_backward); single GPU: largest first, one backward each
+        bucketed = reducer is not None and self.bucketed
+        order = [k for k in (("cls", "dn", "mat") if bucketed else ("dn", "mat", "cls")) if self.flags[k]]
         vals = {"dn": None, "mat": None, "cls": None}
         for i, k in enumerate(order):
+            last = i + 1 == len(order)
+            stack = {"dn": self.denoiser.lm, "mat": self.matcher.matcher}.get(k)
+            if bucketed and stack is not None:
+                stack.taps = []
             if k == "dn":
                 lg = self.denoiser(nx, seed=seed)
                 loss = ops.token_ce(lg.view(-1, lg.size(-1)), x.reshape(-1), unit_grad=True)
@@ -125,11 +170,18 @@ class PretrainStage(nn.Module):
                 loss = ops.mse_loss(self.matcher(nx_1, nx_2, seed=seed), c_label)
             else:
                 loss = ops.token_ce(self.classifier(x, seed=seed), label)
-            loss.backward()
             vals[k] = loss.detach()
+            if bucketed and stack is not None:
+                m = self.named_models[k]
+                head = list((m.fwd if k == "dn" else m.hidden2logits).parameters())
+                embed = [p for n_, p in m.named_parameters() if "embedding" in n_]
+                bucketed_backward(loss, stack, self.groups[k], head, embed, reducer, last=last, tag=k)
+                stack.taps = None
+                continue
+            loss.backward()
             self.groups[k].gather_grads(False)
             if reducer is not None:
-                if i + 1 < len(order):
+                if not last:
                     reducer([self.groups[k]], True)
                 else:
                     reducer([self.groups[k]])
