@@ -377,6 +377,7 @@ def main():
             run_step(stages_, batches, args.warmup + args.steps + it, None)
         torch.cuda.synchronize()
         _lib.gemm_profile(False)
+        shape_recs = _lib.gemm_profile_shapes()
         prof = _lib.gemm_profile_read()
         # HBM traffic per launch cannot be measured inside this process (PMC counters need rocprofv3 around it): it is
         # read from the committed summary of the same workload (tools/profile_pmc.sh) and the JSON line says so
@@ -410,6 +411,23 @@ def main():
                         "min_operand_bytes_per_launch": d["min_operand_bytes_per_launch"],
                         "kernel_ms_per_step": d["kernel_ms_per_step"],
                         "other_mfma_kernels": {k: v for k, v in kernels.items() if k != dom}}
+        if roofline is not None:
+            # per-shape rates of the encoder-layer products (T = B*L tokens of the MLM, 2*B*L of the Matcher): forward / dgrad
+            # (NT kernel, K > 0) and weight gradients (transposed-read kernel, recorded with K < 0)
+            agg = {}
+            for which, M, N, K, ms in shape_recs:
+                if which != 1 or M < 1024 or ms <= 0:
+                    continue
+                a = agg.setdefault((M, N, K), [0, 0.0])
+                a[0] += 1
+                a[1] += ms
+            by_shape = {}
+            for (M, N, K), (n, ms) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:16]:
+                kind = "nt" if K > 0 else "tt"
+                tf = 2.0 * M * N * abs(K) * n / (ms * 1e-3) / 1e12
+                by_shape[f"{M}x{N}x{abs(K)}.{kind}"] = {"launches_per_step": n / nprof, "avg_us": 1000.0 * ms / n, "tflops": tf,
+                                                        "frac": tf / MFMA_PEAK_TFLOPS}
+            roofline["by_shape"] = by_shape
         if args.breakdown:
             timer = _lib.KernelTimer(by_shape=True)
             _lib.set_timer(timer)

@@ -147,6 +147,18 @@ def gemm_profile(enable):
     lib().fn["cst_gemm_profile_enable"](1 if enable else 0)
 
 
+def gemm_profile_shapes(max_records=200000):
+    """-> list of (which, M, N, K, ms) for every GEMM launch recorded since gemm_profile(True)."""
+    mnk = (ctypes.c_int * (3 * max_records))()
+    ms = (ctypes.c_double * max_records)()
+    which = (ctypes.c_int * max_records)()
+    n = ctypes.c_long()
+    rc = lib().fn["cst_gemm_profile_shapes"](max_records, mnk, ms, which, ctypes.byref(n))
+    if rc != 0:
+        raise RuntimeError(lib().last_error())
+    return [(which[i], mnk[3 * i], mnk[3 * i + 1], mnk[3 * i + 2], ms[i]) for i in range(n.value)]
+
+
 def gemm_profile_read():
     """-> {kernel: (total kernel ms, total FLOP, total minimal operand bytes, launches)} since enable."""
     out = {}

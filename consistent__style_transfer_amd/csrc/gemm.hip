@@ -414,11 +414,31 @@ __global__ __launch_bounds__(256) void cst_gemm_splitk_reduce(GemmArgs g) {
 // trace), so the measured duration excludes host launch gaps.
 #include <hip/hip_ext.h>
 #include <vector>
-struct GemmProf { hipEvent_t a, b; double flops; double bytes; int which; };    // which: 0 cst_gemm_kernel, 1 cst_gemm_bf16_kernel
+struct GemmProf { hipEvent_t a, b; double flops; double bytes; int which; int m, n, k; };    // which: 0 cst_gemm_kernel, 1 cst_gemm_bf16_kernel
 static bool g_prof_on = false;
 static std::vector<GemmProf> g_prof;
 bool cst_prof_on() { return g_prof_on; }
-void cst_prof_push(hipEvent_t a, hipEvent_t b, double flops, double bytes, int which) { g_prof.push_back({a, b, flops, bytes, which}); }
+void cst_prof_push(hipEvent_t a, hipEvent_t b, double flops, double bytes, int which) { g_prof.push_back({a, b, flops, bytes, which, 0, 0, 0}); }
+void cst_prof_push_shape(hipEvent_t a, hipEvent_t b, double flops, double bytes, int which, int m, int n, int k) {
+    g_prof.push_back({a, b, flops, bytes, which, m, n, k});
+}
+
+// per-launch records since enable: mnk[3 i .. 3 i + 2] = M, N, K as the kernel saw them (0 where a call site does not record
+// them), ms[i] = kernel duration, which[i] as above.  Does not clear the list (cst_gemm_profile_read(1, ...) does).
+extern "C" int cst_gemm_profile_shapes(long max_records, int* mnk, double* ms, int* which, long* count) {
+    long n = 0;
+    for (auto& p : g_prof) {
+        if (n >= max_records) break;
+        if (hipEventSynchronize(p.b) != hipSuccess) { cst_set_error("cst_gemm_profile_shapes: event sync failed"); return CST_ERR_LAUNCH; }
+        float t = 0.f;
+        (void)hipEventElapsedTime(&t, p.a, p.b);
+        mnk[3 * n] = p.m; mnk[3 * n + 1] = p.n; mnk[3 * n + 2] = p.k;
+        ms[n] = t; which[n] = p.which;
+        ++n;
+    }
+    *count = n;
+    return CST_OK;
+}
 
 extern "C" int cst_gemm_profile_enable(int on) {
     if (on && !g_prof_on) g_prof.clear();
@@ -452,7 +472,7 @@ static void launch_cfg(const GemmArgs& g, int f32, int akm, int bkm, int batch, 
     hipEvent_t ea = nullptr, eb = nullptr;
     if (g_prof_on) {
         (void)hipEventCreate(&ea); (void)hipEventCreate(&eb);
-        g_prof.push_back({ea, eb, 2.0 * g.M * g.N * g.K * batch, 4.0 * ((double)g.M * g.K + (double)g.N * g.K + (double)g.M * g.N) * batch, 0});
+        g_prof.push_back({ea, eb, 2.0 * g.M * g.N * g.K * batch, 4.0 * ((double)g.M * g.K + (double)g.N * g.K + (double)g.M * g.N) * batch, 0, g.M, g.N, g.K});
     }
 #define CST_GEMM_CASE(F, AK, BKM)                                                              \
     if (f32 == F && akm == AK && bkm == BKM) {                                                 \

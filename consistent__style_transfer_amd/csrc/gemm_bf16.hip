@@ -525,6 +525,7 @@ __global__ __launch_bounds__(256) void cst_gemm_bf16_reduce(BGemmArgs g) {
 #include <hip/hip_ext.h>
 extern bool cst_prof_on();
 extern void cst_prof_push(hipEvent_t a, hipEvent_t b, double flops, double bytes, int which);
+extern void cst_prof_push_shape(hipEvent_t a, hipEvent_t b, double flops, double bytes, int which, int m, int n, int k);
 
 // =============================================================================================
 // 256 x 256 tile, 8 waves, K-tiles of 32 in a 4-stage ring (after cdna_hip_programming.md section 5, "The 256^2 8-phase
@@ -773,7 +774,8 @@ static int bgemm_big_launch_t(const BGemmArgs& g, hipStream_t st) {
     if (cst_prof_on()) {
         hipEvent_t ea, eb;
         (void)hipEventCreate(&ea); (void)hipEventCreate(&eb);
-        cst_prof_push(ea, eb, 2.0 * g.M * g.N * g.K, 2.0 * ((double)g.M * g.K + (double)g.N * g.K) + (g.C ? 4.0 : 0.0) * g.M * g.N + (g.Cb ? 2.0 : 0.0) * g.M * g.N, 1);
+        cst_prof_push_shape(ea, eb, 2.0 * g.M * g.N * g.K, 2.0 * ((double)g.M * g.K + (double)g.N * g.K) + (g.C ? 4.0 : 0.0) * g.M * g.N + (g.Cb ? 2.0 : 0.0) * g.M * g.N, 1,
+                            g.M, g.N, g.K);
         hipExtLaunchKernelGGL((cst_gemm_bf16_big_kernel<WR, NST>), grid, block, lds, st, ea, eb, 0, g, gn);
     } else {
         hipLaunchKernelGGL((cst_gemm_bf16_big_kernel<WR, NST>), grid, block, lds, st, g, gn);
@@ -794,7 +796,9 @@ static int bgemm_launch(const BGemmArgs& g, hipStream_t st) {
     if (cst_prof_on()) {
         hipEvent_t ea, eb;
         (void)hipEventCreate(&ea); (void)hipEventCreate(&eb);
-        cst_prof_push(ea, eb, 2.0 * g.M * g.N * g.K, 2.0 * ((double)g.M * g.K + (double)g.N * g.K) + (g.C ? 4.0 : 0.0) * g.M * g.N + (g.Cb ? 2.0 : 0.0) * g.M * g.N, 1);
+        // TT products are recorded with a negative K (C = A^T B: the contraction index is the row index of both operands)
+        cst_prof_push_shape(ea, eb, 2.0 * g.M * g.N * g.K, 2.0 * ((double)g.M * g.K + (double)g.N * g.K) + (g.C ? 4.0 : 0.0) * g.M * g.N + (g.Cb ? 2.0 : 0.0) * g.M * g.N, 1,
+                            g.M, g.N, TT ? -g.K : g.K);
         hipExtLaunchKernelGGL((cst_gemm_bf16_kernel<BM, BN, NSTAGE, TT>), grid, block, lds, st, ea, eb, 0, g);
     } else {
         hipLaunchKernelGGL((cst_gemm_bf16_kernel<BM, BN, NSTAGE, TT>), grid, block, lds, st, g);

@@ -60,6 +60,10 @@ int cst_gemm(const float* A, long lda, int a_kmajor, const float* B, long ldb, i
  * (0 = cst_gemm_kernel, 1 = cst_gemm_bf16_kernel; read 0 first, reading 1 clears).  Not capture-safe. */
 int cst_gemm_profile_enable(int on);
 int cst_gemm_profile_read(int which, double* total_ms_host, double* total_flops_host, double* total_min_bytes_host, long* launches_host);
+/* Per-launch records of the same list (host arrays of max_records entries): M, N, K of every GEMM launch (K < 0: the
+ * transposed-read weight-gradient product, contraction over rows), its duration and kernel family -- bench.py's
+ * roofline.by_shape.  Call before cst_gemm_profile_read(1, ...), which clears the list. */
+int cst_gemm_profile_shapes(long max_records, int* mnk_host, double* ms_host, int* which_host, long* count_host);
 
 /* bf16-operand NT GEMM with direct-to-LDS (global_load_lds) staging in a 3-stage ring:
  * C[M,N] (fp32) and/or Cb[M,N] (bf16) = epilogue(alpha * A[M,K] . B[N,K]^T); A, B bf16 (uint16 storage),

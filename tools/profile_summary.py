@@ -36,7 +36,7 @@ def stats(path, steps, out):
                 f.write(f"| `{short(r['Name'])}` | {int(r['Calls']) / steps:.1f} | {float(r['AverageNs']) / 1e3:.1f} | {float(r['Percentage']):.1f} |\n")
 
 
-def pmc(fetch, write, out):
+def pmc(fetch, write, out, workload="yelp_6l_d768_b256"):
     def agg(path, name):
         d = collections.defaultdict(lambda: [0, 0.0, 0.0])
         for r in csv.DictReader(open(path)):
@@ -50,7 +50,8 @@ def pmc(fetch, write, out):
             d[k][2] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
         return d
     f, w = agg(fetch, "FETCH_SIZE"), agg(write, "WRITE_SIZE")
-    res = {"note": "FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports half the bytes of wide coalesced "
+    res = {"workload": workload,
+           "note": "FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports half the bytes of wide coalesced "
                    "reads (MI355X_MICROARCH.md, HBM) so it is doubled here; separate --pmc passes", "kernels": {}}
     for k in sorted(f, key=lambda k: -f[k][1])[:12]:
         n = f[k][0]
@@ -88,4 +89,4 @@ if __name__ == "__main__":
     elif sys.argv[1] == "stats":
         stats(sys.argv[2], int(sys.argv[3]), sys.argv[4])
     else:
-        pmc(sys.argv[2], sys.argv[3], sys.argv[4])
+        pmc(sys.argv[2], sys.argv[3], sys.argv[4], *(sys.argv[5:6]))
