@@ -30,6 +30,13 @@ void cst_set_error(const char* fmt, ...);
 
 #define CST_WAVE 64
 
+// Zero n 4-byte words with a KERNEL (csrc/pointwise.hip).  Never hipMemsetAsync inside a library call: under segmented
+// hipGraph capture (capture_error_mode thread_local, needed next to RCCL's threads) a memset issued by the autograd engine
+// thread was replayed out of order -- the column-sum target of the last encoder layer got zeroed BEFORE an earlier tenant of
+// the same pool block wrote it, and 5.8e25 came back as a bias gradient (round-2 debugging, tools/debug/bucketed_dbg.py).
+// Kernel nodes keep their stream order.
+int cst_zero_words(void* p, long n_words, hipStream_t st);
+
 // ---- dropout RNG contract (mirrors oracle/rng.py bit for bit) --------------------------------
 __host__ __device__ __forceinline__ uint32_t cst_mix32(uint32_t seed, uint32_t stream, uint32_t idx) {
     uint32_t x = idx ^ (stream * 0x9E3779B1u);

@@ -163,7 +163,7 @@ extern "C" int cst_colsum_bf16(const void* X, long ld, int M, int N, float* out,
     hipStream_t st = (hipStream_t)stream;
     const int cg = cst_div_up(N, 64);
     int splits = 2048 / cg; if (splits < 1) splits = 1; if (splits > M / 32) splits = M / 32; if (splits < 1) splits = 1;
-    if (hipMemsetAsync(out, 0, sizeof(float) * N, st) != hipSuccess) { cst_set_error("cst_colsum_bf16: memset failed"); return CST_ERR_LAUNCH; }
+    if (cst_zero_words(out, N, st) != CST_OK) { cst_set_error("cst_colsum_bf16: zero fill failed"); return CST_ERR_LAUNCH; }
     hipLaunchKernelGGL(colsum_bf16_kernel, dim3(cg, splits), dim3(256), 0, st, (const bf16_t*)X, ld, M, N, out, cst_div_up(M, splits));
     CST_LAUNCH_CHECK("cst_colsum_bf16");
     return CST_OK;
@@ -177,6 +177,7 @@ struct BGemmArgs {
     const bf16_t* A2; const bf16_t* B2;   // second independent problem of the same shape (gridDim.z == 2; slab output only)
     float* C; bf16_t* Cb;           // either or both
     const float* bias; const float* addend; const bf16_t* aux;
+    const float* bscale;            // per-output-column scale (fp8 B operand: B[n][k] = fp8[n][k] * bscale[n]); null = none
     long lda, ldb, ldc, ldcb, ldadd, ldaux;
     int M, N, K;                    // K multiple of 64
     int act;                        // 0 none, 1 relu, 2 leaky(0.1), 3 aux>0 ? v*gate_scale : 0, 4 aux>0 ? v : 0.1 v
@@ -214,6 +215,7 @@ __device__ __forceinline__ u32x2_t lds_read64_tr(unsigned addr) {
 __device__ __forceinline__ int tlds_off(int row, int ch) { return row * 256 + 16 * (ch ^ (((row & 3) << 2) | ((row >> 2) & 3))); }
 
 __device__ __forceinline__ void bgemm_store(const BGemmArgs& g, uint32_t dseed, int m, int n, float acc) {
+    if (g.bscale) acc *= g.bscale[n];
     float v = g.alpha * acc + (g.bias ? g.bias[n] : 0.f);
     if (g.addend) v += g.addend[(long)m * g.ldadd + n];
     if (g.act == 1) v = v > 0.f ? v : 0.f;
@@ -239,7 +241,8 @@ __device__ __forceinline__ bool bgemm_vec_ok(const BGemmArgs& g) {
 // columns n..n+3 of row m (n % 4 == 0, n + 3 < N, bgemm_vec_ok): same arithmetic as bgemm_store
 __device__ __forceinline__ void bgemm_store4(const BGemmArgs& g, uint32_t dseed, int m, int n, const float av[4]) {
     float o[4];
-    float b4[4] = {0.f, 0.f, 0.f, 0.f}, a4[4] = {0.f, 0.f, 0.f, 0.f}, x4[4] = {1.f, 1.f, 1.f, 1.f};
+    float b4[4] = {0.f, 0.f, 0.f, 0.f}, a4[4] = {0.f, 0.f, 0.f, 0.f}, x4[4] = {1.f, 1.f, 1.f, 1.f}, s4[4] = {1.f, 1.f, 1.f, 1.f};
+    if (g.bscale) { s4[0] = g.bscale[n]; s4[1] = g.bscale[n + 1]; s4[2] = g.bscale[n + 2]; s4[3] = g.bscale[n + 3]; }
     if (g.bias) { const float4 t = *reinterpret_cast<const float4*>(g.bias + n); b4[0] = t.x; b4[1] = t.y; b4[2] = t.z; b4[3] = t.w; }
     if (g.addend) { const float4 t = *reinterpret_cast<const float4*>(g.addend + (long)m * g.ldadd + n); a4[0] = t.x; a4[1] = t.y; a4[2] = t.z; a4[3] = t.w; }
     if (g.act >= 3) {
@@ -249,7 +252,7 @@ __device__ __forceinline__ void bgemm_store4(const BGemmArgs& g, uint32_t dseed,
     }
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-        float v = g.alpha * av[e] + b4[e];
+        float v = g.alpha * (av[e] * s4[e]) + b4[e];
         v += a4[e];
         if (g.act == 1) v = v > 0.f ? v : 0.f;
         else if (g.act == 2) v = v > 0.f ? v : 0.1f * v;
@@ -277,10 +280,17 @@ __device__ __forceinline__ void bgemm_store4(const BGemmArgs& g, uint32_t dseed,
 //             64 rows of 256 bytes and the MFMA fragments come from the hardware transposed read
 //             ds_read_b64_tr_b16 (4 rows x 16 columns per 16-lane group, delivered column-major), on the
 //             XOR image (b) of cdna_hip_programming.md T10.  128x128 tiles only.
-template <int BM, int BN, int NSTAGE, bool TT = false>
+// BF8 = true: the B operand is fp8 e4m3 (OCP) in HBM, [N][K] with K contiguous, one byte per element -- the W8A16 path of
+//             BASELINE configs[4] ("fp8 weight MFMA + bf16 activations"): the weight tile travels HBM -> LDS at half the bytes
+//             (64-byte rows; 16-row DMA pieces; slot swizzle g((row >> 2) & 3) as in the 256-wide kernel below), each lane reads its
+//             8 k-values with one ds_read_b64 and widens them in registers (v_cvt_pk_f32_fp8 x 4, v_cvt_pk_bf16_f32 x 4: e4m3
+//             is exactly representable in bf16) for the same v_mfma_f32_16x16x32_bf16; the per-output-channel scale rides in
+//             the epilogue (bscale).  gfx950 has no MFMA that mixes bf16 and fp8 operands.
+template <int BM, int BN, int NSTAGE, bool TT = false, bool BF8 = false>
 __global__ __launch_bounds__(256) void cst_gemm_bf16_kernel(BGemmArgs g) {
-    constexpr int A_BYTES = BM * BROW, B_BYTES = BN * BROW, ST_BYTES = A_BYTES + B_BYTES;
-    constexpr int A_CH = BM / 8 / 4, B_CH = BN / 8 / 4;        // 1-KiB chunks (8 rows) per wave per tile
+    static_assert(!(TT && BF8), "fp8 B operand: NT products only");
+    constexpr int A_BYTES = BM * BROW, B_BYTES = BN * (BF8 ? 64 : BROW), ST_BYTES = A_BYTES + B_BYTES;
+    constexpr int A_CH = BM / 8 / 4, B_CH = BF8 ? BN / 16 / 4 : BN / 8 / 4;   // 1-KiB chunks (8 rows; fp8 B: 16 rows) per wave per tile
     constexpr int LOADS = A_CH + B_CH;                          // global_load_lds instructions per wave per tile
     constexpr int TM = BM / 32, TN = BN / 32;
     static_assert(!TT || (BM == 128 && BN == 128), "the transposed-read image assumes 256-byte tile rows");
@@ -316,10 +326,22 @@ __global__ __launch_bounds__(256) void cst_gemm_bf16_kernel(BGemmArgs g) {
             const int r = (wave * A_CH + c) * 8 + lrow;
             asrc[c] = (blockIdx.z ? g.A2 : g.A) + (long)min(m0 + r, g.M - 1) * g.lda + ((lps ^ (r & 7)) << 3);
         }
+        if constexpr (BF8) {
+            // 16-row pieces of 64-byte rows: lane l lands at (row 16 c + l/4, physical 16-byte slot l%4) and fetches logical slot
+            // (l%4) ^ g(l >> 4) of that row; bsrc counts BYTES here (bf16_t* arithmetic below is done on a byte pointer)
+            const int gsw = (0x1230 >> (4 * (lane >> 4))) & 3;
+#pragma unroll
+            for (int c = 0; c < B_CH; ++c) {
+                const int r = (wave * B_CH + c) * 16 + (lane >> 2);
+                const unsigned char* bq = reinterpret_cast<const unsigned char*>(g.B);
+                bsrc[c] = reinterpret_cast<const bf16_t*>(bq + (long)min(n0 + r, g.N - 1) * g.ldb + (((lane & 3) ^ gsw) << 4));
+            }
+        } else {
 #pragma unroll
         for (int c = 0; c < B_CH; ++c) {
             const int r = (wave * B_CH + c) * 8 + lrow;
             bsrc[c] = (blockIdx.z ? g.B2 : g.B) + (long)min(n0 + r, g.N - 1) * g.ldb + ((lps ^ (r & 7)) << 3);
+        }
         }
     } else {
         // chunk ci = 4 k-rows of 256 bytes; lane l lands at (row 4 ci + l/16, physical 16-byte chunk l%16) and
@@ -351,8 +373,12 @@ __global__ __launch_bounds__(256) void cst_gemm_bf16_kernel(BGemmArgs g) {
         for (int c = 0; c < A_CH; ++c)
             __builtin_amdgcn_global_load_lds((gbl_ptr_t)(asrc[c] + ka), (lds_ptr_t)(st + (wave * A_CH + c) * 1024), 16, 0, 0);
 #pragma unroll
-        for (int c = 0; c < B_CH; ++c)
-            __builtin_amdgcn_global_load_lds((gbl_ptr_t)(bsrc[c] + kb), (lds_ptr_t)(st + A_BYTES + (wave * B_CH + c) * 1024), 16, 0, 0);
+        for (int c = 0; c < B_CH; ++c) {
+            if constexpr (BF8)
+                __builtin_amdgcn_global_load_lds((gbl_ptr_t)(reinterpret_cast<const unsigned char*>(bsrc[c]) + kb), (lds_ptr_t)(st + A_BYTES + (wave * B_CH + c) * 1024), 16, 0, 0);
+            else
+                __builtin_amdgcn_global_load_lds((gbl_ptr_t)(bsrc[c] + kb), (lds_ptr_t)(st + A_BYTES + (wave * B_CH + c) * 1024), 16, 0, 0);
+        }
     };
 
     f32x4_t acc[TM][TN];
@@ -382,12 +408,41 @@ __global__ __launch_bounds__(256) void cst_gemm_bf16_kernel(BGemmArgs g) {
         const unsigned As = lds_base + (t % NSTAGE) * ST_BYTES;
         const unsigned Bs = As + A_BYTES;
         u32x4_t af[2][TM], bfr[2][TN];
+        u32x2_t bq8[2][BF8 ? TN : 1];
+        auto widen = [&](int kk) {                        // fp8 x 8 -> bf16 x 8, after the reads of half kk have landed
+            if constexpr (BF8) {
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const auto lo0 = __builtin_amdgcn_cvt_pk_f32_fp8((int)bq8[kk][j].x, false), lo1 = __builtin_amdgcn_cvt_pk_f32_fp8((int)bq8[kk][j].x, true);
+                    const auto hi0 = __builtin_amdgcn_cvt_pk_f32_fp8((int)bq8[kk][j].y, false), hi1 = __builtin_amdgcn_cvt_pk_f32_fp8((int)bq8[kk][j].y, true);
+                    u32x4_t w;
+                    w.x = (uint32_t)f2bf16(lo0[0]) | ((uint32_t)f2bf16(lo0[1]) << 16);
+                    w.y = (uint32_t)f2bf16(lo1[0]) | ((uint32_t)f2bf16(lo1[1]) << 16);
+                    w.z = (uint32_t)f2bf16(hi0[0]) | ((uint32_t)f2bf16(hi0[1]) << 16);
+                    w.w = (uint32_t)f2bf16(hi1[0]) | ((uint32_t)f2bf16(hi1[1]) << 16);
+                    bfr[kk][j] = w;
+                }
+            }
+        };
         auto read_half = [&](int kk) {
             if constexpr (!TT) {
 #pragma unroll
                 for (int i = 0; i < TM; ++i) af[kk][i] = lds_read128(As + blds_off(wm * (BM / 2) + i * 16 + lr, kk * 4 + lq));
+                if constexpr (BF8) {
+                    // row r = wn * BN/2 + 16 j + lr: swizzle key (r >> 2) & 3 = (lr >> 2) & 3; this lane's 8 k-values are bytes
+                    // 32 kk + 8 lq .. + 7 of the row = 16-byte slot 2 kk + (lq >> 1), half lq & 1
+                    const int fsw = (0x1230 >> (4 * ((lr >> 2) & 3))) & 3;
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        const unsigned ad = Bs + (wn * (BN / 2) + j * 16 + lr) * 64 + (((kk * 2 + (lq >> 1)) ^ fsw) << 4) + ((lq & 1) << 3);
+                        u32x2_t q;
+                        asm volatile("ds_read_b64 %0, %1" : "=v"(q) : "v"(ad) : "memory");
+                        bq8[kk][j] = q;
+                    }
+                } else {
 #pragma unroll
                 for (int j = 0; j < TN; ++j) bfr[kk][j] = lds_read128(Bs + blds_off(wn * (BN / 2) + j * 16 + lr, kk * 4 + lq));
+                }
             } else {
                 // 16-lane group lq owns k = 32 kk + 8 lq .. + 7: two transposed 4-row blocks; lane 4q+p of the group
                 // supplies the address of block row q, columns 4p .. 4p+3 and receives column (lane % 16)
@@ -418,6 +473,7 @@ __global__ __launch_bounds__(256) void cst_gemm_bf16_kernel(BGemmArgs g) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
         __builtin_amdgcn_sched_barrier(0);
+        widen(0);
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -427,6 +483,7 @@ __global__ __launch_bounds__(256) void cst_gemm_bf16_kernel(BGemmArgs g) {
         if constexpr (TT) read_half(1);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
+        widen(1);
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -819,7 +876,7 @@ extern "C" int cst_gemm_bf16(const void* A, long lda, const void* B, long ldb,
     CST_REQUIRE(!C || ldc >= N, "cst_gemm_bf16: ldc < N");
     CST_REQUIRE(!Cb || ldcb >= N, "cst_gemm_bf16: ldcb < N");
     CST_REQUIRE(act >= 0 && act <= 4 && (act < 3 || aux), "cst_gemm_bf16: bad activation / missing aux");
-    BGemmArgs g;
+    BGemmArgs g{};                                  // value-initialised: every pointer the entry point does not set is null
     g.A = (const bf16_t*)A; g.B = (const bf16_t*)B; g.A2 = nullptr; g.B2 = nullptr; g.C = C; g.Cb = (bf16_t*)Cb;
     g.bias = bias; g.addend = addend; g.aux = (const bf16_t*)aux;
     g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.ldcb = ldcb; g.ldadd = ldadd; g.ldaux = ldaux;
@@ -903,7 +960,7 @@ extern "C" int cst_gemm_bf16_tt(const void* A, long lda, const void* B, long ldb
                 "cst_gemm_bf16_tt: M=%d, N=%d must be multiples of 8 and K=%d a multiple of 64", M, N, K);
     CST_REQUIRE(lda >= M && ldb >= N && lda % 8 == 0 && ldb % 8 == 0 && ldc >= N && (((uintptr_t)A | (uintptr_t)B) & 15) == 0,
                 "cst_gemm_bf16_tt: operands must be 16-byte aligned, leading dimensions multiples of 8");
-    BGemmArgs g;
+    BGemmArgs g{};                                  // value-initialised: every pointer the entry point does not set is null
     g.A = (const bf16_t*)A; g.B = (const bf16_t*)B; g.A2 = nullptr; g.B2 = nullptr; g.C = C; g.Cb = nullptr;
     g.bias = nullptr; g.addend = nullptr; g.aux = nullptr;
     g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.ldcb = 0; g.ldadd = 0; g.ldaux = 0;
@@ -1062,7 +1119,7 @@ extern "C" int cst_gemm_bf16_lstm(const void* A, long lda, const void* B, long l
                     al16(workspace) && ((((uintptr_t)h_bf16 | (uintptr_t)h_bf16_2 | (uintptr_t)h_bf16_p2 | (uintptr_t)h_bf16_2_p2) & 7) == 0);
     CST_REQUIRE(al, "cst_gemm_bf16_lstm: every row pointer must be 16-byte aligned (leading dimensions multiples of 4)");
     hipStream_t st = (hipStream_t)stream;
-    BGemmArgs g;
+    BGemmArgs g{};                                  // value-initialised: every pointer the entry point does not set is null
     if (int rc = lstm_gemm_front("cst_gemm_bf16_lstm", g, A, B, A2, B2, lda, ldb, M, 4 * H, K, splitk, workspace, workspace_floats, st)) return rc;
     LstmEpi2 q;
     q.e[0] = LstmEpi{bias, addend, gates, c_prev, h_out, c_out, h_out2, (bf16_t*)h_bf16, (bf16_t*)h_bf16_2};
@@ -1153,7 +1210,7 @@ extern "C" int cst_gemm_bf16_lstm_bwd(const void* A, long lda, const void* B, lo
                     al16(workspace) && ((((uintptr_t)dgates_bf16 | (uintptr_t)dgates_bf16_2) & 7) == 0);
     CST_REQUIRE(al, "cst_gemm_bf16_lstm_bwd: every row pointer must be 16-byte aligned (leading dimensions multiples of 4)");
     hipStream_t st = (hipStream_t)stream;
-    BGemmArgs g;
+    BGemmArgs g{};                                  // value-initialised: every pointer the entry point does not set is null
     if (int rc = lstm_gemm_front("cst_gemm_bf16_lstm_bwd", g, A, B, A2, B2, lda, ldb, M, n_extra + H, K, splitk, workspace, workspace_floats, st)) return rc;
     LstmBwdEpi2 q;
     q.e[0] = LstmBwdEpi{gates, c_prev, c_new, dh_extra, dc_in, dgates, dc_prev, (bf16_t*)dgates_bf16};
@@ -1290,7 +1347,7 @@ extern "C" int cst_gemm_bf16_lstm_attn(const void* A, long lda, const void* B, l
     const size_t lds = sizeof(float) * ((size_t)L * H + H + 64);
     CST_REQUIRE(lds <= 160 * 1024, "cst_gemm_bf16_lstm_attn: memory tile of %zu bytes exceeds the 160 KiB LDS", lds);
     hipStream_t st = (hipStream_t)stream;
-    BGemmArgs g;
+    BGemmArgs g{};                                  // value-initialised: every pointer the entry point does not set is null
     if (int rc = lstm_gemm_front("cst_gemm_bf16_lstm_attn", g, A, B, nullptr, nullptr, lda, ldb, M, 4 * H, K, splitk, workspace, workspace_floats, st)) return rc;
     LstmAttnEpi q;
     q.slab = workspace; q.splits = g.splits; q.M = M; q.H = H;

@@ -563,6 +563,25 @@ extern "C" int cst_adam_step(float* p, const float* g, float* m, float* v, long 
     return CST_OK;
 }
 
+// zero fill as a kernel (see cst_common.h): 16-byte stores where the pointer allows, words otherwise
+__global__ __launch_bounds__(256) void zero_words_kernel(uint32_t* __restrict__ p, long n) {
+    const long n4 = ((reinterpret_cast<uintptr_t>(p) & 15) == 0) ? (n >> 2) : 0;
+    uint4* p4 = reinterpret_cast<uint4*>(p);
+    EW_LOOP(i, n4) p4[i] = make_uint4(0u, 0u, 0u, 0u);
+    for (long i = 4 * n4 + (long)blockIdx.x * EW_THREADS + threadIdx.x; i < n; i += (long)gridDim.x * EW_THREADS) p[i] = 0u;
+}
+int cst_zero_words(void* p, long n_words, hipStream_t st) {
+    if (n_words <= 0) return CST_OK;
+    long b = (n_words / 4 + EW_THREADS - 1) / EW_THREADS; if (b > 2048) b = 2048; if (b < 1) b = 1;
+    hipLaunchKernelGGL(zero_words_kernel, dim3((unsigned)b), dim3(EW_THREADS), 0, st, (uint32_t*)p, n_words);
+    return hipGetLastError() == hipSuccess ? CST_OK : CST_ERR_LAUNCH;
+}
+extern "C" int cst_zero(void* p, long n_bytes, void* stream) {
+    CST_REQUIRE(p && n_bytes >= 0 && n_bytes % 4 == 0 && ((uintptr_t)p & 3) == 0, "cst_zero: pointer and size must be 4-byte aligned");
+    if (cst_zero_words(p, n_bytes / 4, (hipStream_t)stream) != CST_OK) { cst_set_error("cst_zero: launch failed"); return CST_ERR_LAUNCH; }
+    return CST_OK;
+}
+
 // counters that live on the device so a captured graph advances them on every replay
 __global__ void add_i32_kernel(int* p, int inc) { if (threadIdx.x == 0 && blockIdx.x == 0) *p += inc; }
 extern "C" int cst_add_i32(int* p, int inc, void* stream) {

@@ -854,7 +854,7 @@ extern "C" int cst_colsum(const float* X, long ld, int M, int N, float* out, int
     const int rps = cst_div_up(M, splits);
     const int use_atomic = splits > 1;
     if (use_atomic && !accumulate) {
-        if (hipMemsetAsync(out, 0, sizeof(float) * N, st) != hipSuccess) { cst_set_error("cst_colsum: memset failed"); return CST_ERR_LAUNCH; }
+        if (cst_zero_words(out, N, st) != CST_OK) { cst_set_error("cst_colsum: zero fill failed"); return CST_ERR_LAUNCH; }
     }
     hipLaunchKernelGGL(colsum_kernel, dim3(cg, splits), dim3(256), 0, st, X, ld, M, N, out, rps, use_atomic, accumulate);
     CST_LAUNCH_CHECK("cst_colsum");

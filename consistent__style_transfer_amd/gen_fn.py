@@ -143,7 +143,7 @@ class GeneratorFn(torch.autograd.Function):
         genc = _new(dev, 2, Lp, B, 4 * H)             # gate activations
         cenc = _new(dev, 2, Lp, B, H)
         c_cat = _new(dev, B, 2 * H)
-        zeros_c = torch.zeros(B, H, device=dev, dtype=torch.float32)
+        zeros_c = ops.zeros(B, H, device=dev)
         mem2 = memory.view(B, Lp * 2 * H)
         W_ = Hd + 2 * H
         hprevb = _i16(dev, 2, B, Lp, H) if enc_b else None
@@ -199,7 +199,7 @@ class GeneratorFn(torch.autograd.Function):
         wcat = torch.cat([P["decoder.weight_ih_l0"], P["decoder.weight_hh_l0"]], dim=1).contiguous()   # (4Hd, E+Hd)
         bdec = axpby(P["decoder.bias_ih_l0"].view(1, -1), 1.0, P["decoder.bias_hh_l0"].view(1, -1), 1.0).view(-1)
         XH = _new(dev, T, B, E + Hd)                  # [x_t | h_{t-1}]
-        zero_ids = torch.zeros(B, device=dev, dtype=torch.int64)
+        zero_ids = ops.zeros(B, device=dev, dtype=torch.int64)
         embed_gather(P["start_embedding.weight"], XH[0][:, :E], ids_a=zero_ids)
         axpby(h0d, 1.0, out=XH[0][:, E:])
         gdec = _new(dev, T, B, 4 * Hd)
@@ -296,8 +296,8 @@ class GeneratorFn(torch.autograd.Function):
         out2 = out.view(B, T * V)
         r12 = r1.view(B, T * Hd)
         G = {k: None for k in PARAM_KEYS}
-        dE = torch.zeros(V, E, device=dev, dtype=torch.float32)
-        dmem = torch.zeros(B, Lp, 2 * H, device=dev, dtype=torch.float32)
+        dE = ops.zeros(V, E, device=dev)
+        dmem = ops.zeros(B, Lp, 2 * H, device=dev)
         W_ = Hd + 2 * H
         if2 = iffn.view(B, T * W_)
         dpre1 = _new(dev, B, T, Hd)
@@ -408,7 +408,7 @@ class GeneratorFn(torch.autograd.Function):
         dXH = dXH_all[0]
         # step 0 input was the start embedding (no dropout), h_{-1} the style embedding
         G["start_embedding.weight"] = colsum(dXH[:, :E]).view(1, E)
-        dstyle = torch.zeros_like(P["style_embedding.weight"])
+        dstyle = ops.zeros_like(P["style_embedding.weight"])
         embed_scatter_add(dstyle, dXH[:, E:], ids_a=label)
         G["style_embedding.weight"] = dstyle
         # transfer (rnn.py:68)
@@ -497,7 +497,7 @@ class GeneratorFn(torch.autograd.Function):
             dbe = colsum(dgf)
             G["encoder.bias_ih_l0" + suf] = dbe
             G["encoder.bias_hh_l0" + suf] = dbe.clone()
-        dstyle_e = torch.zeros_like(P["enc_style_embedding.weight"])
+        dstyle_e = ops.zeros_like(P["enc_style_embedding.weight"])
         embed_scatter_add(dstyle_e, dh0cat, ids_a=label_i)
         G["enc_style_embedding.weight"] = dstyle_e
         embed_scatter_add(dE, demb, ids_a=ids_in, drop=in_drop)

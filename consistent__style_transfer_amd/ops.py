@@ -5,6 +5,7 @@ PyTorch supplies device memory, streams and the autograd tape only -- every numb
 by libcst_hip.so.  Nothing here falls back to torch arithmetic.
 """
 import math
+import os
 import weakref
 
 import torch
@@ -52,6 +53,23 @@ class Drop:
 
 
 NO_DROP = Drop()
+
+
+def zeros(*shape, device, dtype=torch.float32):
+    """torch.zeros for buffers created inside forward / backward passes that may be captured: torch.empty + cst_zero (a kernel).
+    torch.zeros / Tensor.zero_() may lower to hipMemsetAsync, whose graph node does not keep its stream position when the
+    autograd thread issues it under segmented capture (see cst_common.h)."""
+    t = torch.empty(*shape, device=device, dtype=dtype)
+    nbytes = t.numel() * t.element_size()
+    if nbytes % 4 == 0 and nbytes > 0 and t.is_cuda:
+        call("cst_zero", t, nbytes)
+    else:
+        t.zero_()
+    return t
+
+
+def zeros_like(x):
+    return zeros(*x.shape, device=x.device, dtype=x.dtype)
 
 
 def _ld(t):
@@ -139,7 +157,7 @@ def weight_bf16(W):
         # inside one capture the copies made earlier in the same capture stay valid until the next
         # optimizer step of the group (forward and backward of a layer, the decodes of one stage step)
         hit = _WCACHE_CAPTURE.get(key)
-        if hit is not None and hit[0]() is W and hit[1] == ver:
+        if hit is not None and hit[0]() is W and hit[1] == ver and not os.environ.get("CST_DBG_NOCAPCACHE"):
             return hit[2], hit[3]
         rm, tr = cast_bf16(W.detach())
         _WCACHE_CAPTURE[key] = (weakref.ref(W), ver, rm, tr)
@@ -435,6 +453,8 @@ def _side_put(t, tb):
 def _side_take(t):
     """Keyed by storage address and element count (views of the producer's tensor qualify)."""
     hit = _SIDE_BF16.pop((t.data_ptr(), t.numel()), None)
+    if os.environ.get("CST_DBG_NOSIDE"):
+        return None
     return hit[1] if hit is not None and hit[0]() is not None else None
 
 
@@ -568,7 +588,7 @@ class EncoderLayerBf16Fn(torch.autograd.Function):
             y1b, y1t = cast_bf16(y1, want_t=want_t)
         l1_b16, l1_t = weight_bf16(l1_w)
         Fp = _up64(F)
-        hb = (torch.zeros if Fp != F else torch.empty)(T, Fp, device=dev, dtype=torch.int16)
+        hb = (zeros if Fp != F else torch.empty)(T, Fp, device=dev, dtype=torch.int16)
         gemm_bf16(y1b, l1_b16, T, F, Cb=hb, bias=l1_b, act=1, drop=drop.at(sb + 2))
         ht = cast_bf16(hb[:, :F], want_rm=False)[1] if want_t else None
         l2_b16, l2_t = weight_bf16(l2_w)
@@ -602,7 +622,7 @@ class EncoderLayerBf16Fn(torch.autograd.Function):
             dz2, dn2w, dn2b = _ln_bwd(dy2, z2, m2, r2, n2_w, wg)
             dfb, dft = cast_bf16(dz2, want_t=want_t, drop=drop.at(sb + 3))              # dropout2' fused into the cast
         Fp = _up64(F)
-        dhb = (torch.zeros if Fp != F else torch.empty)(T, Fp, device=dev, dtype=torch.int16)
+        dhb = (zeros if Fp != F else torch.empty)(T, Fp, device=dev, dtype=torch.int16)
         gemm_bf16(dfb, l2_t, T, F, Cb=dhb, aux=hb, act=3, gate_scale=drop.scale)       # relu' and dropout' fused
         dy1 = gemm_bf16(dhb, l1_t, T, d, C=new(T, d), addend=dz2)
         if fuse_b:
@@ -688,9 +708,9 @@ class TpsEmbedFn(torch.autograd.Function):
         dx = dx.contiguous()
         dev = dx.device
         wg = ctx.needs_input_grad[2]
-        dEtok = torch.zeros(V, d, device=dev, dtype=torch.float32) if wg else None
-        dEpos = torch.zeros(npos, d, device=dev, dtype=torch.float32) if wg else None
-        dEseg = torch.zeros(2, d, device=dev, dtype=torch.float32) if (wg and has_seg) else None
+        dEtok = zeros(V, d, device=dev) if wg else None
+        dEpos = zeros(npos, d, device=dev) if wg else None
+        dEseg = zeros(2, d, device=dev) if (wg and has_seg) else None
         grads = [None, None]
         dpre1 = None
         off = 0
@@ -942,7 +962,7 @@ class EmbedFn(torch.autograd.Function):
         shape, transposed = ctx.cfg
         if not ctx.needs_input_grad[1]:
             return None, None, None
-        dt = torch.zeros(*shape, device=dout.device, dtype=torch.float32)
+        dt = zeros(*shape, device=dout.device)
         embed_scatter_add(dt, dout.contiguous(), ids_a=ids, transposed=transposed)
         return None, dt, None
 

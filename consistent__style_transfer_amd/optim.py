@@ -115,7 +115,7 @@ class FlatGroup:
         grads = [p.grad for p in self.params]
         if not accumulate:
             if any(g is None for g in grads):
-                self.flat_g.zero_()
+                call("cst_zero", self.flat_g, 4 * self.total)
         src_host, srcs = self._src_host, self.srcs
         if self.flat_p.is_cuda and torch.cuda.is_current_stream_capturing():
             # a captured graph re-reads the pinned table on every replay: each capture needs its own
@@ -194,7 +194,7 @@ class FlatGroup:
              float(self.betas[0]), float(self.betas[1]), float(self.eps), self.step_dev)
 
     def zero_grad(self):
-        self.flat_g.zero_()
+        call("cst_zero", self.flat_g, 4 * self.total)      # a kernel, not a memset node (cst_common.h)
         self.has_grad = False
 
     def grad_of(self, p):
@@ -207,7 +207,7 @@ def clip_groups(groups, max_norm, scratch):
     live = [g for g in groups if g.has_grad]
     if not live or max_norm is None or max_norm <= 0:
         return
-    scratch.zero_()
+    call("cst_zero", scratch, 4 * scratch.numel())
     for g in live:
         g.sumsq_into(scratch)
     for g in live:

@@ -155,6 +155,10 @@ int cst_layernorm_bwd_b(const float* dy, const float* z, const float* mean, cons
                         float* workspace, long workspace_floats, int T, int d,
                         void* dz_bf16, long lddzb, float drop_p, uint32_t drop_seed, uint32_t drop_stream, const void* drop_seed_dev,
                         float* dparams3, void* stream);
+/* Zero n_bytes (multiple of 4) at p with a kernel launch: the zero-initialised gradient accumulators of the backward passes
+ * (embedding scatter targets, d memory, ...).  A kernel, not hipMemsetAsync: memset nodes issued by the autograd thread lose
+ * their place in the stream order under segmented hipGraph capture (thread_local capture mode next to RCCL). */
+int cst_zero(void* p, long n_bytes, void* stream);
 /* out[c] (+)= sum_r X[r,c]  (bias gradients). */
 int cst_colsum(const float* X, long ld, int M, int N, float* out, int accumulate, void* stream);
 /* out[0] (+)= scale * sum(in[0..n)), one block, deterministic. */
