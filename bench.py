@@ -269,7 +269,7 @@ def main():
     ap.add_argument("--workload", default=HEADLINE, choices=sorted(WORKLOADS))
     ap.add_argument("--no-other-workloads", action="store_true", help="skip the `workloads` leg (BASELINE configs[1], configs[2], reference sizes)")
     ap.add_argument("--no-f32", action="store_true", help="skip the exact-fp32-mode throughput figure")
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "f32", "fp8w"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying hipGraphs")
@@ -458,6 +458,20 @@ def main():
             ops.set_precision(args.precision)
         torch.cuda.empty_cache()
 
+    # BASELINE configs[4]: the same workload with fp8 (e4m3) encoder-layer weights, bf16 activations
+    fp8w_mode = None
+    if rank == 0 and world == 1 and use_graph and args.precision == "bf16" and not args.no_f32:
+        ops.set_precision("fp8w")
+        try:
+            ms8, s8, b8, p8 = time_pipeline(w, device, rank, 5, 2)
+            fp8w_mode = {"ms_per_step": ms8, "value": w["B"] / (ms8 * 1e-3), "unit": "sentences/s", "steps": 5, "warmup": 2,
+                         "note": "same workload with --precision fp8w: QKV / out-projection / FFN weights of the critics in fp8 e4m3 with "
+                                 "per-output-channel scales, widened to bf16 in registers (W8A16)"}
+            del s8, b8, p8
+        finally:
+            ops.set_precision(args.precision)
+        torch.cuda.empty_cache()
+
     # the other BASELINE configs, same step definition, fewer steps (outside the timed region of the headline)
     others = None
     if rank == 0 and world == 1 and use_graph and not args.no_other_workloads:
@@ -481,12 +495,12 @@ def main():
             "metric": "train sentences/sec on Yelp-shaped batches (pretrain+warmup+optimize steps per batch)",
             "value": value, "unit": "sentences/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": args.precision if args.precision == "bf16" else "f32", "data": "synthetic",
+            "dtype": {"bf16": "bf16", "f32": "f32", "fp8w": "bf16 (fp8 e4m3 encoder-layer weights)"}[args.precision], "data": "synthetic",
             "config": {"workload": args.workload, "per_gpu_batch": w["B"], "global_batch": w["B"] * world,
                        "seq_len": w["L"], "vocab": w["V"], "critic_layers": w["n_layer"], "d_model": w["d_model"],
                        "parallelism": f"dp{world}", "stages": "pretrain+warmup+optimize(G+D)", "weights": "random-init",
                        "launch": ("hipGraph replay" if world == 1 else "hipGraph segments + eager all-reduce") if use_graph else "eager"},
-            "roofline": roofline, "cpu_baseline": cpu, "per_stage": per_stage, "f32_mode": f32_mode, "workloads": others,
+            "roofline": roofline, "cpu_baseline": cpu, "per_stage": per_stage, "f32_mode": f32_mode, "fp8w_mode": fp8w_mode, "workloads": others,
         }
         print(json.dumps(line), flush=True)
     if world > 1:

@@ -39,8 +39,9 @@ def build_parser():
     parser.add_argument('--n_layer', type=int, default=None, help="encoder layers of MLM / Matcher (reference constant 6)")
     parser.add_argument('--d_model', type=int, default=None, help="width of MLM / Matcher (reference constant 512)")
     parser.add_argument('--n_head', type=int, default=None, help="attention heads (reference constant 8)")
-    parser.add_argument('--precision', type=str, default="bf16", choices=["bf16", "f32"],
-                        help="MFMA arithmetic of the GEMMs: bf16 operands / fp32 accumulate, or exact fp32")
+    parser.add_argument('--precision', type=str, default="bf16", choices=["bf16", "f32", "fp8w"],
+                        help="MFMA arithmetic of the GEMMs: bf16 operands / fp32 accumulate, exact fp32, or bf16 with fp8 (e4m3, "
+                             "per-output-channel scale) weights in the encoder layers' QKV / out-projection / FFN products")
     parser.add_argument('--no_graph', action="store_true", help="launch kernels eagerly instead of replaying hipGraphs")
     parser.add_argument('--seed', type=int, default=0, help="base seed (data order, noise, dropout, coins)")
     parser.add_argument('--max_steps', type=int, default=None, help="stop after this many training batches (smoke runs)")

@@ -841,12 +841,12 @@ static int bgemm_big_launch_t(const BGemmArgs& g, hipStream_t st) {
 }
 
 
-template <int BM, int BN, int NSTAGE, bool TT = false>
+template <int BM, int BN, int NSTAGE, bool TT = false, bool BF8 = false>
 static int bgemm_launch(const BGemmArgs& g, hipStream_t st) {
-    const size_t lds = (size_t)NSTAGE * (BM + BN) * BROW;
+    const size_t lds = (size_t)NSTAGE * (BM * BROW + BN * (BF8 ? 64 : BROW));
     static bool attr_done = false;
     if (!attr_done && lds > 64 * 1024) {
-        (void)hipFuncSetAttribute((const void*)cst_gemm_bf16_kernel<BM, BN, NSTAGE, TT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)cst_gemm_bf16_kernel<BM, BN, NSTAGE, TT, BF8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_done = true;
     }
     dim3 grid(cst_div_up(g.M, BM) * cst_div_up(g.N, BN), g.splits, g.A2 ? 2 : 1), block(256);
@@ -856,9 +856,9 @@ static int bgemm_launch(const BGemmArgs& g, hipStream_t st) {
         // TT products are recorded with a negative K (C = A^T B: the contraction index is the row index of both operands)
         cst_prof_push_shape(ea, eb, 2.0 * g.M * g.N * g.K, 2.0 * ((double)g.M * g.K + (double)g.N * g.K) + (g.C ? 4.0 : 0.0) * g.M * g.N + (g.Cb ? 2.0 : 0.0) * g.M * g.N, 1,
                             g.M, g.N, TT ? -g.K : g.K);
-        hipExtLaunchKernelGGL((cst_gemm_bf16_kernel<BM, BN, NSTAGE, TT>), grid, block, lds, st, ea, eb, 0, g);
+        hipExtLaunchKernelGGL((cst_gemm_bf16_kernel<BM, BN, NSTAGE, TT, BF8>), grid, block, lds, st, ea, eb, 0, g);
     } else {
-        hipLaunchKernelGGL((cst_gemm_bf16_kernel<BM, BN, NSTAGE, TT>), grid, block, lds, st, g);
+        hipLaunchKernelGGL((cst_gemm_bf16_kernel<BM, BN, NSTAGE, TT, BF8>), grid, block, lds, st, g);
     }
     return 0;
 }
@@ -991,6 +991,96 @@ extern "C" int cst_gemm_bf16_tt(const void* A, long lda, const void* B, long ldb
         int rb = (int)((mn + 255) / 256); if (rb > 2048) rb = 2048;
         static const bool no_batch = getenv("CST_REDUCE_SERIAL") != nullptr;      // A/B switch for tools/splitk_bench_bf16.py
         if (g.splits >= 5 && !no_batch) hipLaunchKernelGGL(cst_gemm_bf16_reduce<true>, dim3(rb), dim3(256), 0, st, g);
+        else hipLaunchKernelGGL(cst_gemm_bf16_reduce<false>, dim3(rb), dim3(256), 0, st, g);
+        CST_LAUNCH_CHECK("cst_gemm_bf16_reduce");
+    }
+    return CST_OK;
+}
+
+// =============================================================================================
+// W8A16: fp8 (e4m3, OCP) weights with one fp32 scale per output channel, bf16 activations, fp32 accumulation
+// (BASELINE configs[4]).  cst_cast_fp8_rows quantises W [R, C] row by row: scale[r] = max|W[r, :]| / 448, q = rne(W / scale)
+// (448 = largest e4m3 magnitude), columns C .. ldo-1 are written as 0 so that ldo can be the 64-padded K of the GEMM.
+// The forward products use the copy of W itself (rows = output channels), the dgrad products a second copy of W^T quantised
+// along ITS rows (the layer's input features): each product's scale then sits on the GEMM's output column, where the epilogue
+// applies it.  Weight-gradient products involve activations only and stay bf16.
+// =============================================================================================
+__global__ __launch_bounds__(256) void cast_fp8_rows_kernel(const float* __restrict__ W, long ldw, long colstride, int R, int C,
+                                                            unsigned char* __restrict__ out, long ldo, float* __restrict__ scale) {
+    __shared__ float red[16];
+    const int r = blockIdx.x;
+    const float* row = W + (long)r * ldw;                  // element (r, c) = row[c * colstride]: colstride != 1 quantises a transposed view
+    float amax = 0.f;
+    for (int c = threadIdx.x; c < C; c += 256) amax = fmaxf(amax, fabsf(row[(long)c * colstride]));
+    amax = block_max(amax, red);
+    const float sc = amax > 0.f ? amax / 448.f : 1.f;
+    const float inv = 1.f / sc;
+    if (threadIdx.x == 0) scale[r] = sc;
+    for (int c4 = threadIdx.x * 4; c4 < ldo; c4 += 1024) {
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int c = c4 + e;
+            v[e] = c < C ? fminf(fmaxf(row[(long)c * colstride] * inv, -448.f), 448.f) : 0.f;
+        }
+        int pk = __builtin_amdgcn_cvt_pk_fp8_f32(v[0], v[1], 0, false);
+        pk = __builtin_amdgcn_cvt_pk_fp8_f32(v[2], v[3], pk, true);
+        *reinterpret_cast<int*>(out + (long)r * ldo + c4) = pk;
+    }
+}
+
+extern "C" int cst_cast_fp8_rows(const float* W, long ldw, long colstride, int R, int C, void* out, long ldo, float* scale, void* stream) {
+    CST_REQUIRE(W && out && scale && R > 0 && C > 0 && ldo >= C && ldo % 16 == 0 && colstride >= 1, "cst_cast_fp8_rows: bad arguments (ldo must be a multiple of 16 >= C)");
+    CST_REQUIRE(((uintptr_t)out & 15) == 0, "cst_cast_fp8_rows: output must be 16-byte aligned");
+    hipLaunchKernelGGL(cast_fp8_rows_kernel, dim3(R), dim3(256), 0, (hipStream_t)stream, W, ldw, colstride, R, C, (unsigned char*)out, ldo, scale);
+    CST_LAUNCH_CHECK("cst_cast_fp8_rows");
+    return CST_OK;
+}
+
+// C / Cb [M, N] = epi(alpha * bscale[n] * A[M, K] . Bq[N, K]^T): A bf16 (K padded to 64), Bq fp8 e4m3 [N, ldb bytes], everything
+// else as cst_gemm_bf16 (64 x 128 tiles, 2-stage ring, split-K through the workspace).
+extern "C" int cst_gemm_bf16_w8(const void* A, long lda, const void* Bq, long ldb, const float* bscale,
+                                float* C, long ldc, void* Cb, long ldcb, int M, int N, int K,
+                                const float* bias, const float* addend, long ldadd, const void* aux, long ldaux,
+                                int act, float gate_scale, float alpha, int accumulate,
+                                float drop_p, uint32_t drop_seed, uint32_t drop_stream, const void* drop_seed_dev,
+                                int splitk, float* workspace, long workspace_floats, void* stream) {
+    CST_REQUIRE(A && Bq && bscale && (C || Cb), "cst_gemm_bf16_w8: null operand");
+    CST_REQUIRE(M > 0 && N > 0 && K > 0 && K % 64 == 0, "cst_gemm_bf16_w8: K=%d must be a positive multiple of 64 (zero-padded operands)", K);
+    CST_REQUIRE(lda >= K && ldb >= K && lda % 8 == 0 && ldb % 16 == 0, "cst_gemm_bf16_w8: lda (elements) / ldb (bytes) must be >= K, multiples of 8 / 16");
+    CST_REQUIRE((((uintptr_t)A | (uintptr_t)Bq) & 15) == 0, "cst_gemm_bf16_w8: operands must be 16-byte aligned");
+    CST_REQUIRE((!C || ldc >= N) && (!Cb || ldcb >= N), "cst_gemm_bf16_w8: ldc / ldcb < N");
+    CST_REQUIRE(act >= 0 && act <= 4 && (act < 3 || aux), "cst_gemm_bf16_w8: bad activation / missing aux");
+    BGemmArgs g{};
+    g.A = (const bf16_t*)A; g.B = (const bf16_t*)Bq; g.C = C; g.Cb = (bf16_t*)Cb;
+    g.bias = bias; g.addend = addend; g.aux = (const bf16_t*)aux; g.bscale = bscale;
+    g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.ldcb = ldcb; g.ldadd = ldadd; g.ldaux = ldaux;
+    g.M = M; g.N = N; g.K = K; g.act = act; g.alpha = alpha; g.gate_scale = gate_scale; g.accumulate = accumulate;
+    g.drop = cst_make_drop(drop_p, drop_seed, drop_stream, drop_seed_dev);
+    const long tiles = (long)cst_div_up(M, 64) * cst_div_up(N, 128);
+    int splits = 1;
+    if (splitk > 1) splits = splitk;
+    else if (splitk == 0 && workspace && tiles < 192 && K >= 512) {
+        splits = (int)((384 + tiles - 1) / tiles);
+        if (splits > K / 256) splits = K / 256;
+    }
+    g.k_per_split = K;
+    if (splits > 1) {
+        int kps = cst_div_up(cst_div_up(K, splits), 64) * 64;
+        splits = cst_div_up(K, kps);
+        while (splits > 1 && (long)splits * M * N > workspace_floats) { kps += 64; splits = cst_div_up(K, kps); }
+        g.k_per_split = kps;
+    }
+    if (splits <= 1) { splits = 1; g.k_per_split = K; }
+    CST_REQUIRE(splits == 1 || workspace, "cst_gemm_bf16_w8: split-K needs a workspace");
+    g.splits = splits; g.slab = workspace;
+    hipStream_t st = (hipStream_t)stream;
+    bgemm_launch<64, 128, 2, false, true>(g, st);
+    CST_LAUNCH_CHECK("cst_gemm_bf16_w8");
+    if (splits > 1) {
+        long mn = ((long)M * N + 3) / 4;
+        int rb = (int)((mn + 255) / 256); if (rb > 2048) rb = 2048;
+        if (g.splits >= 5) hipLaunchKernelGGL(cst_gemm_bf16_reduce<true>, dim3(rb), dim3(256), 0, st, g);
         else hipLaunchKernelGGL(cst_gemm_bf16_reduce<false>, dim3(rb), dim3(256), 0, st, g);
         CST_LAUNCH_CHECK("cst_gemm_bf16_reduce");
     }

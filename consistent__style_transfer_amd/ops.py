@@ -20,18 +20,21 @@ STREAM_TFM = 1000
 STREAM_CLS = 2000
 STREAM_DISC = 3000
 
-_STATE = {"f32": False}
+_STATE = {"f32": False, "fp8w": False}
 
 
 def set_precision(name):
-    """'bf16' (v_mfma_f32_16x16x32_bf16, fp32 accumulate) or 'f32' (exact v_mfma_f32_16x16x4_f32)."""
-    if name not in ("bf16", "f32"):
+    """'bf16' (v_mfma_f32_16x16x32_bf16, fp32 accumulate), 'f32' (exact v_mfma_f32_16x16x4_f32), or 'fp8w' = bf16 everywhere
+    except that the weights of the encoder layers' Linear products (packed QKV, out-projection, FFN) are fp8 e4m3 with a
+    per-output-channel scale, widened to bf16 in registers (BASELINE configs[4]: "fp8 weight MFMA + bf16 activations")."""
+    if name not in ("bf16", "f32", "fp8w"):
         raise ValueError(name)
     _STATE["f32"] = name == "f32"
+    _STATE["fp8w"] = name == "fp8w"
 
 
 def get_precision():
-    return "f32" if _STATE["f32"] else "bf16"
+    return "f32" if _STATE["f32"] else ("fp8w" if _STATE["fp8w"] else "bf16")
 
 
 class Drop:
@@ -157,7 +160,7 @@ def weight_bf16(W):
         # inside one capture the copies made earlier in the same capture stay valid until the next
         # optimizer step of the group (forward and backward of a layer, the decodes of one stage step)
         hit = _WCACHE_CAPTURE.get(key)
-        if hit is not None and hit[0]() is W and hit[1] == ver and not os.environ.get("CST_DBG_NOCAPCACHE"):
+        if hit is not None and hit[0]() is W and hit[1] == ver:
             return hit[2], hit[3]
         rm, tr = cast_bf16(W.detach())
         _WCACHE_CAPTURE[key] = (weakref.ref(W), ver, rm, tr)
@@ -171,10 +174,60 @@ def weight_bf16(W):
     return rm, tr
 
 
+def cast_fp8_rows(W, transposed=False):
+    """fp32 [N, K] -> (fp8 e4m3 bytes [N, up64(K)], fp32 scale [N]); transposed: the same for W^T ([K, up64(N)], scale [K])."""
+    N, K = W.shape
+    R, C = (K, N) if transposed else (N, K)
+    q = torch.empty(R, _up64(C), device=W.device, dtype=torch.uint8)
+    sc = torch.empty(R, device=W.device, dtype=torch.float32)
+    if transposed:
+        call("cst_cast_fp8_rows", W, 1, _ld(W), R, C, q, q.stride(0), sc)        # element (r, c) of W^T = W[c, r]
+    else:
+        call("cst_cast_fp8_rows", W, _ld(W), 1, R, C, q, q.stride(0), sc)
+    return q, sc
+
+
+_W8CACHE = {}
+_W8CACHE_CAPTURE = {}
+
+
+def weight_fp8(W):
+    """(Wq, scale, WqT, scaleT) of an encoder-layer weight, cached exactly like weight_bf16 (per optimizer version; recast
+    inside every hipGraph capture; frozen critics once)."""
+    grp = getattr(W, "_cst_group", None)
+    capturing = torch.cuda.is_current_stream_capturing()
+    ver = (W._version, grp.version if grp is not None else 0, W.data_ptr(), tuple(W.shape))
+    key = id(W)
+    cache = _W8CACHE_CAPTURE if (grp is not None and capturing) else _W8CACHE
+    hit = cache.get(key)
+    if hit is not None and hit[0]() is W and hit[1] == ver:
+        return hit[2]
+    Wd = W.detach()
+    out = (*cast_fp8_rows(Wd), *cast_fp8_rows(Wd, transposed=True))
+    if grp is not None and capturing:
+        _W8CACHE_CAPTURE[key] = (weakref.ref(W), ver, out)
+    elif not capturing:
+        _W8CACHE[key] = (weakref.ref(W, lambda _r, k=key: _W8CACHE.pop(k, None)), ver, out)
+    return out
+
+
+def gemm_bf16_w8(Ab, Bq, bscale, M, N, C=None, Cb=None, bias=None, addend=None, aux=None, act=0, gate_scale=1.0, alpha=1.0,
+                 drop=NO_DROP, splitk=0, accumulate=False):
+    """C / Cb [M,N] = epi(alpha * bscale[n] * Ab[M,Kp] Bq[N,Kp]^T); Ab bf16 from cast_bf16, Bq fp8 from cast_fp8_rows."""
+    Kp = Ab.shape[1]
+    assert Bq.shape[1] == Kp and Ab.dtype == torch.int16 and Bq.dtype == torch.uint8 and Bq.shape[0] >= N
+    call("cst_gemm_bf16_w8", Ab, Ab.stride(0), Bq, Bq.stride(0), bscale, C, _ld(C) if C is not None else 0,
+         Cb, Cb.stride(0) if Cb is not None else 0, M, N, Kp, bias, addend, _ld(addend) if addend is not None else 0,
+         aux, aux.stride(0) if aux is not None else 0, act, float(gate_scale), float(alpha), int(accumulate), *drop.args(),
+         splitk, _workspace(Ab.device), WS_FLOATS)
+    return C if C is not None else Cb
+
+
 def capture_scope_reset():
     """Called by graphs.GraphedStep right before and right after a capture: copies cached during a
     capture live in that graph's private pool and mean nothing to any other capture or to eager code."""
     _WCACHE_CAPTURE.clear()
+    _W8CACHE_CAPTURE.clear()
     _SIDE_BF16.clear()
 
 
@@ -453,8 +506,6 @@ def _side_put(t, tb):
 def _side_take(t):
     """Keyed by storage address and element count (views of the producer's tensor qualify)."""
     hit = _SIDE_BF16.pop((t.data_ptr(), t.numel()), None)
-    if os.environ.get("CST_DBG_NOSIDE"):
-        return None
     return hit[1] if hit is not None and hit[0]() is not None else None
 
 
@@ -542,6 +593,23 @@ def _gout(W):
     return grp.grad_view(W) if (grp is not None and grp.direct) else None
 
 
+def _wops(W):
+    """B operands of the two products a Linear weight W [N, K] takes part in: (forward, dgrad), each either ("b", bf16 copy) or,
+    in fp8w mode, ("q", fp8 copy, per-output-column scale)."""
+    if _STATE["fp8w"]:
+        q, sc, qt, sct = weight_fp8(W)
+        return ("q", q, sc), ("q", qt, sct)
+    b, t = weight_bf16(W)
+    return ("b", b), ("b", t)
+
+
+def _mm(Ab, opnd, M, N, **kw):
+    if opnd[0] == "q":
+        kw.pop("tile", None)
+        return gemm_bf16_w8(Ab, opnd[1], opnd[2], M, N, **kw)
+    return gemm_bf16(Ab, opnd[1], M, N, **kw)
+
+
 class EncoderLayerBf16Fn(torch.autograd.Function):
     """The same layer as EncoderLayerFn on the bf16-operand GEMMs (cst_gemm_bf16 / cst_gemm_bf16_tt, direct-to-LDS
     ring).  Forward and dgrad products read K-contiguous bf16 copies (activations cast once, weights cached per
@@ -568,8 +636,8 @@ class EncoderLayerBf16Fn(torch.autograd.Function):
         xt = None
         if xb is None:
             xb, xt = cast_bf16(x, want_t=want_t)
-        inw_b, inw_t = weight_bf16(in_w)
-        qkv = gemm_bf16(xb, inw_b, T, 3 * d, C=new(T, 3 * d), bias=in_b)
+        inw_b, inw_t = _wops(in_w)
+        qkv = _mm(xb, inw_b, T, 3 * d, C=new(T, 3 * d), bias=in_b)
         att, lse = new(T, d), new(B * H * S)
         if fuse_b:
             attb, attt = newb(T, d), None
@@ -577,8 +645,8 @@ class EncoderLayerBf16Fn(torch.autograd.Function):
         else:
             call("cst_mha_fwd", qkv, att, lse, B, S, H, d // H, *drop.at(sb + 0).args())
             attb, attt = cast_bf16(att, want_t=want_t)
-        outw_b, outw_t = weight_bf16(out_w)
-        z1 = gemm_bf16(attb, outw_b, T, d, C=new(T, d), bias=out_b)
+        outw_b, outw_t = _wops(out_w)
+        z1 = _mm(attb, outw_b, T, d, C=new(T, d), bias=out_b)
         y1, m1, r1 = new(T, d), new(T), new(T)
         if fuse_b:
             y1b, y1t = newb(T, d), None
@@ -586,13 +654,13 @@ class EncoderLayerBf16Fn(torch.autograd.Function):
         else:
             _ln_fwd(z1, x, n1_w, n1_b, drop.at(sb + 1), z1, y1, m1, r1)
             y1b, y1t = cast_bf16(y1, want_t=want_t)
-        l1_b16, l1_t = weight_bf16(l1_w)
+        l1_b16, l1_t = _wops(l1_w)
         Fp = _up64(F)
         hb = (zeros if Fp != F else torch.empty)(T, Fp, device=dev, dtype=torch.int16)
-        gemm_bf16(y1b, l1_b16, T, F, Cb=hb, bias=l1_b, act=1, drop=drop.at(sb + 2))
+        _mm(y1b, l1_b16, T, F, Cb=hb, bias=l1_b, act=1, drop=drop.at(sb + 2))
         ht = cast_bf16(hb[:, :F], want_rm=False)[1] if want_t else None
-        l2_b16, l2_t = weight_bf16(l2_w)
-        z2 = gemm_bf16(hb, l2_b16, T, d, C=new(T, d), bias=l2_b)
+        l2_b16, l2_t = _wops(l2_w)
+        z2 = _mm(hb, l2_b16, T, d, C=new(T, d), bias=l2_b)
         y2, m2, r2 = new(T, d), new(T), new(T)
         if fuse_b:
             y2b = newb(T, d)
@@ -602,14 +670,16 @@ class EncoderLayerBf16Fn(torch.autograd.Function):
             _ln_fwd(z2, y1, n2_w, n2_b, drop.at(sb + 3), z2, y2, m2, r2)
         # operands of the weight gradients: row-major copies (tt) or transposed copies
         wx, watt, wy1, wh = (xb, attb, y1b, hb) if tt else (xt, attt, y1t, ht)
-        ctx.save_for_backward(wx, watt, wy1, wh, hb, inw_t, outw_t, l1_t, l2_t, n1_w, n2_w, qkv, lse, z1, m1, r1, z2, m2, r2)
+        ctx.save_for_backward(wx, watt, wy1, wh, hb, n1_w, n2_w, qkv, lse, z1, m1, r1, z2, m2, r2)
+        ctx.wt = (inw_t, outw_t, l1_t, l2_t)              # dgrad operands: ("b", bf16 W^T) or ("q", fp8 W^T, scale)
         ctx.cfg = (B, S, H, drop, sb, T, d, F, wg, tt, fuse_b)
         ctx.wrefs = (in_w, out_w, l1_w, l2_w)             # parameters (not saved tensors): only to find their gradient slots
         return y2
 
     @staticmethod
     def backward(ctx, dy2):
-        wx, watt, wy1, wh, hb, inw_t, outw_t, l1_t, l2_t, n1_w, n2_w, qkv, lse, z1, m1, r1, z2, m2, r2 = ctx.saved_tensors
+        wx, watt, wy1, wh, hb, n1_w, n2_w, qkv, lse, z1, m1, r1, z2, m2, r2 = ctx.saved_tensors
+        inw_t, outw_t, l1_t, l2_t = ctx.wt
         B, S, H, drop, sb, T, d, F, wg, tt, fuse_b = ctx.cfg
         dev = dy2.device
         want_t = wg and not tt
@@ -623,15 +693,15 @@ class EncoderLayerBf16Fn(torch.autograd.Function):
             dfb, dft = cast_bf16(dz2, want_t=want_t, drop=drop.at(sb + 3))              # dropout2' fused into the cast
         Fp = _up64(F)
         dhb = (zeros if Fp != F else torch.empty)(T, Fp, device=dev, dtype=torch.int16)
-        gemm_bf16(dfb, l2_t, T, F, Cb=dhb, aux=hb, act=3, gate_scale=drop.scale)       # relu' and dropout' fused
-        dy1 = gemm_bf16(dhb, l1_t, T, d, C=new(T, d), addend=dz2)
+        _mm(dfb, l2_t, T, F, Cb=dhb, aux=hb, act=3, gate_scale=drop.scale)             # relu' and dropout' fused
+        dy1 = _mm(dhb, l1_t, T, d, C=new(T, d), addend=dz2)
         if fuse_b:
             dz1, dn1w, dn1b, dob, doutb_f = _ln_bwd(dy1, z1, m1, r1, n1_w, wg, dzb_drop=drop.at(sb + 1))
             dot = None
         else:
             dz1, dn1w, dn1b = _ln_bwd(dy1, z1, m1, r1, n1_w, wg)
             dob, dot = cast_bf16(dz1, want_t=want_t, drop=drop.at(sb + 1))
-        datt = gemm_bf16(dob, outw_t, T, d, C=new(T, d))
+        datt = _mm(dob, outw_t, T, d, C=new(T, d))
         dqkv = torch.empty_like(qkv)
         if fuse_b:
             dqb, dqt = torch.empty(T, 3 * d, device=dev, dtype=torch.int16), None
@@ -639,7 +709,7 @@ class EncoderLayerBf16Fn(torch.autograd.Function):
         else:
             call("cst_mha_bwd", qkv, datt, lse, dqkv, B, S, H, d // H, *drop.at(sb + 0).args())
             dqb, dqt = cast_bf16(dqkv, want_t=want_t)
-        dx = gemm_bf16(dqb, inw_t, T, d, C=new(T, d), addend=dz1) if ctx.needs_input_grad[0] else None
+        dx = _mm(dqb, inw_t, T, d, C=new(T, d), addend=dz1) if ctx.needs_input_grad[0] else None
         dinw = dinb = doutw = doutb = dl1w = dl1b = dl2w = dl2b = None
         if wg:
             if tt:                                        # dW = dY^T X from the row-major copies

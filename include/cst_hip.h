@@ -204,6 +204,22 @@ int cst_dot_attn_bwd_steps(float* diffn, long ldrow, long gstep, const float* q,
 int cst_lstm_cell_fwd(float* gates, long ldg, const float* c_prev, long ldcp, float* h_out, long ldh,
                       float* c_out, long ldc, float* h_out2, long ldh2,
                       void* h_bf16, long ldhb, void* h_bf16_2, long ldhb2, int B, int H, void* stream);
+/* W8A16 (BASELINE configs[4], "fp8 weight MFMA + bf16 activations"): the weights of the encoder layers' Linear products
+ * (packed in_proj, out_proj, linear1, linear2 of nn.TransformerEncoderLayer: mlm.py:20-22, match.py:18-20) as fp8 e4m3 (OCP)
+ * with one fp32 scale per output channel.
+ * cst_cast_fp8_rows: out[r, c] = fp8(W(r, c) / scale[r]), scale[r] = max_c |W(r, c)| / 448; W(r, c) = W[r * ldw + c * colstride]
+ *   (colstride > 1 quantises a transposed view: the dgrad product needs W^T with scales along its own rows); out is [R, ldo]
+ *   bytes, ldo a multiple of 16 >= C, columns >= C zero.
+ * cst_gemm_bf16_w8: C / Cb [M,N] = epi(alpha * bscale[n] * A[M,K] Bq[N,K]^T), A bf16 as in cst_gemm_bf16, Bq fp8 with ldb in
+ *   bytes; the weight tile moves HBM -> LDS at one byte per element and is widened to bf16 in registers in front of
+ *   v_mfma_f32_16x16x32_bf16 (gfx950 has no MFMA that mixes bf16 and fp8 operands); epilogues as cst_gemm_bf16. */
+int cst_cast_fp8_rows(const float* W, long ldw, long colstride, int R, int C, void* out, long ldo, float* scale, void* stream);
+int cst_gemm_bf16_w8(const void* A, long lda, const void* Bq, long ldb, const float* bscale,
+                     float* C, long ldc, void* Cb, long ldcb, int M, int N, int K,
+                     const float* bias, const float* addend, long ldadd, const void* aux, long ldaux,
+                     int act, float gate_scale, float alpha, int accumulate,
+                     float drop_p, uint32_t drop_seed, uint32_t drop_stream, const void* drop_seed_dev,
+                     int splitk, float* workspace, long workspace_floats, void* stream);
 /* C[M,N] (+)= A^T B with A [K,M] and B [K,N] bf16, the CONTRACTION index being the row index of both: the weight
  * gradients dW = dY^T X of every Linear on the path (backward of mlm.py:20-24, match.py:18-22) straight from the
  * row-major bf16 activations, no transposed copies.  M, N multiples of 8, K a multiple of 64 (token count);

@@ -150,6 +150,47 @@ def test_gemm_bf16_256_tile(ops, shape, tile):
     assert torch.equal(C.cpu(), ref)
 
 
+@pytest.mark.parametrize("shape", [(64, 128, 64), (130, 300, 200), (4608, 2304, 768), (4608, 768, 2048), (256, 512, 1024), (96, 2048, 640)])
+def test_gemm_bf16_w8_fp8_weights(ops, shape):
+    """W8A16 (BASELINE configs[4]): fp8 e4m3 (OCP) weights with per-output-channel scales.  The quantiser is checked against
+    torch.float8_e4m3fn bit for bit (which also proves the OCP -- not FNUZ -- encoding), the GEMM against the product with the
+    DEQUANTISED weights (so only bf16-product rounding is left), and against the unquantised product within the e4m3 grid error."""
+    M, N, K = shape
+    A, W = rnd(M, K, seed=1), rnd(N, K, seed=2)
+    W[3 % N] *= 37.0                                               # rows of very different magnitude: per-row scales matter
+    Ab, _ = ops.cast_bf16(dev(A), want_t=False)
+    q, sc = ops.cast_fp8_rows(dev(W))
+    assert q.shape == (N, (K + 63) // 64 * 64) and q.dtype == torch.uint8
+    ref_sc = W.abs().amax(1) / 448.0
+    close(sc, ref_sc, 1e-6, 0.0)
+    ref_q = (W * (1.0 / sc.cpu())[:, None]).clamp(-448, 448).to(torch.float8_e4m3fn)      # the kernel multiplies by 1 / scale
+    assert torch.equal(q[:, :K].cpu().view(torch.float8_e4m3fn).float(), ref_q.float())
+    assert int(q[:, K:].cpu().sum()) == 0
+    Wdq = ref_q.float() * ref_sc[:, None]
+    ref = _bf16_round(A) @ Wdq.t()
+    C = torch.full((M, N), float("nan"), device="cuda")
+    ops.gemm_bf16_w8(Ab, q, sc, M, N, C=C)
+    close(C, ref, 2e-3, 2e-3 * math.sqrt(K) * float(W.abs().max()) / 4, f"{shape}")
+    full = A @ W.t()
+    assert rel(C, full) < 6e-2                                      # e4m3: 3 mantissa bits -> ~3 % rms per weight, averaged down over K
+    # transposed quantisation (the dgrad operand): W^T with scales along its own rows
+    qt, sct = ops.cast_fp8_rows(dev(W), transposed=True)
+    ref_sct = W.abs().amax(0) / 448.0
+    close(sct, ref_sct, 1e-6, 0.0)
+    ref_qt = (W.t() * (1.0 / sct.cpu())[:, None]).clamp(-448, 448).to(torch.float8_e4m3fn)
+    assert torch.equal(qt[:, :N].cpu().view(torch.float8_e4m3fn).float(), ref_qt.float())
+    # epilogue: bias + relu + bf16-only output, as the FFN1 product uses it
+    bias = rnd(N, seed=3)
+    Cb = torch.zeros(M, (N + 63) // 64 * 64, device="cuda", dtype=torch.int16)
+    ops.gemm_bf16_w8(Ab, q, sc, M, N, Cb=Cb, bias=dev(bias), act=1)
+    close(Cb.view(torch.bfloat16).float()[:, :N], torch.relu(ref + bias), 1e-2, 1e-2 * math.sqrt(K) * float(W.abs().max()) / 4)
+
+
+def rel(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return float((a - b).norm() / b.norm())
+
+
 @pytest.mark.parametrize("tile", [64, 128])
 def test_gemm_epilogues(ops, tile):
     ops.set_precision("f32")
