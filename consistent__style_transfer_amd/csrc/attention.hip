@@ -27,6 +27,20 @@ typedef float f32x4_t __attribute__((ext_vector_type(4)));
 
 constexpr int MHA_NW = 8;            // waves per workgroup: 2-3 resident workgroups give 4-6 waves / SIMD
 
+// four consecutive elements at element offset `off` of an fp32 (HB = false) or bf16 (HB = true) array, as floats.  The bf16 forms
+// (cst_mha_fwd_h / cst_mha_bwd_h) halve the HBM streams of the attention core in bf16 mode -- qkv comes straight from the
+// in-projection GEMM's bf16 output, d(attention output) from the out-projection dgrad's -- while the LDS images and every
+// product stay fp32 (exact arithmetic on bf16-rounded inputs).
+template <bool HB>
+__device__ __forceinline__ float4 mha_ld4(const void* base, long off) {
+    if constexpr (HB) {
+        const uint2 u = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(base) + off);
+        return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u));
+    } else {
+        return *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(base) + off);
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // MHA forward.  qkv [B,S,3d] (q | k | v thirds, heads interleaved inside each third as torch's
 // packed in_proj does), out [B,S,d], lse [B,H,S].
@@ -44,8 +58,8 @@ __host__ __device__ inline size_t mha_fwd_lds_floats(int S, int hd) {
     return 3 * SP * (hd + 4) + 16 + SP * (SP + 4);
 }
 
-template <int HD, int ST>
-__global__ __launch_bounds__(MHA_NW * 64) void mha_fwd_kernel(const float* __restrict__ qkv, float* __restrict__ out,
+template <int HD, int ST, bool QB = false>
+__global__ __launch_bounds__(MHA_NW * 64) void mha_fwd_kernel(const void* __restrict__ qkv, float* __restrict__ out,
                                                              float* __restrict__ lse, int S, int H, float scale, CstDrop drop,
                                                              unsigned short* __restrict__ outb, long ldob) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -60,7 +74,7 @@ __global__ __launch_bounds__(MHA_NW * 64) void mha_fwd_kernel(const float* __res
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lr = lane & 15, lq = lane >> 4;
-    const float* base = qkv + (long)b * S * 3 * d + h * HD;
+    const long base = (long)b * S * 3 * d + h * HD;          // element offset of this (b, h) slice
     {
         constexpr int nel = SP * HD4;
         constexpr int QIT = (nel + NTHR - 1) / NTHR;
@@ -69,10 +83,10 @@ __global__ __launch_bounds__(MHA_NW * 64) void mha_fwd_kernel(const float* __res
         for (int it = 0; it < QIT; ++it) {
             const int e = min((int)threadIdx.x + NTHR * it, nel - 1);
             const int i = min(e / HD4, S - 1), c = (e % HD4) * 4;
-            const float* src = base + (long)i * 3 * d + c;
-            tq[it] = *reinterpret_cast<const float4*>(src);
-            tk[it] = *reinterpret_cast<const float4*>(src + d);
-            tv[it] = *reinterpret_cast<const float4*>(src + 2 * d);
+            const long src = base + (long)i * 3 * d + c;
+            tq[it] = mha_ld4<QB>(qkv, src);
+            tk[it] = mha_ld4<QB>(qkv, src + d);
+            tv[it] = mha_ld4<QB>(qkv, src + 2 * d);
         }
 #pragma unroll
         for (int it = 0; it < QIT; ++it) {
@@ -173,7 +187,7 @@ __global__ __launch_bounds__(MHA_NW * 64) void mha_fwd_kernel(const float* __res
             for (int r = 0; r < 4; ++r) {
                 const int mrow = mt * 16 + lq * 4 + r;
                 if (mrow < S && n < HD) {
-                    ob[(long)mrow * d + n] = acc[q][r];
+                    if (out) ob[(long)mrow * d + n] = acc[q][r];
                     if (outb) {                                   // A operand of the out-projection
                         __bf16 hh = (__bf16)acc[q][r];
                         outb[((long)b * S + mrow) * ldob + h * HD + n] = __builtin_bit_cast(unsigned short, hh);
@@ -193,17 +207,36 @@ extern "C" int cst_mha_fwd(const float* qkv, float* out, float* lse, int B, int 
     return cst_mha_fwd_b(qkv, out, lse, B, S, H, hd, drop_p, drop_seed, drop_stream, drop_seed_dev, nullptr, 0, stream);
 }
 
+static int mha_fwd_any(const void* qkv, int qkv_bf16, float* out, float* lse, int B, int S, int H, int hd,
+                       float drop_p, uint32_t drop_seed, uint32_t drop_stream, const void* drop_seed_dev,
+                       void* out_bf16, long ldob, void* stream);
+
 extern "C" int cst_mha_fwd_b(const float* qkv, float* out, float* lse, int B, int S, int H, int hd,
                              float drop_p, uint32_t drop_seed, uint32_t drop_stream, const void* drop_seed_dev,
                              void* out_bf16, long ldob, void* stream) {
+    CST_REQUIRE(out, "cst_mha_fwd: null pointer");
+    return mha_fwd_any(qkv, 0, out, lse, B, S, H, hd, drop_p, drop_seed, drop_stream, drop_seed_dev, out_bf16, ldob, stream);
+}
+
+extern "C" int cst_mha_fwd_h(const void* qkv_bf16, float* out, float* lse, int B, int S, int H, int hd,
+                             float drop_p, uint32_t drop_seed, uint32_t drop_stream, const void* drop_seed_dev,
+                             void* out_bf16, long ldob, void* stream) {
+    CST_REQUIRE(out || out_bf16, "cst_mha_fwd_h: no output");
+    CST_REQUIRE(S <= MHA_SMAX && (hd == 64 || hd == 96), "cst_mha_fwd_h: bf16 qkv is built for S <= %d and head dims 64 / 96 (got S=%d, hd=%d)", MHA_SMAX, S, hd);
+    return mha_fwd_any(qkv_bf16, 1, out, lse, B, S, H, hd, drop_p, drop_seed, drop_stream, drop_seed_dev, out_bf16, ldob, stream);
+}
+
+static int mha_fwd_any(const void* qkv, int qkv_bf16, float* out, float* lse, int B, int S, int H, int hd,
+                       float drop_p, uint32_t drop_seed, uint32_t drop_stream, const void* drop_seed_dev,
+                       void* out_bf16, long ldob, void* stream) {
     CST_REQUIRE(!out_bf16 || ldob >= (long)H * hd, "cst_mha_fwd: bf16 leading dimension < d");
-    CST_REQUIRE(qkv && out && lse, "cst_mha_fwd: null pointer");
+    CST_REQUIRE(qkv && lse, "cst_mha_fwd: null pointer");
     CST_REQUIRE(B > 0 && S > 0 && S <= MHA_SMAX_LONG && H > 0, "cst_mha_fwd: S=%d unsupported (max %d)", S, MHA_SMAX_LONG);
     CST_REQUIRE(((uintptr_t)qkv & 15) == 0 && hd % 4 == 0, "cst_mha_fwd: qkv must be 16-byte aligned, hd a multiple of 4");
     CstDrop dr = cst_make_drop(drop_p, drop_seed, drop_stream, drop_seed_dev);
     const float scale = 1.0f / sqrtf((float)hd);
     if (S > MHA_SMAX) {
-        const int rc = cst_mha_fwd_long(qkv, out, lse, B, S, H, hd, scale, dr, out_bf16, ldob, (hipStream_t)stream);
+        const int rc = cst_mha_fwd_long((const float*)qkv, out, lse, B, S, H, hd, scale, dr, out_bf16, ldob, (hipStream_t)stream);
         if (rc != CST_OK) return rc;
         CST_LAUNCH_CHECK("cst_mha_fwd (long)");
         return CST_OK;
@@ -214,16 +247,23 @@ extern "C" int cst_mha_fwd_b(const float* qkv, float* out, float* lse, int B, in
     hipStream_t st = (hipStream_t)stream;
 #define MHA_FWD_LAUNCH(HDV, STV)                                                                                  \
     {                                                                                                             \
-        if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)mha_fwd_kernel<HDV, STV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-        hipLaunchKernelGGL((mha_fwd_kernel<HDV, STV>), grid, block, lds, st, qkv, out, lse, S, H, scale, dr, (unsigned short*)out_bf16, ldob); \
+        if constexpr (HDV == 64 || HDV == 96) {                                                                    \
+            if (qkv_bf16) {                                                                                       \
+                if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)mha_fwd_kernel<HDV, STV, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+                hipLaunchKernelGGL((mha_fwd_kernel<HDV, STV, true>), grid, block, lds, st, qkv, out, lse, S, H, scale, dr, (unsigned short*)out_bf16, ldob); \
+                break;                                                                                            \
+            }                                                                                                     \
+        }                                                                                                         \
+        if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)mha_fwd_kernel<HDV, STV, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL((mha_fwd_kernel<HDV, STV, false>), grid, block, lds, st, qkv, out, lse, S, H, scale, dr, (unsigned short*)out_bf16, ldob); \
     }
 #define MHA_FWD_CASE(HDV)                                                                                         \
     case HDV: {                                                                                                   \
         switch ((S + 15) / 16) {                                                                                  \
-            case 1: MHA_FWD_LAUNCH(HDV, 1) break;                                                                 \
-            case 2: MHA_FWD_LAUNCH(HDV, 2) break;                                                                 \
-            case 3: MHA_FWD_LAUNCH(HDV, 3) break;                                                                 \
-            default: MHA_FWD_LAUNCH(HDV, 4) break;                                                                \
+            case 1: do MHA_FWD_LAUNCH(HDV, 1) while (0); break;                                                   \
+            case 2: do MHA_FWD_LAUNCH(HDV, 2) while (0); break;                                                   \
+            case 3: do MHA_FWD_LAUNCH(HDV, 3) while (0); break;                                                   \
+            default: do MHA_FWD_LAUNCH(HDV, 4) while (0); break;                                                  \
         }                                                                                                         \
         break;                                                                                                    \
     }
@@ -257,8 +297,8 @@ __host__ __device__ inline size_t mha_bwd_lds_floats(int S, int hd) {
     return 4 * SP * (hd + 4) + 16 + 2 * SP * (SP + 4) + SP * 4 + SP;
 }
 
-template <int HD, int ST>
-__global__ __launch_bounds__(MHA_NW * 64) void mha_bwd_kernel(const float* __restrict__ qkv, const float* __restrict__ dout,
+template <int HD, int ST, bool QB = false>
+__global__ __launch_bounds__(MHA_NW * 64) void mha_bwd_kernel(const void* __restrict__ qkv, const void* __restrict__ dout,
                                                       const float* __restrict__ lse, float* __restrict__ dqkv,
                                                       int S, int H, float scale, CstDrop drop,
                                                       unsigned short* __restrict__ dqkvb, long lddb) {
@@ -278,8 +318,8 @@ __global__ __launch_bounds__(MHA_NW * 64) void mha_bwd_kernel(const float* __res
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lr = lane & 15, lq = lane >> 4;
-    const float* base = qkv + (long)b * S * 3 * d + h * HD;
-    const float* dob = dout + (long)b * S * d + h * HD;
+    const long base = (long)b * S * 3 * d + h * HD;          // element offsets of this (b, h) slice in qkv / dout
+    const long dob = (long)b * S * d + h * HD;
 
     // stage Q, K, V, dO: every 16-byte load is issued before the first LDS store
     {
@@ -291,11 +331,11 @@ __global__ __launch_bounds__(MHA_NW * 64) void mha_bwd_kernel(const float* __res
             // unconditional (clamped) loads: iterations past the tile re-read its last element
             const int e = min((int)threadIdx.x + NTHR * it, nel - 1);
             const int i = min(e / HD4, S - 1), c = (e % HD4) * 4;
-            const float* src = base + (long)i * 3 * d + c;
-            tq[it] = *reinterpret_cast<const float4*>(src);
-            tk[it] = *reinterpret_cast<const float4*>(src + d);
-            tv[it] = *reinterpret_cast<const float4*>(src + 2 * d);
-            to[it] = *reinterpret_cast<const float4*>(dob + (long)i * d + c);
+            const long src = base + (long)i * 3 * d + c;
+            tq[it] = mha_ld4<QB>(qkv, src);
+            tk[it] = mha_ld4<QB>(qkv, src + d);
+            tv[it] = mha_ld4<QB>(qkv, src + 2 * d);
+            to[it] = mha_ld4<QB>(dout, dob + (long)i * d + c);
         }
         if (threadIdx.x < SP) lse_s[threadIdx.x] = (int)threadIdx.x < S ? lse[((long)b * H + h) * S + threadIdx.x] : 0.f;
 #pragma unroll
@@ -422,7 +462,7 @@ __global__ __launch_bounds__(MHA_NW * 64) void mha_bwd_kernel(const float* __res
             for (int r = 0; r < 4; ++r) {
                 const int m = mt * 16 + lq * 4 + r;
                 if (m < S && n < HD) {
-                    dq[(long)m * 3 * d + which * d + n] = acc[q][r];
+                    if (dqkv) dq[(long)m * 3 * d + which * d + n] = acc[q][r];
                     if (dqkvb) {                                  // A operand of the in-projection dgrad / weight gradient
                         __bf16 hh = (__bf16)acc[q][r];
                         dqkvb[((long)b * S + m) * lddb + which * d + h * HD + n] = __builtin_bit_cast(unsigned short, hh);
@@ -444,18 +484,38 @@ extern "C" int cst_mha_bwd(const float* qkv, const float* dout, const float* lse
     return cst_mha_bwd_b(qkv, dout, lse, dqkv, B, S, H, hd, drop_p, drop_seed, drop_stream, drop_seed_dev, nullptr, 0, stream);
 }
 
+static int mha_bwd_any(const void* qkv, const void* dout, int io_bf16, const float* lse, float* dqkv, int B, int S, int H, int hd,
+                       float drop_p, uint32_t drop_seed, uint32_t drop_stream, const void* drop_seed_dev,
+                       void* dqkv_bf16, long lddb, void* stream);
+
 extern "C" int cst_mha_bwd_b(const float* qkv, const float* dout, const float* lse, float* dqkv,
                              int B, int S, int H, int hd,
                              float drop_p, uint32_t drop_seed, uint32_t drop_stream, const void* drop_seed_dev,
                              void* dqkv_bf16, long lddb, void* stream) {
+    CST_REQUIRE(dqkv, "cst_mha_bwd: null pointer");
+    return mha_bwd_any(qkv, dout, 0, lse, dqkv, B, S, H, hd, drop_p, drop_seed, drop_stream, drop_seed_dev, dqkv_bf16, lddb, stream);
+}
+
+extern "C" int cst_mha_bwd_h(const void* qkv_bf16, const void* dout_bf16, const float* lse, float* dqkv,
+                             int B, int S, int H, int hd,
+                             float drop_p, uint32_t drop_seed, uint32_t drop_stream, const void* drop_seed_dev,
+                             void* dqkv_bf16, long lddb, void* stream) {
+    CST_REQUIRE(dqkv || dqkv_bf16, "cst_mha_bwd_h: no output");
+    CST_REQUIRE(S <= MHA_SMAX && (hd == 64 || hd == 96), "cst_mha_bwd_h: bf16 qkv / dout are built for S <= %d and head dims 64 / 96 (got S=%d, hd=%d)", MHA_SMAX, S, hd);
+    return mha_bwd_any(qkv_bf16, dout_bf16, 1, lse, dqkv, B, S, H, hd, drop_p, drop_seed, drop_stream, drop_seed_dev, dqkv_bf16, lddb, stream);
+}
+
+static int mha_bwd_any(const void* qkv, const void* dout, int io_bf16, const float* lse, float* dqkv, int B, int S, int H, int hd,
+                       float drop_p, uint32_t drop_seed, uint32_t drop_stream, const void* drop_seed_dev,
+                       void* dqkv_bf16, long lddb, void* stream) {
     CST_REQUIRE(!dqkv_bf16 || lddb >= 3L * H * hd, "cst_mha_bwd: bf16 leading dimension < 3d");
-    CST_REQUIRE(qkv && dout && lse && dqkv, "cst_mha_bwd: null pointer");
+    CST_REQUIRE(qkv && dout && lse, "cst_mha_bwd: null pointer");
     CST_REQUIRE(B > 0 && S > 0 && S <= MHA_SMAX_LONG && H > 0, "cst_mha_bwd: S=%d unsupported (max %d)", S, MHA_SMAX_LONG);
     CST_REQUIRE((((uintptr_t)qkv | (uintptr_t)dout) & 15) == 0 && hd % 4 == 0, "cst_mha_bwd: qkv / dout must be 16-byte aligned, hd a multiple of 4");
     CstDrop dr = cst_make_drop(drop_p, drop_seed, drop_stream, drop_seed_dev);
     const float scale = 1.0f / sqrtf((float)hd);
     if (S > MHA_SMAX) {
-        const int rc = cst_mha_bwd_long(qkv, dout, lse, dqkv, B, S, H, hd, scale, dr, dqkv_bf16, lddb, (hipStream_t)stream);
+        const int rc = cst_mha_bwd_long((const float*)qkv, (const float*)dout, lse, dqkv, B, S, H, hd, scale, dr, dqkv_bf16, lddb, (hipStream_t)stream);
         if (rc != CST_OK) return rc;
         CST_LAUNCH_CHECK("cst_mha_bwd (long)");
         return CST_OK;
@@ -466,16 +526,23 @@ extern "C" int cst_mha_bwd_b(const float* qkv, const float* dout, const float* l
     hipStream_t st = (hipStream_t)stream;
 #define MHA_BWD_LAUNCH(HDV, STV)                                                                                  \
     {                                                                                                             \
-        if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)mha_bwd_kernel<HDV, STV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-        hipLaunchKernelGGL((mha_bwd_kernel<HDV, STV>), grid, block, lds, st, qkv, dout, lse, dqkv, S, H, scale, dr, (unsigned short*)dqkv_bf16, lddb); \
+        if constexpr (HDV == 64 || HDV == 96) {                                                                    \
+            if (io_bf16) {                                                                                        \
+                if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)mha_bwd_kernel<HDV, STV, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+                hipLaunchKernelGGL((mha_bwd_kernel<HDV, STV, true>), grid, block, lds, st, qkv, dout, lse, dqkv, S, H, scale, dr, (unsigned short*)dqkv_bf16, lddb); \
+                break;                                                                                            \
+            }                                                                                                     \
+        }                                                                                                         \
+        if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)mha_bwd_kernel<HDV, STV, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL((mha_bwd_kernel<HDV, STV, false>), grid, block, lds, st, qkv, dout, lse, dqkv, S, H, scale, dr, (unsigned short*)dqkv_bf16, lddb); \
     }
 #define MHA_BWD_CASE(HDV)                                                                                         \
     case HDV: {                                                                                                   \
         switch ((S + 15) / 16) {                                                                                  \
-            case 1: MHA_BWD_LAUNCH(HDV, 1) break;                                                                 \
-            case 2: MHA_BWD_LAUNCH(HDV, 2) break;                                                                 \
-            case 3: MHA_BWD_LAUNCH(HDV, 3) break;                                                                 \
-            default: MHA_BWD_LAUNCH(HDV, 4) break;                                                                \
+            case 1: do MHA_BWD_LAUNCH(HDV, 1) while (0); break;                                                   \
+            case 2: do MHA_BWD_LAUNCH(HDV, 2) while (0); break;                                                   \
+            case 3: do MHA_BWD_LAUNCH(HDV, 3) while (0); break;                                                   \
+            default: do MHA_BWD_LAUNCH(HDV, 4) while (0); break;                                                  \
         }                                                                                                         \
         break;                                                                                                    \
     }

@@ -637,9 +637,20 @@ class EncoderLayerBf16Fn(torch.autograd.Function):
         if xb is None:
             xb, xt = cast_bf16(x, want_t=want_t)
         inw_b, inw_t = _wops(in_w)
-        qkv = _mm(xb, inw_b, T, 3 * d, C=new(T, 3 * d), bias=in_b)
-        att, lse = new(T, d), new(B * H * S)
-        if fuse_b:
+        # bf16-only attention I/O (cst_mha_fwd_h / _bwd_h): qkv, the attention output and (backward) their gradients never exist in
+        # fp32 in HBM -- the in-projection writes bf16, the attention core reads it, the out-projection reads the core's bf16 output
+        hq = fuse_b and S <= 64 and (d // H) in (64, 96)
+        lse = new(B * H * S)
+        if hq:
+            qkv = _mm(xb, inw_b, T, 3 * d, Cb=newb(T, 3 * d), bias=in_b)
+            att, attb, attt = None, newb(T, d), None
+            call("cst_mha_fwd_h", qkv, None, lse, B, S, H, d // H, *drop.at(sb + 0).args(), attb, d)
+        else:
+            qkv = _mm(xb, inw_b, T, 3 * d, C=new(T, 3 * d), bias=in_b)
+            att = new(T, d)
+        if hq:
+            pass
+        elif fuse_b:
             attb, attt = newb(T, d), None
             call("cst_mha_fwd_b", qkv, att, lse, B, S, H, d // H, *drop.at(sb + 0).args(), attb, d)
         else:
@@ -673,6 +684,7 @@ class EncoderLayerBf16Fn(torch.autograd.Function):
         ctx.save_for_backward(wx, watt, wy1, wh, hb, n1_w, n2_w, qkv, lse, z1, m1, r1, z2, m2, r2)
         ctx.wt = (inw_t, outw_t, l1_t, l2_t)              # dgrad operands: ("b", bf16 W^T) or ("q", fp8 W^T, scale)
         ctx.cfg = (B, S, H, drop, sb, T, d, F, wg, tt, fuse_b)
+        ctx.hq = hq
         ctx.wrefs = (in_w, out_w, l1_w, l2_w)             # parameters (not saved tensors): only to find their gradient slots
         return y2
 
@@ -701,9 +713,18 @@ class EncoderLayerBf16Fn(torch.autograd.Function):
         else:
             dz1, dn1w, dn1b = _ln_bwd(dy1, z1, m1, r1, n1_w, wg)
             dob, dot = cast_bf16(dz1, want_t=want_t, drop=drop.at(sb + 1))
-        datt = _mm(dob, outw_t, T, d, C=new(T, d))
-        dqkv = torch.empty_like(qkv)
-        if fuse_b:
+        hq = ctx.hq
+        if hq:
+            dattb = _mm(dob, outw_t, T, d, Cb=torch.empty(T, d, device=dev, dtype=torch.int16))
+            dqkv, dqt = None, None
+            dqb = torch.empty(T, 3 * d, device=dev, dtype=torch.int16)
+            call("cst_mha_bwd_h", qkv, dattb, lse, None, B, S, H, d // H, *drop.at(sb + 0).args(), dqb, 3 * d)
+        else:
+            datt = _mm(dob, outw_t, T, d, C=new(T, d))
+            dqkv = torch.empty_like(qkv)
+        if hq:
+            pass
+        elif fuse_b:
             dqb, dqt = torch.empty(T, 3 * d, device=dev, dtype=torch.int16), None
             call("cst_mha_bwd_b", qkv, datt, lse, dqkv, B, S, H, d // H, *drop.at(sb + 0).args(), dqb, 3 * d)
         else:
@@ -730,7 +751,7 @@ class EncoderLayerBf16Fn(torch.autograd.Function):
                 dl2b = colsum_bf16(dfb, d) if drop.p > 0 else colsum(dz2)
                 doutb = colsum_bf16(dob, d) if drop.p > 0 else colsum(dz1)
             dl1b = colsum_bf16(dhb, F)
-            dinb = colsum(dqkv)
+            dinb = colsum_bf16(dqb, 3 * d) if hq else colsum(dqkv)
         return (dx, dinw, dinb, doutw, doutb, dl1w, dl1b, dl2w, dl2b, dn1w, dn1b, dn2w, dn2b,
                 None, None, None, None, None)
 

@@ -176,6 +176,16 @@ int cst_mha_fwd(const float* qkv, float* out, float* lse, int B, int S, int H, i
 int cst_mha_fwd_b(const float* qkv, float* out, float* lse, int B, int S, int H, int hd,
                   float drop_p, uint32_t drop_seed, uint32_t drop_stream, const void* drop_seed_dev,
                   void* out_bf16, long ldob, void* stream);
+/* _h: the same attention core with bf16 qkv [B,S,3d] and (backward) bf16 d(attention output) [B,S,d] in HBM and optional
+ * fp32 results (out / dqkv may be null when the bf16 twin is all the caller consumes): in bf16 mode the encoder layer keeps
+ * qkv, the attention output, its gradient and dqkv in bf16 only, which halves-to-thirds the attention core's HBM traffic.
+ * S <= 64, head dims 64 / 96.  LDS images and all arithmetic stay fp32. */
+int cst_mha_fwd_h(const void* qkv_bf16, float* out, float* lse, int B, int S, int H, int hd,
+                  float drop_p, uint32_t drop_seed, uint32_t drop_stream, const void* drop_seed_dev,
+                  void* out_bf16, long ldob, void* stream);
+int cst_mha_bwd_h(const void* qkv_bf16, const void* dout_bf16, const float* lse, float* dqkv, int B, int S, int H, int hd,
+                  float drop_p, uint32_t drop_seed, uint32_t drop_stream, const void* drop_seed_dev,
+                  void* dqkv_bf16, long lddb, void* stream);
 int cst_mha_bwd(const float* qkv, const float* dout, const float* lse, float* dqkv, int B, int S, int H, int hd,
                 float drop_p, uint32_t drop_seed, uint32_t drop_stream, const void* drop_seed_dev, void* stream);
 int cst_mha_bwd_b(const float* qkv, const float* dout, const float* lse, float* dqkv, int B, int S, int H, int hd,

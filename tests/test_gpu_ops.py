@@ -417,6 +417,36 @@ def test_mha(ops, B, S, H, hd, p):
     assert torch.equal(dqb.view(torch.bfloat16), dqkv.to(torch.bfloat16))
 
 
+@pytest.mark.parametrize("B,S,H,hd,p", [(2, 36, 8, 64, 0.1), (3, 18, 8, 96, 0.1), (1, 64, 2, 64, 0.0), (2, 36, 8, 96, 0.0), (2, 7, 3, 96, 0.1)])
+def test_mha_bf16_io_equals_fp32_io_on_rounded_inputs(ops, B, S, H, hd, p):
+    """cst_mha_fwd_h / cst_mha_bwd_h: bf16 qkv and d(output) in HBM, fp32 LDS images and arithmetic -- bit for bit the fp32-I/O
+    kernels run on the bf16-rounded values, with or without the optional fp32 results."""
+    from consistent__style_transfer_amd._lib import call
+    d = H * hd
+    qkv = _bf16_round(rnd(B * S, 3 * d, seed=1, scale=0.7))
+    w = _bf16_round(rnd(B * S, d, seed=2))
+    qb, _ = ops.cast_bf16(dev(qkv), want_t=False)
+    wb, _ = ops.cast_bf16(dev(w), want_t=False)
+    drop = ops.Drop(p, 7, 1000)
+    out, lse = torch.empty(B * S, d, device="cuda"), torch.empty(B * H * S, device="cuda")
+    outb = torch.zeros(B * S, d, device="cuda", dtype=torch.int16)
+    call("cst_mha_fwd_b", dev(qkv), out, lse, B, S, H, hd, *drop.args(), outb, d)
+    out2, lse2 = torch.empty_like(out), torch.empty_like(lse)
+    outb2, outb3 = torch.zeros_like(outb), torch.zeros_like(outb)
+    call("cst_mha_fwd_h", qb, out2, lse2, B, S, H, hd, *drop.args(), outb2, d)
+    call("cst_mha_fwd_h", qb, None, lse2, B, S, H, hd, *drop.args(), outb3, d)          # bf16 result only
+    assert torch.equal(out2, out) and torch.equal(lse2, lse) and torch.equal(outb2, outb) and torch.equal(outb3, outb)
+    dq = torch.empty(B * S, 3 * d, device="cuda")
+    dqb = torch.zeros(B * S, 3 * d, device="cuda", dtype=torch.int16)
+    call("cst_mha_bwd_b", dev(qkv), dev(w), lse, dq, B, S, H, hd, *drop.args(), dqb, 3 * d)
+    dq2, dqb2, dqb3 = torch.empty_like(dq), torch.zeros_like(dqb), torch.zeros_like(dqb)
+    call("cst_mha_bwd_h", qb, wb, lse, dq2, B, S, H, hd, *drop.args(), dqb2, 3 * d)
+    call("cst_mha_bwd_h", qb, wb, lse, None, B, S, H, hd, *drop.args(), dqb3, 3 * d)
+    assert torch.equal(dq2, dq) and torch.equal(dqb2, dqb) and torch.equal(dqb3, dqb)
+    with pytest.raises(RuntimeError, match="head dims 64 / 96"):
+        call("cst_mha_fwd_h", qb, None, lse2, B, S, H * hd // 32, 32, *drop.args(), outb3, d)
+
+
 def test_mha_rejects_unsupported_lengths(ops):
     from consistent__style_transfer_amd._lib import call
     B, S, H, hd = 1, 129, 2, 64
