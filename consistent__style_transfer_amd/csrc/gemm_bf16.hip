@@ -814,6 +814,238 @@ __global__ __launch_bounds__(256 * WR, 2) void cst_gemm_bf16_big_kernel(BGemmArg
     }
 }
 
+// =============================================================================================
+// Loader / consumer, persistent: 256 x 128 tiles, 4 MFMA waves + 4 DMA waves per workgroup, one workgroup per CU walking
+// its share of the tiles.
+//
+// Why (round-2 counters, profiles/round2_gemm_pmc_counters.txt): in every kernel above a wave both issues the tile's
+// global_load_lds pieces and runs its MFMAs, and an LDS-DMA piece costs ~100 cycles to ISSUE (MI355X_MICROARCH.md, cycle
+// constants) -- 6 pieces = ~600 cycles per K-tile against 256 cycles of MFMA at 64 x 128, in-order in the same wave: the
+// matrix pipe idles at 25-28 % however the loop is pipelined (three pipelines, same time).  VMEM and MFMA issue from
+// DIFFERENT waves of a SIMD proceed in the same cycles, so the roles are split: waves 4-7 (one per SIMD) only issue DMA and
+// count vmcnt, waves 0-3 (one per SIMD) only read fragments and issue MFMAs back to back.  One barrier per 32-deep K-tile
+// hands a landed stage to the consumers and a drained stage back to the loaders.  The K-tile stream runs on across tile
+// boundaries (persistent workgroup): while the consumers write a finished tile out -- 128 KB of fp32 per workgroup, the
+// largest HBM stream of these products -- the loaders already have the next tile's first K-tiles in flight.
+//   LDS: NST stages x (A [256][64 B] + B [128][64 B]) = NST x 24 KiB (swizzle as the 256-wide kernel above) + 4 x 8 KiB of C staging.
+//   consumer step g:  barrier(g) ; read fragments of K-tile g+1 (other register set) ; 32 MFMA on K-tile g ; lgkmcnt(0) ;
+//                     after a tile's last K-tile: epilogue from the accumulators (no barrier inside)
+//   loader step g:    vmcnt(pieces of the K-tiles younger than g+1) ; barrier(g) ; DMA K-tile g+NST-1 into the stage K-tile g-1 left
+// Requires M % 256 == 0, N % 128 == 0, K % 32 == 0, no split-K.
+// =============================================================================================
+template <int NST>
+__global__ __launch_bounds__(512, 2) void cst_gemm_bf16_lc_kernel(BGemmArgs g, int gn) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int BM = 256, BN = 128;
+    constexpr int A_BYTES = BM * GB_ROW, B_BYTES = BN * GB_ROW, STAGE = A_BYTES + B_BYTES;      // 16 + 8 KiB
+    constexpr int D = NST - 1;
+    constexpr int PA = BM / 16 / 4, PB = BN / 16 / 4, PT = PA + PB;                              // pieces per loader wave per K-tile
+    static_assert(D >= 2 && D <= 4, "vmcnt cases below cover prefetch distances 2..4");
+    const int tilesM = g.M / BM, tilesN = g.N / BN, ntiles = tilesM * tilesN;
+    const int nk = g.K / GB_K;
+    int vb;                                                // virtual workgroup id: consecutive ids share an XCD
+    {
+        const int nblk = gridDim.x, q = nblk >> 3, r = nblk & 7, xcd = blockIdx.x & 7;
+        vb = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (blockIdx.x >> 3);
+    }
+    const int mytiles = (ntiles - vb + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int G = mytiles * nk;                            // K-tiles this workgroup streams
+    auto tile_origin = [&](int j, int& m0, int& n0) {      // j-th tile of this workgroup
+        const int id = vb + j * (int)gridDim.x;
+        const int grp = id / (gn * tilesM);
+        const int gw = min(gn, tilesN - grp * gn);
+        const int local = id - grp * gn * tilesM;
+        m0 = (local / gw) * BM;
+        n0 = (grp * gn + local % gw) * BN;
+    };
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (G == 0) return;
+
+    if (wave >= 4) {
+        // ------------------------------------------------------------------------------ loaders
+        const int lw = wave - 4;
+        const int gsw = (0x1230 >> (4 * (lane >> 4))) & 3;
+        const int src_slot = (lane & 3) ^ gsw;
+        const bf16_t* abase = nullptr;
+        const bf16_t* bbase = nullptr;
+        int cur_j = -1;
+        auto issue = [&](int gk) {
+            const int j = gk / nk, t = gk - j * nk;
+            if (j != cur_j) {
+                int m0, n0;
+                tile_origin(j, m0, n0);
+                abase = g.A + (long)(m0 + (lane >> 2)) * g.lda + (src_slot << 3);
+                bbase = g.B + (long)(n0 + (lane >> 2)) * g.ldb + (src_slot << 3);
+                cur_j = j;
+            }
+            char* st = smem + (gk % NST) * STAGE;
+            const long k = (long)t * GB_K;
+#pragma unroll
+            for (int c = 0; c < PA; ++c) {
+                const int r0 = (PA * lw + c) * 16;
+                __builtin_amdgcn_global_load_lds((gbl_ptr_t)(abase + (long)r0 * g.lda + k), (lds_ptr_t)(st + r0 * GB_ROW), 16, 0, 0);
+            }
+#pragma unroll
+            for (int c = 0; c < PB; ++c) {
+                const int r0 = (PB * lw + c) * 16;
+                __builtin_amdgcn_global_load_lds((gbl_ptr_t)(bbase + (long)r0 * g.ldb + k), (lds_ptr_t)(st + A_BYTES + r0 * GB_ROW), 16, 0, 0);
+            }
+        };
+        auto wait_younger = [&](int younger) {             // all but the `younger` most recent K-tiles of this wave have landed
+            if (younger >= 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * PT) : "memory");
+            else if (younger == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PT) : "memory");
+            else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PT) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        };
+        const int pre = min(D, G);
+        for (int gk = 0; gk < pre; ++gk) issue(gk);
+        wait_younger(pre - 1);                             // K-tile 0 landed
+        __builtin_amdgcn_s_barrier();                      // barrier(-1)
+        for (int gk = 0; gk < G; ++gk) {
+            // issued so far: K-tiles 0 .. min(gk + D, G) - 1; K-tile gk + 1 must have landed
+            const int last = min(gk + D, G) - 1;
+            wait_younger(max(0, last - (gk + 1)));
+            __builtin_amdgcn_s_barrier();                  // barrier(gk)
+            if (gk + D < G) issue(gk + D);
+        }
+        return;
+    }
+
+    // ---------------------------------------------------------------------------------- consumers
+    const int wr = wave >> 1, wc = wave & 1;
+    const int lr = lane & 15, lq = lane >> 4;
+    const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+    const int fsw = (0x1230 >> (4 * ((lr >> 2) & 3))) & 3;
+    const unsigned a_ad = lds_base + (wr * 128 + lr) * GB_ROW + ((lq ^ fsw) << 4);
+    const unsigned b_ad = lds_base + A_BYTES + (wc * 64 + lr) * GB_ROW + ((lq ^ fsw) << 4);
+    float* Cs = reinterpret_cast<float*>(smem + NST * STAGE) + wave * 32 * 64;       // 8 KiB per consumer wave
+    const uint32_t dseed = g.drop.p > 0.f ? cst_drop_seed(g.drop) : 0u;
+    const bool vec = bgemm_vec_ok(g);
+
+    f32x4_t acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    struct { u32x4_t a[2][4]; u32x4_t b[2][4]; } f;        // a[row half][row tile] of the current K-tile, b[set][column tile]
+
+    // fragments: A(mh 0) and B of K-tile g+1 are read during the second half of step g, A(mh 1) of K-tile g during its first half
+#define LC_READ_A(MH, ST_OFF)                                                                      \
+    {                                                                                              \
+        const unsigned aa = a_ad + (ST_OFF);                                                       \
+        f.a[MH][0] = lds_read128_off<(MH * 64 + 0) * GB_ROW>(aa);   f.a[MH][1] = lds_read128_off<(MH * 64 + 16) * GB_ROW>(aa);  \
+        f.a[MH][2] = lds_read128_off<(MH * 64 + 32) * GB_ROW>(aa);  f.a[MH][3] = lds_read128_off<(MH * 64 + 48) * GB_ROW>(aa);  \
+    }
+#define LC_READ_B(SET, ST_OFF)                                                                     \
+    {                                                                                              \
+        const unsigned bb = b_ad + (ST_OFF);                                                       \
+        f.b[SET][0] = lds_read128_off<0 * GB_ROW>(bb);      f.b[SET][1] = lds_read128_off<16 * GB_ROW>(bb);     \
+        f.b[SET][2] = lds_read128_off<32 * GB_ROW>(bb);     f.b[SET][3] = lds_read128_off<48 * GB_ROW>(bb);     \
+    }
+#define LC_MFMA(MH, SB)                                                                            \
+    __builtin_amdgcn_s_setprio(1);                                                                 \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                  \
+    _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                  \
+        acc[MH * 4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, f.a[MH][i]), \
+                                                                      __builtin_bit_cast(bf16x8_t, f.b[SB][j]), acc[MH * 4 + i][j], 0, 0, 0); \
+    __builtin_amdgcn_s_setprio(0);
+#define LC_WAIT_LDS()                                                                              \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                             \
+    __builtin_amdgcn_sched_barrier(0);
+    auto epilogue = [&](int j) {
+        int m0, n0;
+        tile_origin(j, m0, n0);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {                      // 32-row quarters of the 128 x 64 wave tile
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) Cs[(i * 16 + lq * 4 + r) * 64 + jj * 16 + lr] = acc[q * 2 + i][jj][r];
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll 4
+            for (int it = 0; it < 8; ++it) {
+                const int idx = lane + 64 * it;
+                const int rr = idx >> 4, cc = (idx & 15) * 4;
+                const int m = m0 + wr * 128 + q * 32 + rr, n = n0 + wc * 64 + cc;
+                const float4 a4 = *reinterpret_cast<const float4*>(&Cs[rr * 64 + cc]);
+                const float av[4] = {a4.x, a4.y, a4.z, a4.w};
+                if (vec) bgemm_store4(g, dseed, m, n, av);
+                else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) bgemm_store(g, dseed, m, n + e, av[e]);
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) acc[i][jj] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    };
+#define LC_STEP(SB)                                                                                \
+    {                                                                                              \
+        __builtin_amdgcn_s_barrier();                      /* barrier(gk): K-tile gk + 1 has landed */ \
+        LC_READ_A(1, (gk % NST) * STAGE)                                                           \
+        LC_MFMA(0, SB)                                                                             \
+        LC_WAIT_LDS()                                                                              \
+        if (gk + 1 < G) {                                                                          \
+            LC_READ_A(0, ((gk + 1) % NST) * STAGE)                                                 \
+            LC_READ_B(1 - SB, ((gk + 1) % NST) * STAGE)                                            \
+        }                                                                                          \
+        LC_MFMA(1, SB)                                                                             \
+        LC_WAIT_LDS()                                                                              \
+        if (++kt == nk) { epilogue(jt); kt = 0; ++jt; }                                            \
+    }
+    __builtin_amdgcn_s_barrier();                          // barrier(-1): K-tile 0 has landed
+    LC_READ_A(0, 0)
+    LC_READ_B(0, 0)
+    LC_WAIT_LDS()
+    int kt = 0, jt = 0, gk = 0;
+    for (; gk + 1 < G; gk += 2) {
+        LC_STEP(0)
+        ++gk;
+        LC_STEP(1)
+        --gk;
+    }
+    if (gk < G) LC_STEP(0)
+#undef LC_STEP
+#undef LC_MFMA
+#undef LC_READ_A
+#undef LC_READ_B
+#undef LC_WAIT_LDS
+}
+
+static bool bgemm_lc_ok(const BGemmArgs& g) {
+    return g.M % 256 == 0 && g.N % 128 == 0 && g.K % GB_K == 0 && g.splits == 1 && !g.slab_only && !g.A2;
+}
+
+static int bgemm_lc_launch(const BGemmArgs& g, hipStream_t st) {
+    constexpr int NST = 5;
+    const size_t lds = (size_t)NST * (256 + 128) * GB_ROW + 4 * 32 * 64 * sizeof(float);
+    static const int gn = getenv("CST_GB_GN") ? atoi(getenv("CST_GB_GN")) : 2;
+    static const int ncu = []() { int dev = 0, n = 256; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n > 0 ? n : 256; }();
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void*)cst_gemm_bf16_lc_kernel<NST>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_done = true;
+    }
+    const int ntiles = (g.M / 256) * (g.N / 128);
+    dim3 grid(ntiles < ncu ? ntiles : ncu, 1, 1), block(512);
+    if (cst_prof_on()) {
+        hipEvent_t ea, eb;
+        (void)hipEventCreate(&ea); (void)hipEventCreate(&eb);
+        cst_prof_push_shape(ea, eb, 2.0 * g.M * g.N * g.K, 2.0 * ((double)g.M * g.K + (double)g.N * g.K) + (g.C ? 4.0 : 0.0) * g.M * g.N + (g.Cb ? 2.0 : 0.0) * g.M * g.N, 1,
+                            g.M, g.N, g.K);
+        hipExtLaunchKernelGGL((cst_gemm_bf16_lc_kernel<NST>), grid, block, lds, st, ea, eb, 0, g, gn);
+    } else {
+        hipLaunchKernelGGL((cst_gemm_bf16_lc_kernel<NST>), grid, block, lds, st, g, gn);
+    }
+    return 0;
+}
+
 static bool bgemm_big_ok(const BGemmArgs& g, int wr) {
     return g.M % (128 * wr) == 0 && g.N % GB_T == 0 && g.K % GB_K == 0 && g.splits == 1 && !g.slab_only && !g.A2;
 }
@@ -929,6 +1161,12 @@ extern "C" int cst_gemm_bf16(const void* A, long lda, const void* B, long ldb,
         const long t256 = (long)(M / GB_T) * (N / GB_T);
         const bool want = tile == 256 || tile == 252 || (tile == 0 && splitk <= 1 && big_mode == 2) ||
                           (tile == 0 && splitk <= 1 && big_mode == 1 && N >= 1024 && K >= 256 && t256 >= 128);
+        if (tile == 248 && splits == 1 && bgemm_lc_ok(g)) {          // 248: loader / consumer persistent kernel (256 x 128 tiles)
+            bgemm_lc_launch(g, st);
+            CST_LAUNCH_CHECK("cst_gemm_bf16 (loader/consumer)");
+            return CST_OK;
+        }
+        if (tile == 248) tile = 0;
         const int wr = tile == 256 ? 2 : 1;
         if (want && splits == 1 && bgemm_big_ok(g, wr)) {
             if (wr == 2) bgemm_big_launch_t<2, 4>(g, st);
