@@ -30,7 +30,9 @@ def mix32(seed, stream, idx):
 
 
 def keep_threshold(p):
-    return int(np.floor(float(p) * 16777216.0))
+    """floor(p * 2^24) in the kernel's arithmetic (cst_make_drop: float p, float product): 0.3f * 2^24 rounds to 5033165.0 in fp32
+    where the float64 product floors to 5033164 -- one element in 16.7 M, found by a 21 M-element GEMM epilogue test."""
+    return int(np.floor(np.float32(np.float32(p) * np.float32(16777216.0))))
 
 
 def dropout_mask(seed, stream, shape, p):
