@@ -8,11 +8,13 @@
 // loads of tile t+1 cannot stay in flight across the barrier without a second register set.  Here
 // operands are already bf16 and K-major on both sides (transposed copies are made once by
 // cst_cast_bf16 / cst_transpose_bf16, so forward, dgrad and wgrad are all NT products), so tiles go
-// HBM -> LDS with global_load_lds_dwordx4 (no VGPR destination) into a 3-stage ring:
-//   iteration t:  s_waitcnt vmcnt(loads of the one newer tile) ; s_barrier ; issue tile t+2 ;
+// HBM -> LDS with global_load_lds_dwordx4 (no VGPR destination) into an NSTAGE-deep ring:
+//   iteration t:  s_waitcnt vmcnt(loads of the newer tiles) ; s_barrier ; issue tile t+NSTAGE-1 ;
 //                 ds_read_b128 fragments of tile t ; 32 x v_mfma_f32_16x16x32_bf16
-// i.e. one raw barrier per K-tile and two tiles of loads in flight behind the MFMAs (counted vmcnt,
+// i.e. one raw barrier per K-tile and NSTAGE-1 tiles of loads in flight behind the MFMAs (counted vmcnt,
 // never a drain inside the loop; all LDS lives in ONE array so hipcc adds no vmcnt(0) of its own).
+// The shipped dispatch instantiates NSTAGE = 2 only (48 KiB at 64 x 128: three workgroups per CU; 3- and 4-deep rings
+// were measured slower because they cost a resident workgroup -- tile codes 65/129/130 keep them reachable for benchmarks).
 // LDS image = [rows][128 B] with the 16-byte slot XOR-swizzle of gemm.hip; because a
 // global_load_lds wave-instruction writes 1 KiB linearly (lane l -> base + 16 l), the swizzle is
 // applied to the per-lane SOURCE address (same 128-byte line, so coalescing is unchanged).
@@ -187,6 +189,7 @@ struct BGemmArgs {
     int splits, k_per_split;        // k_per_split multiple of 64
     int slab_only;                  // write the raw partial product(s) to the slab even when splits == 1
     float* slab;
+    int abl;                        // timing ablations (CST_GB_ABL, tools/gemm_bench.py abl): 1 no DMA, 2 no MFMA, 4 no fragment reads, 8 no write-out
 };
 
 constexpr int BBK = 64;             // bf16 elements of K per tile = 128 bytes per row
@@ -271,6 +274,99 @@ __device__ __forceinline__ void bgemm_store4(const BGemmArgs& g, uint32_t dseed,
         u.x = (uint32_t)f2bf16(o[0]) | ((uint32_t)f2bf16(o[1]) << 16);
         u.y = (uint32_t)f2bf16(o[2]) | ((uint32_t)f2bf16(o[3]) << 16);
         *reinterpret_cast<uint2*>(g.Cb + (long)m * g.ldcb + n) = u;
+    }
+}
+
+// Wave-level write-out of a staged [ROWS][64] fp32 sub-tile (LDS byte address cs, row stride 256 B) to rows m0.., columns n0..n0+63.
+//
+// Why this shape (round 2, tools/gemm_bench.py abl): gfx950 counts loads AND stores in vmcnt, in issue order.  The per-segment
+// loop this replaces (LDS read -> optional bias / addend / aux loads -> store, all behind runtime tests) made hipcc put
+// s_waitcnt vmcnt(0) in front of every segment -- once for the C++ LDS read (it cannot prove an LDS-DMA is not pending), once for
+// the loads that follow the previous segment's store -- so each wave paid one full store round trip per 1 KiB segment: the write-out
+// alone took 28 us (64 x 128 tiles) to 50 us (256 x 256) of a 54-79 us product.  Here a wave first requests its whole sub-tile from
+// LDS (inline asm: invisible to that pass) and every per-element operand of the batch, waits once, then issues all its stores back to
+// back.  Per-column operands (bias, fp8 channel scale) are loaded once per lane: a lane keeps the same four columns in every segment.
+// Requires bgemm_vec_ok and the sub-tile fully inside the matrix (edge tiles keep the element-wise path).
+template <int ROWS>
+__device__ __forceinline__ void bgemm_write_rows(const BGemmArgs& g, uint32_t dseed, unsigned cs, int m0, int n0, int lane) {
+    constexpr int NB = 4;                               // segments (4 rows x 256 B each) per batch
+    static_assert(ROWS % (4 * NB) == 0, "whole batches");
+    const int r4 = lane >> 4, n = n0 + ((lane & 15) << 2);
+    float s4[4] = {1.f, 1.f, 1.f, 1.f}, b4[4] = {0.f, 0.f, 0.f, 0.f};
+    if (g.bscale) { const float4 t = *reinterpret_cast<const float4*>(g.bscale + n); s4[0] = t.x; s4[1] = t.y; s4[2] = t.z; s4[3] = t.w; }
+    if (g.bias) { const float4 t = *reinterpret_cast<const float4*>(g.bias + n); b4[0] = t.x; b4[1] = t.y; b4[2] = t.z; b4[3] = t.w; }
+    unsigned ad0 = cs + r4 * 256 + ((lane & 15) << 4);
+    const int act = g.act;
+    const float alpha = g.alpha;
+    const bool has_add = g.addend != nullptr, has_old = g.C && g.accumulate;
+    // v > 0 ? v * ps : v * ns   (nz: the negative side is an exact +0, as the element-wise path writes it)
+    const float ps = act == 3 ? g.gate_scale : 1.f, ns = (act == 2 || act == 4) ? 0.1f : (act == 0 ? 1.f : 0.f);
+    const bool nz = act == 1 || act == 3;
+    // per-lane row pointers, advanced by four rows per segment (null streams are never dereferenced)
+    float* cp = g.C ? g.C + (long)(m0 + r4) * g.ldc + n : nullptr;
+    bf16_t* cbp = g.Cb ? g.Cb + (long)(m0 + r4) * g.ldcb + n : nullptr;
+    const float* ap = has_add ? g.addend + (long)(m0 + r4) * g.ldadd + n : nullptr;
+    const bf16_t* xp = act >= 3 ? g.aux + (long)(m0 + r4) * g.ldaux + n : nullptr;
+    const long c4 = 4 * g.ldc, cb4 = 4 * g.ldcb, a4s = 4 * g.ldadd, x4s = 4 * g.ldaux;
+    uint32_t didx = (uint32_t)((long)(m0 + r4) * g.N + n);
+#pragma unroll 1
+    for (int b0 = 0; b0 < ROWS / 4; b0 += NB) {
+        u32x4_t v[NB];
+        float4 ad[NB], old[NB];
+        uint2 ax[NB];
+#pragma unroll
+        for (int i = 0; i < NB; ++i) v[i] = lds_read128(ad0 + i * 1024);
+        ad0 += NB * 1024;
+        if (has_add) {
+#pragma unroll
+            for (int i = 0; i < NB; ++i) ad[i] = *reinterpret_cast<const float4*>(ap + i * a4s);
+            ap += NB * a4s;
+        }
+        if (act >= 3) {
+#pragma unroll
+            for (int i = 0; i < NB; ++i) ax[i] = *reinterpret_cast<const uint2*>(xp + i * x4s);
+            xp += NB * x4s;
+        }
+        if (has_old) {
+#pragma unroll
+            for (int i = 0; i < NB; ++i) old[i] = *reinterpret_cast<const float4*>(cp + i * c4);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            float o[4] = {__uint_as_float(v[i].x), __uint_as_float(v[i].y), __uint_as_float(v[i].z), __uint_as_float(v[i].w)};
+            float x4[4] = {1.f, 1.f, 1.f, 1.f};
+            if (act >= 3) {
+                x4[0] = bf162f((bf16_t)(ax[i].x & 0xffffu)); x4[1] = bf162f((bf16_t)(ax[i].x >> 16));
+                x4[2] = bf162f((bf16_t)(ax[i].y & 0xffffu)); x4[3] = bf162f((bf16_t)(ax[i].y >> 16));
+            }
+            // activation as two wave-uniform slopes and a gate value (act 0-2: the value itself, act 3-4: aux): no branches per element
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float w = alpha * (o[e] * s4[e]) + b4[e];
+                if (has_add) w += (&ad[i].x)[e];
+                const float gv = act >= 3 ? x4[e] : w;
+                o[e] = gv > 0.f ? w * ps : (nz ? 0.f : w * ns);
+            }
+            if (g.drop.p > 0.f) {
+                const uint32_t di = didx + (uint32_t)(4 * i) * (uint32_t)g.N;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] *= cst_drop_mask(g.drop, dseed, di + e);
+            }
+            if (cp) {
+                if (has_old) { o[0] += old[i].x; o[1] += old[i].y; o[2] += old[i].z; o[3] += old[i].w; }
+                *reinterpret_cast<float4*>(cp + i * c4) = make_float4(o[0], o[1], o[2], o[3]);
+            }
+            if (cbp) {
+                uint2 u;
+                u.x = (uint32_t)f2bf16(o[0]) | ((uint32_t)f2bf16(o[1]) << 16);
+                u.y = (uint32_t)f2bf16(o[2]) | ((uint32_t)f2bf16(o[3]) << 16);
+                *reinterpret_cast<uint2*>(cbp + i * cb4) = u;
+            }
+        }
+        if (cp) cp += NB * c4;
+        if (cbp) cbp += NB * cb4;
+        didx += (uint32_t)(4 * NB) * (uint32_t)g.N;
     }
 }
 
@@ -366,6 +462,7 @@ __global__ __launch_bounds__(256) void cst_gemm_bf16_kernel(BGemmArgs g) {
     const int nk = (kend - kbeg) / BBK;
 
     auto issue = [&](int t) {
+        if (g.abl & 1) return;
         char* st = smem + (t % NSTAGE) * ST_BYTES;
         const int k = kbeg + t * BBK;
         const long ka = TT ? (long)k * g.lda : k, kb = TT ? (long)k * g.ldb : k;     // TT: k advances rows
@@ -465,15 +562,16 @@ __global__ __launch_bounds__(256) void cst_gemm_bf16_kernel(BGemmArgs g) {
         };
         // NT: both 32-wide k halves are requested before the first MFMA (the second half's reads retire under
         // the first half's MFMAs); TT issues twice as many (64-bit) reads, more than lgkmcnt can count: half by half
-        read_half(0);
+        if (!(g.abl & 4)) read_half(0);
         if constexpr (!TT) {
-            read_half(1);
+            if (!(g.abl & 4)) read_half(1);
             asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(TM + TN) : "memory");      // first half landed
         } else {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
         __builtin_amdgcn_sched_barrier(0);
         widen(0);
+        if (!(g.abl & 2))
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -484,6 +582,7 @@ __global__ __launch_bounds__(256) void cst_gemm_bf16_kernel(BGemmArgs g) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
         widen(1);
+        if (!(g.abl & 2))
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -492,6 +591,7 @@ __global__ __launch_bounds__(256) void cst_gemm_bf16_kernel(BGemmArgs g) {
                                                                     __builtin_bit_cast(bf16x8_t, bfr[1][j]), acc[i][j], 0, 0, 0);
     }
     __syncthreads();                                  // all tile reads done before smem is reused for C
+    if (g.abl & 8) return;
 
     if (g.splits > 1 || g.slab_only) {
         float* slab = g.slab + (((long)blockIdx.z * g.splits + blockIdx.y) * g.M) * g.N;
@@ -524,6 +624,11 @@ __global__ __launch_bounds__(256) void cst_gemm_bf16_kernel(BGemmArgs g) {
     __builtin_amdgcn_wave_barrier();
     constexpr int C4 = WN / 4;
     const bool vec = bgemm_vec_ok(g);
+    static_assert(CLD == 64, "bgemm_write_rows assumes 256-byte staging rows");
+    if (vec && m0 + wm * WM + WM <= g.M && n0 + wn * WN + WN <= g.N) {        // wave-uniform: the whole sub-tile is inside the matrix
+        bgemm_write_rows<WM>(g, dseed, lds_base + wave * WM * CLD * 4, m0 + wm * WM, n0 + wn * WN, lane);
+        return;
+    }
 #pragma unroll
     for (int it = 0; it < WM * C4 / 64; ++it) {
         const int idx = lane + 64 * it;
@@ -664,6 +769,8 @@ __global__ __launch_bounds__(256 * WR, 2) void cst_gemm_bf16_big_kernel(BGemmArg
     constexpr int PA = BM / 16 / NW, PB = GB_T / 16 / NW;      // DMA pieces (16 rows) per wave per K-tile
     constexpr int D = NST - 1;                                  // prefetch distance in K-tiles
     static_assert(D == 2 || D == 3, "wait counts below are written out for prefetch distances 2 and 3");
+    const int abl = gn >> 16;               // timing ablations (CST_GB_ABL): 1 = no DMA, 2 = no MFMA, 4 = no fragment reads
+    gn &= 0xffff;
     const int tilesM = g.M / BM, tilesN = g.N / GB_T;
     int id;
     {
@@ -689,6 +796,7 @@ __global__ __launch_bounds__(256 * WR, 2) void cst_gemm_bf16_big_kernel(BGemmArg
     const bf16_t* abase = g.A + (long)(m0 + (lane >> 2)) * g.lda + (src_slot << 3);
     const bf16_t* bbase = g.B + (long)(n0 + (lane >> 2)) * g.ldb + (src_slot << 3);
     auto issue_a = [&](int t) {
+        if (abl & 1) return;
         char* st = smem + (t % NST) * STAGE;
         const long k = (long)t * GB_K;
 #pragma unroll
@@ -698,6 +806,7 @@ __global__ __launch_bounds__(256 * WR, 2) void cst_gemm_bf16_big_kernel(BGemmArg
         }
     };
     auto issue_b = [&](int t) {
+        if (abl & 1) return;
         char* st = smem + (t % NST) * STAGE + A_BYTES;
         const long k = (long)t * GB_K;
 #pragma unroll
@@ -756,17 +865,17 @@ __global__ __launch_bounds__(256 * WR, 2) void cst_gemm_bf16_big_kernel(BGemmArg
     {                                                                                                           \
         const unsigned cur = (t % NST) * STAGE, nxt = ((t + 1) % NST) * STAGE;                                  \
         if (t + D < nk) issue_b(t + D);                                                                         \
-        gb_read_a<1, 1>(f, a_ad + cur);                                                                         \
-        gb_mfma<0, SB, 0>(f, acc);                                                                              \
+        if (!(abl & 4)) gb_read_a<1, 1>(f, a_ad + cur);                                                         \
+        if (!(abl & 2)) gb_mfma<0, SB, 0>(f, acc);                                                                            \
         GB_PHASE_END()                                                                                          \
         GB_WAIT_NEXT()                                                                                          \
         __builtin_amdgcn_s_barrier();                                                                           \
         if (t + D < nk) issue_a(t + D);                                                                         \
-        if (t + 1 < nk) {                                                                                       \
+        if (t + 1 < nk && !(abl & 4)) {                                                                         \
             gb_read_a<0, 0>(f, a_ad + nxt);                                                                     \
             gb_read_b<1 - SB>(f, b_ad + nxt);                                                                   \
         }                                                                                                       \
-        gb_mfma<1, SB, 1>(f, acc);                                                                              \
+        if (!(abl & 2)) gb_mfma<1, SB, 1>(f, acc);                                                                            \
         GB_PHASE_END()                                                                                          \
     }
     int t = 0;
@@ -781,6 +890,7 @@ __global__ __launch_bounds__(256 * WR, 2) void cst_gemm_bf16_big_kernel(BGemmArg
 #undef GB_WAIT_NEXT
 #undef GB_PHASE_END
     __syncthreads();                                  // every fragment read is done before the ring becomes C staging
+    if (abl & 8) return;                              // ablation: no write-out
 
     // epilogue: the wave tile's two 64 x 64 halves through LDS (16 KiB per wave), whole 256-byte row segments per store
     const uint32_t dseed = g.drop.p > 0.f ? cst_drop_seed(g.drop) : 0u;
@@ -797,17 +907,16 @@ __global__ __launch_bounds__(256 * WR, 2) void cst_gemm_bf16_big_kernel(BGemmArg
 #pragma unroll
                 for (int r = 0; r < 4; ++r) Cs[(i * 16 + lq * 4 + r) * CLD + j * 16 + lr] = acc[mh * 4 + i][j][r];
         __builtin_amdgcn_wave_barrier();
+        if (vec) bgemm_write_rows<64>(g, dseed, lds_base + wave * 64 * CLD * 4, m0 + wr * 128 + mh * 64, n0 + wc * 64, lane);
+        else {
 #pragma unroll 4
-        for (int it = 0; it < 64 * C4 / 64; ++it) {
-            const int idx = lane + 64 * it;
-            const int rr = idx / C4, cc = (idx % C4) * 4;
-            const int m = m0 + wr * 128 + mh * 64 + rr, n = n0 + wc * 64 + cc;
-            const float4 a4 = *reinterpret_cast<const float4*>(&Cs[rr * CLD + cc]);
-            const float av[4] = {a4.x, a4.y, a4.z, a4.w};
-            if (vec) bgemm_store4(g, dseed, m, n, av);
-            else {
+            for (int it = 0; it < 64 * C4 / 64; ++it) {
+                const int idx = lane + 64 * it;
+                const int rr = idx / C4, cc = (idx % C4) * 4;
+                const int m = m0 + wr * 128 + mh * 64 + rr, n = n0 + wc * 64 + cc;
+                const float4 a4 = *reinterpret_cast<const float4*>(&Cs[rr * CLD + cc]);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) bgemm_store(g, dseed, m, n + e, av[e]);
+                for (int e = 0; e < 4; ++e) bgemm_store(g, dseed, m, n + e, (&a4.x)[e]);
             }
         }
         __builtin_amdgcn_wave_barrier();
@@ -965,17 +1074,16 @@ __global__ __launch_bounds__(512, 2) void cst_gemm_bf16_lc_kernel(BGemmArgs g, i
 #pragma unroll
                     for (int r = 0; r < 4; ++r) Cs[(i * 16 + lq * 4 + r) * 64 + jj * 16 + lr] = acc[q * 2 + i][jj][r];
             __builtin_amdgcn_wave_barrier();
+            if (vec) bgemm_write_rows<32>(g, dseed, (unsigned)(uintptr_t)(__attribute__((address_space(3))) float*)Cs, m0 + wr * 128 + q * 32, n0 + wc * 64, lane);
+            else {
 #pragma unroll 4
-            for (int it = 0; it < 8; ++it) {
-                const int idx = lane + 64 * it;
-                const int rr = idx >> 4, cc = (idx & 15) * 4;
-                const int m = m0 + wr * 128 + q * 32 + rr, n = n0 + wc * 64 + cc;
-                const float4 a4 = *reinterpret_cast<const float4*>(&Cs[rr * 64 + cc]);
-                const float av[4] = {a4.x, a4.y, a4.z, a4.w};
-                if (vec) bgemm_store4(g, dseed, m, n, av);
-                else {
+                for (int it = 0; it < 8; ++it) {
+                    const int idx = lane + 64 * it;
+                    const int rr = idx >> 4, cc = (idx & 15) * 4;
+                    const int m = m0 + wr * 128 + q * 32 + rr, n = n0 + wc * 64 + cc;
+                    const float4 a4 = *reinterpret_cast<const float4*>(&Cs[rr * 64 + cc]);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) bgemm_store(g, dseed, m, n + e, av[e]);
+                    for (int e = 0; e < 4; ++e) bgemm_store(g, dseed, m, n + e, (&a4.x)[e]);
                 }
             }
             __builtin_amdgcn_wave_barrier();
@@ -1053,7 +1161,9 @@ static bool bgemm_big_ok(const BGemmArgs& g, int wr) {
 template <int WR, int NST>
 static int bgemm_big_launch_t(const BGemmArgs& g, hipStream_t st) {
     const size_t lds = (size_t)NST * (128 * WR + GB_T) * GB_ROW;
-    static const int gn = getenv("CST_GB_GN") ? atoi(getenv("CST_GB_GN")) : 2;        // tile columns per XCD strip (A/B panel sharing)
+    static const int gn0 = getenv("CST_GB_GN") ? atoi(getenv("CST_GB_GN")) : 2;       // tile columns per XCD strip (A/B panel sharing)
+    const char* ab = getenv("CST_GB_ABL");                                             // timing ablations (tools/gemm_bench.py abl): results are wrong
+    const int gn = gn0 | ((ab ? atoi(ab) : 0) << 16);
     static bool attr_done = false;
     if (!attr_done) {
         (void)hipFuncSetAttribute((const void*)cst_gemm_bf16_big_kernel<WR, NST>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -1114,6 +1224,7 @@ extern "C" int cst_gemm_bf16(const void* A, long lda, const void* B, long ldb,
     g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.ldcb = ldcb; g.ldadd = ldadd; g.ldaux = ldaux;
     g.M = M; g.N = N; g.K = K; g.act = act; g.alpha = alpha; g.gate_scale = gate_scale; g.accumulate = accumulate;
     g.slab_only = 0;
+    { const char* ab = getenv("CST_GB_ABL"); g.abl = ab ? atoi(ab) : 0; }       // bench-only timing ablations (wrong results)
     g.drop = cst_make_drop(drop_p, drop_seed, drop_stream, drop_seed_dev);
     // tile / ring / split choice (tools/gemm_bench.py bf16nt): the 2-stage ring with two workgroups per
     // CU beats the 3-stage one at these sizes; 64x128 tiles when they alone give >= 256 workgroups,

@@ -65,7 +65,9 @@ int cst_gemm_profile_read(int which, double* total_ms_host, double* total_flops_
  * roofline.by_shape.  Call before cst_gemm_profile_read(1, ...), which clears the list. */
 int cst_gemm_profile_shapes(long max_records, int* mnk_host, double* ms_host, int* which_host, long* count_host);
 
-/* bf16-operand NT GEMM with direct-to-LDS (global_load_lds) staging in a 3-stage ring:
+/* bf16-operand NT GEMM with direct-to-LDS (global_load_lds) staging in a 2-stage ring (`tile` 0 = chosen by shape between
+ * 64x128 and 128x128; 64 / 128 force one; 65 / 129 / 130 = deeper rings, 256 / 252 / 248 = the 256-wide and loader/consumer
+ * kernels, measured slower and kept for benchmarks only -- they need M % 256, N % 256 (248: N % 128) and no split-K):
  * C[M,N] (fp32) and/or Cb[M,N] (bf16) = epilogue(alpha * A[M,K] . B[N,K]^T); A, B bf16 (uint16 storage),
  * K contiguous and a multiple of 64 (zero padding is written by cst_cast_bf16), lda/ldb multiples of
  * 8, 16-byte aligned.  Epilogue as cst_gemm (aux is bf16).  The encoder layers' QKV / out-proj / FFN

@@ -110,7 +110,38 @@ def main_pmc():
             torch.cuda.synchronize()
 
 
+def main_abl():
+    """Where the 256-wide kernels' time goes: the same launch with parts switched off (CST_GB_ABL bits: 1 no DMA, 2 no MFMA, 4 no
+    fragment reads, 8 no write-out; results are wrong, only the time means something)."""
+    shapes = [(9216, 2048, 768), (4608, 2304, 768), (9216, 768, 2048), (16384, 4096, 1024)]
+    masks = [0, 8, 1, 9, 2, 6, 14, 7, 15]
+    for M, N, K in shapes:
+        A, B = torch.randn(M, K, device="cuda"), torch.randn(N, K, device="cuda")
+        Ab, _ = ops.cast_bf16(A, want_t=False)
+        Bb, _ = ops.cast_bf16(B, want_t=False)
+        C = torch.empty(M, N, device="cuda")
+        for tile in (64, 128, 256, 252):
+            row = []
+            for mask in masks:
+                os.environ["CST_GB_ABL"] = str(mask)
+                for _ in range(3):
+                    ops.gemm_bf16(Ab, Bb, M, N, C=C, tile=tile)
+                torch.cuda.synchronize()
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record()
+                for _ in range(20):
+                    ops.gemm_bf16(Ab, Bb, M, N, C=C, tile=tile)
+                b.record()
+                torch.cuda.synchronize()
+                row.append(a.elapsed_time(b) * 1000 / 20)
+            os.environ["CST_GB_ABL"] = "0"
+            print(f"{M}x{N}x{K} t{tile}  " + "  ".join(f"abl{m}:{u:6.1f}" for m, u in zip(masks, row)), flush=True)
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "abl":
+        main_abl()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "pmc":
         main_pmc()
         sys.exit(0)
