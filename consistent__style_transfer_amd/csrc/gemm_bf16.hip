@@ -208,6 +208,14 @@ __device__ __forceinline__ u32x4_t lds_read128(unsigned addr) {
     return v;
 }
 
+// Four 16-byte reads 1 KiB apart AND their wait in one statement: the compiler believes an asm's outputs are valid when the statement
+// ends, so a separate wait statement leaves it free to copy a not-yet-landed register in between (it did: two of four columns wrong).
+__device__ __forceinline__ void lds_read128x4_wait(unsigned addr, u32x4_t (&v)[4]) {
+    asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:1024\n\tds_read_b128 %2, %4 offset:2048\n\t"
+                 "ds_read_b128 %3, %4 offset:3072\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]) : "v"(addr) : "memory");
+}
+
 typedef __attribute__((ext_vector_type(2))) unsigned u32x2_t;
 __device__ __forceinline__ u32x2_t lds_read64_tr(unsigned addr) {
     u32x2_t v;
@@ -232,7 +240,7 @@ __device__ __forceinline__ void bgemm_store(const BGemmArgs& g, uint32_t dseed, 
 
 // Which of the epilogue's streams can move as 16-byte (fp32) / 8-byte (bf16) vectors: four
 // consecutive columns per lane.  Evaluated once per kernel (wave-uniform).
-__device__ __forceinline__ bool bgemm_vec_ok(const BGemmArgs& g) {
+__host__ __device__ __forceinline__ bool bgemm_vec_ok(const BGemmArgs& g) {
     const bool vc = !g.C || ((g.ldc % 4 == 0) && ((reinterpret_cast<uintptr_t>(g.C) & 15) == 0));
     const bool vb = !g.Cb || ((g.ldcb % 4 == 0) && ((reinterpret_cast<uintptr_t>(g.Cb) & 7) == 0));
     const bool va = !g.addend || ((g.ldadd % 4 == 0) && ((reinterpret_cast<uintptr_t>(g.addend) & 15) == 0));
@@ -287,18 +295,30 @@ __device__ __forceinline__ void bgemm_store4(const BGemmArgs& g, uint32_t dseed,
 // LDS (inline asm: invisible to that pass) and every per-element operand of the batch, waits once, then issues all its stores back to
 // back.  Per-column operands (bias, fp8 channel scale) are loaded once per lane: a lane keeps the same four columns in every segment.
 // Requires bgemm_vec_ok and the sub-tile fully inside the matrix (edge tiles keep the element-wise path).
-template <int ROWS>
-__device__ __forceinline__ void bgemm_write_rows(const BGemmArgs& g, uint32_t dseed, unsigned cs, int m0, int n0, int lane) {
+// LOADS = false is the instantiation for launches without per-element operands (no addend, no aux gate, no accumulate): its loop
+// holds no global load, so hipcc has no reason to wait on vmcnt inside it and the stores of a wave never wait for each other.  With
+// LOADS = true every batch's loads come after the previous batch's stores in the counter, i.e. one store round trip per batch.
+// this lane's four columns' bias and fp8 channel scale (the same in every segment), pinned in registers on return
+__device__ __forceinline__ void bgemm_col_operands(const BGemmArgs& g, int n0, int lane, float (&s4)[4], float (&b4)[4]) {
+    const int n = n0 + ((lane & 15) << 2);
+    s4[0] = s4[1] = s4[2] = s4[3] = 1.f;
+    b4[0] = b4[1] = b4[2] = b4[3] = 0.f;
+    if (g.bscale) { const float4 t = *reinterpret_cast<const float4*>(g.bscale + n); s4[0] = t.x; s4[1] = t.y; s4[2] = t.z; s4[3] = t.w; }
+    if (g.bias) { const float4 t = *reinterpret_cast<const float4*>(g.bias + n); b4[0] = t.x; b4[1] = t.y; b4[2] = t.z; b4[3] = t.w; }
+    // their vmcnt wait must not end up inside a store loop, behind stores
+    asm volatile("" : "+v"(s4[0]), "+v"(s4[1]), "+v"(s4[2]), "+v"(s4[3]), "+v"(b4[0]), "+v"(b4[1]), "+v"(b4[2]), "+v"(b4[3]));
+}
+
+template <int ROWS, bool LOADS>
+__device__ __forceinline__ void bgemm_write_rows_t(const BGemmArgs& g, uint32_t dseed, unsigned cs, int m0, int n0, int lane,
+                                                   const float (&s4)[4], const float (&b4)[4]) {
     constexpr int NB = 4;                               // segments (4 rows x 256 B each) per batch
     static_assert(ROWS % (4 * NB) == 0, "whole batches");
     const int r4 = lane >> 4, n = n0 + ((lane & 15) << 2);
-    float s4[4] = {1.f, 1.f, 1.f, 1.f}, b4[4] = {0.f, 0.f, 0.f, 0.f};
-    if (g.bscale) { const float4 t = *reinterpret_cast<const float4*>(g.bscale + n); s4[0] = t.x; s4[1] = t.y; s4[2] = t.z; s4[3] = t.w; }
-    if (g.bias) { const float4 t = *reinterpret_cast<const float4*>(g.bias + n); b4[0] = t.x; b4[1] = t.y; b4[2] = t.z; b4[3] = t.w; }
     unsigned ad0 = cs + r4 * 256 + ((lane & 15) << 4);
     const int act = g.act;
     const float alpha = g.alpha;
-    const bool has_add = g.addend != nullptr, has_old = g.C && g.accumulate;
+    const bool has_add = LOADS && g.addend != nullptr, has_old = LOADS && g.C && g.accumulate, has_aux = LOADS && act >= 3;
     // v > 0 ? v * ps : v * ns   (nz: the negative side is an exact +0, as the element-wise path writes it)
     const float ps = act == 3 ? g.gate_scale : 1.f, ns = (act == 2 || act == 4) ? 0.1f : (act == 0 ? 1.f : 0.f);
     const bool nz = act == 1 || act == 3;
@@ -306,46 +326,49 @@ __device__ __forceinline__ void bgemm_write_rows(const BGemmArgs& g, uint32_t ds
     float* cp = g.C ? g.C + (long)(m0 + r4) * g.ldc + n : nullptr;
     bf16_t* cbp = g.Cb ? g.Cb + (long)(m0 + r4) * g.ldcb + n : nullptr;
     const float* ap = has_add ? g.addend + (long)(m0 + r4) * g.ldadd + n : nullptr;
-    const bf16_t* xp = act >= 3 ? g.aux + (long)(m0 + r4) * g.ldaux + n : nullptr;
+    const bf16_t* xp = has_aux ? g.aux + (long)(m0 + r4) * g.ldaux + n : nullptr;
     const long c4 = 4 * g.ldc, cb4 = 4 * g.ldcb, a4s = 4 * g.ldadd, x4s = 4 * g.ldaux;
     uint32_t didx = (uint32_t)((long)(m0 + r4) * g.N + n);
 #pragma unroll 1
     for (int b0 = 0; b0 < ROWS / 4; b0 += NB) {
         u32x4_t v[NB];
-        float4 ad[NB], old[NB];
-        uint2 ax[NB];
+        float4 ad[LOADS ? NB : 1], old[LOADS ? NB : 1];
+        uint2 ax[LOADS ? NB : 1];
+        if constexpr (LOADS) {
+            if (has_add) {
 #pragma unroll
-        for (int i = 0; i < NB; ++i) v[i] = lds_read128(ad0 + i * 1024);
+                for (int i = 0; i < NB; ++i) ad[i] = *reinterpret_cast<const float4*>(ap + i * a4s);
+                ap += NB * a4s;
+            }
+            if (has_aux) {
+#pragma unroll
+                for (int i = 0; i < NB; ++i) ax[i] = *reinterpret_cast<const uint2*>(xp + i * x4s);
+                xp += NB * x4s;
+            }
+            if (has_old) {
+#pragma unroll
+                for (int i = 0; i < NB; ++i) old[i] = *reinterpret_cast<const float4*>(cp + i * c4);
+            }
+        }
+        static_assert(NB == 4, "lds_read128x4_wait");
+        lds_read128x4_wait(ad0, v);
         ad0 += NB * 1024;
-        if (has_add) {
-#pragma unroll
-            for (int i = 0; i < NB; ++i) ad[i] = *reinterpret_cast<const float4*>(ap + i * a4s);
-            ap += NB * a4s;
-        }
-        if (act >= 3) {
-#pragma unroll
-            for (int i = 0; i < NB; ++i) ax[i] = *reinterpret_cast<const uint2*>(xp + i * x4s);
-            xp += NB * x4s;
-        }
-        if (has_old) {
-#pragma unroll
-            for (int i = 0; i < NB; ++i) old[i] = *reinterpret_cast<const float4*>(cp + i * c4);
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
             float o[4] = {__uint_as_float(v[i].x), __uint_as_float(v[i].y), __uint_as_float(v[i].z), __uint_as_float(v[i].w)};
             float x4[4] = {1.f, 1.f, 1.f, 1.f};
-            if (act >= 3) {
-                x4[0] = bf162f((bf16_t)(ax[i].x & 0xffffu)); x4[1] = bf162f((bf16_t)(ax[i].x >> 16));
-                x4[2] = bf162f((bf16_t)(ax[i].y & 0xffffu)); x4[3] = bf162f((bf16_t)(ax[i].y >> 16));
+            if constexpr (LOADS) {
+                if (has_aux) {
+                    x4[0] = bf162f((bf16_t)(ax[i].x & 0xffffu)); x4[1] = bf162f((bf16_t)(ax[i].x >> 16));
+                    x4[2] = bf162f((bf16_t)(ax[i].y & 0xffffu)); x4[3] = bf162f((bf16_t)(ax[i].y >> 16));
+                }
             }
             // activation as two wave-uniform slopes and a gate value (act 0-2: the value itself, act 3-4: aux): no branches per element
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 float w = alpha * (o[e] * s4[e]) + b4[e];
-                if (has_add) w += (&ad[i].x)[e];
-                const float gv = act >= 3 ? x4[e] : w;
+                if constexpr (LOADS) { if (has_add) w += (&ad[i].x)[e]; }
+                const float gv = has_aux ? x4[e] : w;
                 o[e] = gv > 0.f ? w * ps : (nz ? 0.f : w * ns);
             }
             if (g.drop.p > 0.f) {
@@ -354,7 +377,7 @@ __device__ __forceinline__ void bgemm_write_rows(const BGemmArgs& g, uint32_t ds
                 for (int e = 0; e < 4; ++e) o[e] *= cst_drop_mask(g.drop, dseed, di + e);
             }
             if (cp) {
-                if (has_old) { o[0] += old[i].x; o[1] += old[i].y; o[2] += old[i].z; o[3] += old[i].w; }
+                if constexpr (LOADS) { if (has_old) { o[0] += old[i].x; o[1] += old[i].y; o[2] += old[i].z; o[3] += old[i].w; } }
                 *reinterpret_cast<float4*>(cp + i * c4) = make_float4(o[0], o[1], o[2], o[3]);
             }
             if (cbp) {
@@ -368,6 +391,13 @@ __device__ __forceinline__ void bgemm_write_rows(const BGemmArgs& g, uint32_t ds
         if (cbp) cbp += NB * cb4;
         didx += (uint32_t)(4 * NB) * (uint32_t)g.N;
     }
+}
+
+template <int ROWS>
+__device__ __forceinline__ void bgemm_write_rows(const BGemmArgs& g, uint32_t dseed, unsigned cs, int m0, int n0, int lane,
+                                                 const float (&s4)[4], const float (&b4)[4]) {
+    if (!g.addend && g.act < 3 && !(g.C && g.accumulate)) bgemm_write_rows_t<ROWS, false>(g, dseed, cs, m0, n0, lane, s4, b4);
+    else bgemm_write_rows_t<ROWS, true>(g, dseed, cs, m0, n0, lane, s4, b4);
 }
 
 // TT = false: C = A B^T, A [M,K] and B [N,K] with K contiguous (row reads of the tile: ds_read_b128).
@@ -626,7 +656,9 @@ __global__ __launch_bounds__(256) void cst_gemm_bf16_kernel(BGemmArgs g) {
     const bool vec = bgemm_vec_ok(g);
     static_assert(CLD == 64, "bgemm_write_rows assumes 256-byte staging rows");
     if (vec && m0 + wm * WM + WM <= g.M && n0 + wn * WN + WN <= g.N) {        // wave-uniform: the whole sub-tile is inside the matrix
-        bgemm_write_rows<WM>(g, dseed, lds_base + wave * WM * CLD * 4, m0 + wm * WM, n0 + wn * WN, lane);
+        float s4[4], b4[4];
+        bgemm_col_operands(g, n0 + wn * WN, lane, s4, b4);
+        bgemm_write_rows<WM>(g, dseed, lds_base + wave * WM * CLD * 4, m0 + wm * WM, n0 + wn * WN, lane, s4, b4);
         return;
     }
 #pragma unroll
@@ -898,6 +930,8 @@ __global__ __launch_bounds__(256 * WR, 2) void cst_gemm_bf16_big_kernel(BGemmArg
     static_assert(NW * 64 * CLD * 4 <= NST * STAGE, "C staging must fit the ring");
     float* Cs = reinterpret_cast<float*>(smem) + wave * 64 * CLD;
     const bool vec = bgemm_vec_ok(g);
+    float s4[4], b4[4];
+    if (vec) bgemm_col_operands(g, n0 + wc * 64, lane, s4, b4);
 #pragma unroll
     for (int mh = 0; mh < 2; ++mh) {
 #pragma unroll
@@ -907,7 +941,7 @@ __global__ __launch_bounds__(256 * WR, 2) void cst_gemm_bf16_big_kernel(BGemmArg
 #pragma unroll
                 for (int r = 0; r < 4; ++r) Cs[(i * 16 + lq * 4 + r) * CLD + j * 16 + lr] = acc[mh * 4 + i][j][r];
         __builtin_amdgcn_wave_barrier();
-        if (vec) bgemm_write_rows<64>(g, dseed, lds_base + wave * 64 * CLD * 4, m0 + wr * 128 + mh * 64, n0 + wc * 64, lane);
+        if (vec) bgemm_write_rows<64>(g, dseed, lds_base + wave * 64 * CLD * 4, m0 + wr * 128 + mh * 64, n0 + wc * 64, lane, s4, b4);
         else {
 #pragma unroll 4
             for (int it = 0; it < 64 * C4 / 64; ++it) {
@@ -925,33 +959,40 @@ __global__ __launch_bounds__(256 * WR, 2) void cst_gemm_bf16_big_kernel(BGemmArg
 
 // =============================================================================================
 // Loader / consumer, persistent: 256 x 128 tiles, 4 MFMA waves + 4 DMA waves per workgroup, one workgroup per CU walking
-// its share of the tiles.
+// its share of the tiles (tile code 248).
 //
-// Why (round-2 counters, profiles/round2_gemm_pmc_counters.txt): in every kernel above a wave both issues the tile's
-// global_load_lds pieces and runs its MFMAs, and an LDS-DMA piece costs ~100 cycles to ISSUE (MI355X_MICROARCH.md, cycle
-// constants) -- 6 pieces = ~600 cycles per K-tile against 256 cycles of MFMA at 64 x 128, in-order in the same wave: the
-// matrix pipe idles at 25-28 % however the loop is pipelined (three pipelines, same time).  VMEM and MFMA issue from
-// DIFFERENT waves of a SIMD proceed in the same cycles, so the roles are split: waves 4-7 (one per SIMD) only issue DMA and
-// count vmcnt, waves 0-3 (one per SIMD) only read fragments and issue MFMAs back to back.  One barrier per 32-deep K-tile
-// hands a landed stage to the consumers and a drained stage back to the loaders.  The K-tile stream runs on across tile
-// boundaries (persistent workgroup): while the consumers write a finished tile out -- 128 KB of fp32 per workgroup, the
-// largest HBM stream of these products -- the loaders already have the next tile's first K-tiles in flight.
-//   LDS: NST stages x (A [256][64 B] + B [128][64 B]) = NST x 24 KiB (swizzle as the 256-wide kernel above) + 4 x 8 KiB of C staging.
-//   consumer step g:  barrier(g) ; read fragments of K-tile g+1 (other register set) ; 32 MFMA on K-tile g ; lgkmcnt(0) ;
-//                     after a tile's last K-tile: epilogue from the accumulators (no barrier inside)
-//   loader step g:    vmcnt(pieces of the K-tiles younger than g+1) ; barrier(g) ; DMA K-tile g+NST-1 into the stage K-tile g-1 left
-// Requires M % 256 == 0, N % 128 == 0, K % 32 == 0, no split-K.
+// Why (profiles/round2_gemm_ablation.txt): in the kernels above a product costs (L2 -> LDS fill) + (C write-out) -- the MFMAs
+// are hidden, but the workgroups of a CU fill in lockstep and then write in lockstep, and a wave cannot do both at once:
+// gfx950 counts loads and stores in one vmcnt, so a wave with stores in flight cannot wait for a younger load without waiting
+// for the stores.  Here the roles are split: waves 4-7 only issue LDS-DMA and count vmcnt (loads only), waves 0-3 only read
+// fragments, issue MFMAs and write C (stores only, never waited for).  The K-tile stream runs on across tile boundaries, so
+// while the MFMA waves write a finished tile out the DMA waves already fill the next tile's first K-tiles.
+//   K-tile = 64 (full 128-byte rows: half-line rows, as the 256-wide kernels above use, fetch every line twice and were measured
+//   at half the fill rate).  LDS: 3 stages x (A [256][128 B] + B [128][128 B]) = 144 KiB, image and swizzle of the small-tile
+//   kernel (blds_off).  The stage a tile's last K-tile was read from doubles as its C staging (the loaders get it back at the
+//   next barrier, which the MFMA waves only reach after the write-out).
+//   MFMA waves, K-tile g: barrier(g) ; read A(row half 0) and B of k-half 0 ; then per 32-deep half: read A(row half 1) ; 16 MFMA (row
+//                      half 0) ; read A(row half 0) and B of the next half ; 16 MFMA (row half 1).  Nothing of K-tile g + 1 is read before
+//                      barrier(g + 1): one exposed fragment read per K-tile buys a second K-tile in flight (three stages: one being
+//                      read, two landing).
+//   DMA waves, step g: vmcnt(pieces of K-tile g + 1) -> K-tile g landed ; barrier(g) ; DMA K-tile g + 2 into the stage K-tile g - 1 left
+// Requires M % 256 == 0, N % 128 == 0, K % 64 == 0, no split-K.
 // =============================================================================================
-template <int NST>
-__global__ __launch_bounds__(512, 2) void cst_gemm_bf16_lc_kernel(BGemmArgs g, int gn) {
+__device__ __forceinline__ void lds_write32(unsigned addr, float v) {
+    asm volatile("ds_write_b32 %0, %1" ::"v"(addr), "v"(v) : "memory");
+}
+
+constexpr int LC_NST = 3;
+constexpr int LC_BM = 256, LC_BN = 128;
+constexpr int LC_A_BYTES = LC_BM * BROW, LC_B_BYTES = LC_BN * BROW, LC_STAGE = LC_A_BYTES + LC_B_BYTES;     // 32 + 16 KiB
+
+__global__ __launch_bounds__(512) void cst_gemm_bf16_lc_kernel(BGemmArgs g, int gn) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int BM = 256, BN = 128;
-    constexpr int A_BYTES = BM * GB_ROW, B_BYTES = BN * GB_ROW, STAGE = A_BYTES + B_BYTES;      // 16 + 8 KiB
-    constexpr int D = NST - 1;
-    constexpr int PA = BM / 16 / 4, PB = BN / 16 / 4, PT = PA + PB;                              // pieces per loader wave per K-tile
-    static_assert(D >= 2 && D <= 4, "vmcnt cases below cover prefetch distances 2..4");
+    constexpr int NST = LC_NST, D = NST - 1, BM = LC_BM, BN = LC_BN, STAGE = LC_STAGE;
+    constexpr int PA = BM / 8 / 4, PB = BN / 8 / 4, PT = PA + PB;            // 1-KiB pieces (8 rows) per loader wave per K-tile: 8 + 4
+    static_assert(D == 2, "the vmcnt cases below are written for a prefetch distance of 2");
     const int tilesM = g.M / BM, tilesN = g.N / BN, ntiles = tilesM * tilesN;
-    const int nk = g.K / GB_K;
+    const int nk = g.K / BBK;
     int vb;                                                // virtual workgroup id: consecutive ids share an XCD
     {
         const int nblk = gridDim.x, q = nblk >> 3, r = nblk & 7, xcd = blockIdx.x & 7;
@@ -974,8 +1015,7 @@ __global__ __launch_bounds__(512, 2) void cst_gemm_bf16_lc_kernel(BGemmArgs g, i
     if (wave >= 4) {
         // ------------------------------------------------------------------------------ loaders
         const int lw = wave - 4;
-        const int gsw = (0x1230 >> (4 * (lane >> 4))) & 3;
-        const int src_slot = (lane & 3) ^ gsw;
+        const int lrow = lane >> 3, lps = lane & 7;        // lane lands at (row 8 p + lrow, physical slot lps): fetches logical slot lps ^ lrow
         const bf16_t* abase = nullptr;
         const bf16_t* bbase = nullptr;
         int cur_j = -1;
@@ -984,73 +1024,67 @@ __global__ __launch_bounds__(512, 2) void cst_gemm_bf16_lc_kernel(BGemmArgs g, i
             if (j != cur_j) {
                 int m0, n0;
                 tile_origin(j, m0, n0);
-                abase = g.A + (long)(m0 + (lane >> 2)) * g.lda + (src_slot << 3);
-                bbase = g.B + (long)(n0 + (lane >> 2)) * g.ldb + (src_slot << 3);
+                abase = g.A + (long)(m0 + lrow) * g.lda + ((lps ^ lrow) << 3);
+                bbase = g.B + (long)(n0 + lrow) * g.ldb + ((lps ^ lrow) << 3);
                 cur_j = j;
             }
             char* st = smem + (gk % NST) * STAGE;
-            const long k = (long)t * GB_K;
+            const long k = (long)t * BBK;
 #pragma unroll
             for (int c = 0; c < PA; ++c) {
-                const int r0 = (PA * lw + c) * 16;
-                __builtin_amdgcn_global_load_lds((gbl_ptr_t)(abase + (long)r0 * g.lda + k), (lds_ptr_t)(st + r0 * GB_ROW), 16, 0, 0);
+                const int r0 = (PA * lw + c) * 8;
+                __builtin_amdgcn_global_load_lds((gbl_ptr_t)(abase + (long)r0 * g.lda + k), (lds_ptr_t)(st + r0 * BROW), 16, 0, 0);
             }
 #pragma unroll
             for (int c = 0; c < PB; ++c) {
-                const int r0 = (PB * lw + c) * 16;
-                __builtin_amdgcn_global_load_lds((gbl_ptr_t)(bbase + (long)r0 * g.ldb + k), (lds_ptr_t)(st + A_BYTES + r0 * GB_ROW), 16, 0, 0);
+                const int r0 = (PB * lw + c) * 8;
+                __builtin_amdgcn_global_load_lds((gbl_ptr_t)(bbase + (long)r0 * g.ldb + k), (lds_ptr_t)(st + LC_A_BYTES + r0 * BROW), 16, 0, 0);
             }
         };
         auto wait_younger = [&](int younger) {             // all but the `younger` most recent K-tiles of this wave have landed
-            if (younger >= 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * PT) : "memory");
-            else if (younger == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PT) : "memory");
-            else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PT) : "memory");
+            if (younger >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PT) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         };
         const int pre = min(D, G);
         for (int gk = 0; gk < pre; ++gk) issue(gk);
-        wait_younger(pre - 1);                             // K-tile 0 landed
-        __builtin_amdgcn_s_barrier();                      // barrier(-1)
         for (int gk = 0; gk < G; ++gk) {
-            // issued so far: K-tiles 0 .. min(gk + D, G) - 1; K-tile gk + 1 must have landed
-            const int last = min(gk + D, G) - 1;
-            wait_younger(max(0, last - (gk + 1)));
-            __builtin_amdgcn_s_barrier();                  // barrier(gk)
-            if (gk + D < G) issue(gk + D);
+            // issued so far: K-tiles 0 .. min(gk + D, G) - 1; K-tile gk must have landed -- the one issued after it may stay in flight
+            wait_younger(min(gk + D, G) - 1 - gk);
+            __builtin_amdgcn_s_barrier();                  // barrier(gk): K-tile gk is in LDS; the MFMA waves are done with K-tile gk - 1
+            if (gk + D < G) issue(gk + D);                 // into the stage K-tile gk - 1 left
         }
         return;
     }
 
     // ---------------------------------------------------------------------------------- consumers
-    const int wr = wave >> 1, wc = wave & 1;
+    const int wr = wave >> 1, wc = wave & 1;               // wave tile: rows wr * 128 .. + 127, columns wc * 64 .. + 63
     const int lr = lane & 15, lq = lane >> 4;
     const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
-    const int fsw = (0x1230 >> (4 * ((lr >> 2) & 3))) & 3;
-    const unsigned a_ad = lds_base + (wr * 128 + lr) * GB_ROW + ((lq ^ fsw) << 4);
-    const unsigned b_ad = lds_base + A_BYTES + (wc * 64 + lr) * GB_ROW + ((lq ^ fsw) << 4);
-    float* Cs = reinterpret_cast<float*>(smem + NST * STAGE) + wave * 32 * 64;       // 8 KiB per consumer wave
+    // fragment of row (16 t + lr), k-half kk: 16-byte slot (4 kk + lq) ^ (lr & 7)
+    const unsigned a_ad = lds_base + (wr * 128 + lr) * BROW + ((lq ^ (lr & 7)) << 4);
+    const unsigned b_ad = lds_base + LC_A_BYTES + (wc * 64 + lr) * BROW + ((lq ^ (lr & 7)) << 4);
+    const unsigned a_ad1 = lds_base + (wr * 128 + lr) * BROW + (((4 + lq) ^ (lr & 7)) << 4);               // k-half 1
+    const unsigned b_ad1 = lds_base + LC_A_BYTES + (wc * 64 + lr) * BROW + (((4 + lq) ^ (lr & 7)) << 4);
     const uint32_t dseed = g.drop.p > 0.f ? cst_drop_seed(g.drop) : 0u;
-    const bool vec = bgemm_vec_ok(g);
 
     f32x4_t acc[8][4];
 #pragma unroll
     for (int i = 0; i < 8; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-    struct { u32x4_t a[2][4]; u32x4_t b[2][4]; } f;        // a[row half][row tile] of the current K-tile, b[set][column tile]
+    struct { u32x4_t a[2][4]; u32x4_t b[2][4]; } f;        // a[row half][row tile], b[k-half parity][column tile]
 
-    // fragments: A(mh 0) and B of K-tile g+1 are read during the second half of step g, A(mh 1) of K-tile g during its first half
-#define LC_READ_A(MH, ST_OFF)                                                                      \
+#define LC_READ_A(MH, AD)                                                                          \
     {                                                                                              \
-        const unsigned aa = a_ad + (ST_OFF);                                                       \
-        f.a[MH][0] = lds_read128_off<(MH * 64 + 0) * GB_ROW>(aa);   f.a[MH][1] = lds_read128_off<(MH * 64 + 16) * GB_ROW>(aa);  \
-        f.a[MH][2] = lds_read128_off<(MH * 64 + 32) * GB_ROW>(aa);  f.a[MH][3] = lds_read128_off<(MH * 64 + 48) * GB_ROW>(aa);  \
+        const unsigned aa = (AD);                                                                  \
+        f.a[MH][0] = lds_read128_off<(MH * 64 + 0) * BROW>(aa);   f.a[MH][1] = lds_read128_off<(MH * 64 + 16) * BROW>(aa);  \
+        f.a[MH][2] = lds_read128_off<(MH * 64 + 32) * BROW>(aa);  f.a[MH][3] = lds_read128_off<(MH * 64 + 48) * BROW>(aa);  \
     }
-#define LC_READ_B(SET, ST_OFF)                                                                     \
+#define LC_READ_B(SET, AD)                                                                         \
     {                                                                                              \
-        const unsigned bb = b_ad + (ST_OFF);                                                       \
-        f.b[SET][0] = lds_read128_off<0 * GB_ROW>(bb);      f.b[SET][1] = lds_read128_off<16 * GB_ROW>(bb);     \
-        f.b[SET][2] = lds_read128_off<32 * GB_ROW>(bb);     f.b[SET][3] = lds_read128_off<48 * GB_ROW>(bb);     \
+        const unsigned bb = (AD);                                                                  \
+        f.b[SET][0] = lds_read128_off<0 * BROW>(bb);      f.b[SET][1] = lds_read128_off<16 * BROW>(bb);     \
+        f.b[SET][2] = lds_read128_off<32 * BROW>(bb);     f.b[SET][3] = lds_read128_off<48 * BROW>(bb);     \
     }
 #define LC_MFMA(MH, SB)                                                                            \
     __builtin_amdgcn_s_setprio(1);                                                                 \
@@ -1062,64 +1096,51 @@ __global__ __launch_bounds__(512, 2) void cst_gemm_bf16_lc_kernel(BGemmArgs g, i
 #define LC_WAIT_LDS()                                                                              \
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                             \
     __builtin_amdgcn_sched_barrier(0);
-    auto epilogue = [&](int j) {
+    // write-out of tile j through the stage K-tile gk was read from (8 KiB per wave, 32-row quarters of the 128 x 64 wave tile)
+    auto epilogue = [&](int j, int gk) {
         int m0, n0;
         tile_origin(j, m0, n0);
+        const unsigned cs = lds_base + (gk % NST) * STAGE + wave * 32 * 64 * 4;
+        const unsigned cw = cs + (lq * 4 * 64 + lr) * 4;
+        float s4[4], b4[4];
+        bgemm_col_operands(g, n0 + wc * 64, lane, s4, b4);      // the one vmcnt wait of the write-out (the previous tile's stores are long done)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {                      // 32-row quarters of the 128 x 64 wave tile
+        for (int q = 0; q < 4; ++q) {
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int jj = 0; jj < 4; ++jj)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) Cs[(i * 16 + lq * 4 + r) * 64 + jj * 16 + lr] = acc[q * 2 + i][jj][r];
-            __builtin_amdgcn_wave_barrier();
-            if (vec) bgemm_write_rows<32>(g, dseed, (unsigned)(uintptr_t)(__attribute__((address_space(3))) float*)Cs, m0 + wr * 128 + q * 32, n0 + wc * 64, lane);
-            else {
-#pragma unroll 4
-                for (int it = 0; it < 8; ++it) {
-                    const int idx = lane + 64 * it;
-                    const int rr = idx >> 4, cc = (idx & 15) * 4;
-                    const int m = m0 + wr * 128 + q * 32 + rr, n = n0 + wc * 64 + cc;
-                    const float4 a4 = *reinterpret_cast<const float4*>(&Cs[rr * 64 + cc]);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) bgemm_store(g, dseed, m, n + e, (&a4.x)[e]);
-                }
-            }
-            __builtin_amdgcn_wave_barrier();
+                    for (int r = 0; r < 4; ++r) lds_write32(cw + ((i * 16 + r) * 64 + jj * 16) * 4, acc[q * 2 + i][jj][r]);
+            bgemm_write_rows_t<32, false>(g, dseed, cs, m0 + wr * 128 + q * 32, n0 + wc * 64, lane, s4, b4);   // launcher: bgemm_vec_ok, no per-element operands
         }
 #pragma unroll
         for (int i = 0; i < 8; ++i)
 #pragma unroll
             for (int jj = 0; jj < 4; ++jj) acc[i][jj] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
     };
-#define LC_STEP(SB)                                                                                \
-    {                                                                                              \
-        __builtin_amdgcn_s_barrier();                      /* barrier(gk): K-tile gk + 1 has landed */ \
-        LC_READ_A(1, (gk % NST) * STAGE)                                                           \
-        LC_MFMA(0, SB)                                                                             \
-        LC_WAIT_LDS()                                                                              \
-        if (gk + 1 < G) {                                                                          \
-            LC_READ_A(0, ((gk + 1) % NST) * STAGE)                                                 \
-            LC_READ_B(1 - SB, ((gk + 1) % NST) * STAGE)                                            \
-        }                                                                                          \
-        LC_MFMA(1, SB)                                                                             \
-        LC_WAIT_LDS()                                                                              \
-        if (++kt == nk) { epilogue(jt); kt = 0; ++jt; }                                            \
+    int kt = 0, jt = 0;
+    for (int gk = 0; gk < G; ++gk) {
+        const unsigned so = (gk % NST) * STAGE;
+        __builtin_amdgcn_s_barrier();                      // barrier(gk): K-tile gk has landed
+        LC_READ_A(0, a_ad + so)
+        LC_READ_B(0, b_ad + so)
+        LC_WAIT_LDS()
+        // ---- k-half 0 (B set 0)
+        LC_READ_A(1, a_ad + so)
+        LC_MFMA(0, 0)
+        LC_WAIT_LDS()
+        LC_READ_A(0, a_ad1 + so)
+        LC_READ_B(1, b_ad1 + so)
+        LC_MFMA(1, 0)
+        LC_WAIT_LDS()
+        // ---- k-half 1 (B set 1)
+        LC_READ_A(1, a_ad1 + so)
+        LC_MFMA(0, 1)
+        LC_WAIT_LDS()
+        LC_MFMA(1, 1)
+        if (++kt == nk) { epilogue(jt, gk); kt = 0; ++jt; }
     }
-    __builtin_amdgcn_s_barrier();                          // barrier(-1): K-tile 0 has landed
-    LC_READ_A(0, 0)
-    LC_READ_B(0, 0)
-    LC_WAIT_LDS()
-    int kt = 0, jt = 0, gk = 0;
-    for (; gk + 1 < G; gk += 2) {
-        LC_STEP(0)
-        ++gk;
-        LC_STEP(1)
-        --gk;
-    }
-    if (gk < G) LC_STEP(0)
-#undef LC_STEP
 #undef LC_MFMA
 #undef LC_READ_A
 #undef LC_READ_B
@@ -1127,29 +1148,29 @@ __global__ __launch_bounds__(512, 2) void cst_gemm_bf16_lc_kernel(BGemmArgs g, i
 }
 
 static bool bgemm_lc_ok(const BGemmArgs& g) {
-    return g.M % 256 == 0 && g.N % 128 == 0 && g.K % GB_K == 0 && g.splits == 1 && !g.slab_only && !g.A2;
+    return g.M % LC_BM == 0 && g.N % LC_BN == 0 && g.K % BBK == 0 && g.splits == 1 && !g.slab_only && !g.A2 && bgemm_vec_ok(g) &&
+           !g.addend && g.act < 3 && !(g.C && g.accumulate);       // the MFMA waves' write-out holds no global load
 }
 
 static int bgemm_lc_launch(const BGemmArgs& g, hipStream_t st) {
-    constexpr int NST = 5;
-    const size_t lds = (size_t)NST * (256 + 128) * GB_ROW + 4 * 32 * 64 * sizeof(float);
+    const size_t lds = (size_t)LC_NST * LC_STAGE;
     static const int gn = getenv("CST_GB_GN") ? atoi(getenv("CST_GB_GN")) : 2;
     static const int ncu = []() { int dev = 0, n = 256; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n > 0 ? n : 256; }();
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)cst_gemm_bf16_lc_kernel<NST>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)cst_gemm_bf16_lc_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_done = true;
     }
-    const int ntiles = (g.M / 256) * (g.N / 128);
+    const int ntiles = (g.M / LC_BM) * (g.N / LC_BN);
     dim3 grid(ntiles < ncu ? ntiles : ncu, 1, 1), block(512);
     if (cst_prof_on()) {
         hipEvent_t ea, eb;
         (void)hipEventCreate(&ea); (void)hipEventCreate(&eb);
         cst_prof_push_shape(ea, eb, 2.0 * g.M * g.N * g.K, 2.0 * ((double)g.M * g.K + (double)g.N * g.K) + (g.C ? 4.0 : 0.0) * g.M * g.N + (g.Cb ? 2.0 : 0.0) * g.M * g.N, 1,
                             g.M, g.N, g.K);
-        hipExtLaunchKernelGGL((cst_gemm_bf16_lc_kernel<NST>), grid, block, lds, st, ea, eb, 0, g, gn);
+        hipExtLaunchKernelGGL(cst_gemm_bf16_lc_kernel, grid, block, lds, st, ea, eb, 0, g, gn);
     } else {
-        hipLaunchKernelGGL((cst_gemm_bf16_lc_kernel<NST>), grid, block, lds, st, g, gn);
+        hipLaunchKernelGGL(cst_gemm_bf16_lc_kernel, grid, block, lds, st, g, gn);
     }
     return 0;
 }
