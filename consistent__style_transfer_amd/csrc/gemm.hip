@@ -353,7 +353,22 @@ __global__ __launch_bounds__(NW * 64) void cst_gemm_kernel(GemmArgs g) {
     float* Cs = reinterpret_cast<float*>(smem) + wave * PR * CLD;
     static_assert((PR * (WN / 4)) % 64 == 0, "C staging rows must divide over the wave");
     constexpr int C4 = WN / 4;                             // float4 chunks per row of the wave block
-    const bool cvec = (g.ldc % 4 == 0) && ((reinterpret_cast<uintptr_t>(C) & 15) == 0) && !g.accumulate;
+    const bool cvec = (g.ldc % 4 == 0) && ((reinterpret_cast<uintptr_t>(C) & 15) == 0);
+    // Vector path: the wave's block is inside the matrix and every stream it touches moves as float4.  All of a pass's loads (old C when
+    // accumulating, addend, aux) are requested before its first store and the stores are issued back to back: loads and stores share
+    // one in-order counter (vmcnt), so a load behind a store costs that store's whole round trip -- the element-wise loop below pays one
+    // per element (the straight-through product d p += dx E^T, an accumulate, ran 16 of them in a row per wave).
+    constexpr int IT = PR * C4 / 64;
+    static_assert(64 % C4 == 0, "a lane keeps its four columns in every iteration");
+    const bool fast = cvec && m0 + wm * WM + WM <= g.M && n0 + wn * WN + WN <= g.N &&
+                      (!addend || ((g.ldadd % 4 == 0) && ((reinterpret_cast<uintptr_t>(addend) & 15) == 0))) &&
+                      (g.act < 3 || ((g.ldaux % 4 == 0) && ((reinterpret_cast<uintptr_t>(aux) & 15) == 0))) &&
+                      (!bias || ((reinterpret_cast<uintptr_t>(bias) & 15) == 0));
+    float b4[4] = {0.f, 0.f, 0.f, 0.f};
+    if (fast && bias) {
+        const float4 t = *reinterpret_cast<const float4*>(bias + n0 + wn * WN + (lane % C4) * 4);
+        b4[0] = t.x; b4[1] = t.y; b4[2] = t.z; b4[3] = t.w;
+    }
 #pragma unroll
     for (int ps = 0; ps < PASSES; ++ps) {
         if (ps > 0) __builtin_amdgcn_wave_barrier();
@@ -364,29 +379,55 @@ __global__ __launch_bounds__(NW * 64) void cst_gemm_kernel(GemmArgs g) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) Cs[(i * 16 + lq * 4 + r) * CLD + j * 16 + lr] = acc[ps * (TM / PASSES) + i][j][r];
         __builtin_amdgcn_wave_barrier();
+        if (fast) {
+            float4 a4[IT], old[IT], ad[IT], ax[IT];
+            const int cc = (lane % C4) * 4, n = n0 + wn * WN + cc;
+            const int mrow = m0 + wm * WM + ps * PR + lane / C4;
 #pragma unroll
-        for (int it = 0; it < PR * C4 / 64; ++it) {
+            for (int it = 0; it < IT; ++it) a4[it] = *reinterpret_cast<const float4*>(&Cs[(lane / C4 + (64 / C4) * it) * CLD + cc]);
+            if (g.accumulate) {
+#pragma unroll
+                for (int it = 0; it < IT; ++it) old[it] = *reinterpret_cast<const float4*>(C + (long)(mrow + (64 / C4) * it) * g.ldc + n);
+            }
+            if (addend) {
+#pragma unroll
+                for (int it = 0; it < IT; ++it) ad[it] = *reinterpret_cast<const float4*>(addend + (long)(mrow + (64 / C4) * it) * g.ldadd + n);
+            }
+            if (g.act >= 3) {
+#pragma unroll
+                for (int it = 0; it < IT; ++it) ax[it] = *reinterpret_cast<const float4*>(aux + (long)(mrow + (64 / C4) * it) * g.ldaux + n);
+            }
+#pragma unroll
+            for (int it = 0; it < IT; ++it) {
+                const int m = mrow + (64 / C4) * it;
+                float o[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float v = g.alpha * (&a4[it].x)[e] + b4[e];
+                    if (addend) v += (&ad[it].x)[e];
+                    if (g.act == 1) v = v > 0.f ? v : 0.f;
+                    else if (g.act == 2) v = v > 0.f ? v : 0.1f * v;
+                    else if (g.act == 3) v = (&ax[it].x)[e] > 0.f ? v * g.gate_scale : 0.f;
+                    else if (g.act == 4) v = (&ax[it].x)[e] > 0.f ? v : 0.1f * v;
+                    if (g.drop.p > 0.f) v *= cst_drop_mask(g.drop, dseed, (uint32_t)((long)m * g.N + n + e + bz * (long)g.M * g.N));
+                    if (g.accumulate) v += (&old[it].x)[e];
+                    o[e] = v;
+                }
+                *reinterpret_cast<float4*>(C + (long)m * g.ldc + n) = make_float4(o[0], o[1], o[2], o[3]);
+            }
+            continue;
+        }
+#pragma unroll
+        for (int it = 0; it < IT; ++it) {
             const int idx = lane + 64 * it;
             const int rr = idx / C4, cc = (idx % C4) * 4;
             const int m = m0 + wm * WM + ps * PR + rr, n = n0 + wn * WN + cc;
             if (m >= g.M || n >= g.N) continue;
             const float4 a4 = *reinterpret_cast<const float4*>(&Cs[rr * CLD + cc]);
             const float av[4] = {a4.x, a4.y, a4.z, a4.w};
-            if (cvec && n + 3 < g.N && !addend && !aux && g.drop.p <= 0.f) {
-                float o[4];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    float v = g.alpha * av[e] + (bias ? bias[n + e] : 0.f);
-                    if (g.act == 1) v = v > 0.f ? v : 0.f;
-                    else if (g.act == 2) v = v > 0.f ? v : 0.1f * v;
-                    o[e] = v;
-                }
-                *reinterpret_cast<float4*>(C + (long)m * g.ldc + n) = make_float4(o[0], o[1], o[2], o[3]);
-            } else {
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    if (n + e < g.N) gemm_epilogue_store(g, C, bias, addend, aux, dseed, bz, m, n + e, av[e]);
-            }
+            for (int e = 0; e < 4; ++e)
+                if (n + e < g.N) gemm_epilogue_store(g, C, bias, addend, aux, dseed, bz, m, n + e, av[e]);
         }
     }
 }
