@@ -207,6 +207,149 @@ extern "C" int cst_mha_fwd(const float* qkv, float* out, float* lse, int B, int 
     return cst_mha_fwd_b(qkv, out, lse, B, S, H, hd, drop_p, drop_seed, drop_stream, drop_seed_dev, nullptr, 0, stream);
 }
 
+// ---------------------------------------------------------------------------------------------
+// MHA forward, bf16 qkv (cst_mha_fwd_h), HD a multiple of 32: bf16 LDS images of Q, K, V (40 KiB in all at S = 36, hd = 96 against
+// 68 KiB: four workgroups per CU instead of two), Q K^T on v_mfma_f32_16x16x32_bf16 (exact products, another summation order than the
+// fp32-image kernel), P V on the fp32 matrix pipe with V widened from its image.  Mirrors mha_bwd_hb_kernel below.
+// ---------------------------------------------------------------------------------------------
+typedef __attribute__((ext_vector_type(8))) __bf16 mha_bf16x8_t;
+
+__host__ __device__ inline size_t mha_fwd_hb_lds_bytes(int S, int hd) {
+    const size_t SP = (size_t)((S + 15) / 16) * 16;
+    return 3 * SP * (hd + 8) * 2 + 64 + sizeof(float) * SP * (SP + 4);
+}
+
+template <int HD, int ST>
+__global__ __launch_bounds__(MHA_NW * 64) void mha_fwd_hb_kernel(const unsigned short* __restrict__ qkv, float* __restrict__ out,
+                                                         float* __restrict__ lse, int S, int H, float scale, CstDrop drop,
+                                                         unsigned short* __restrict__ outb, long ldob) {
+    static_assert(HD % 32 == 0, "bf16 MFMA k-steps of 32");
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    constexpr int HD4 = HD / 4, HDB = HD + 8, NT = HD / 16;
+    constexpr int SP = ST * 16, SS = SP + 4, KSEG = SP / 4, NTHR = MHA_NW * 64;
+    unsigned short* Qs = reinterpret_cast<unsigned short*>(smem_raw);      // [SP][HDB]
+    unsigned short* Ks = Qs + SP * HDB;
+    unsigned short* Vs = Ks + SP * HDB;
+    float* Pm = reinterpret_cast<float*>(Vs + SP * HDB + 32);               // [SP][SS]
+    const int b = blockIdx.x / H, h = blockIdx.x % H;
+    const int d = H * HD;
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lr = lane & 15, lq = lane >> 4;
+    const long base = (long)b * S * 3 * d + h * HD;
+    {
+        constexpr int nel = SP * HD4;
+        constexpr int QIT = (nel + NTHR - 1) / NTHR;
+        uint2 tq[QIT], tk[QIT], tv[QIT];
+#pragma unroll
+        for (int it = 0; it < QIT; ++it) {
+            const int e = min((int)threadIdx.x + NTHR * it, nel - 1);
+            const int i = min(e / HD4, S - 1), c = (e % HD4) * 4;
+            const long src = base + (long)i * 3 * d + c;
+            tq[it] = *reinterpret_cast<const uint2*>(qkv + src);
+            tk[it] = *reinterpret_cast<const uint2*>(qkv + src + d);
+            tv[it] = *reinterpret_cast<const uint2*>(qkv + src + 2 * d);
+        }
+#pragma unroll
+        for (int it = 0; it < QIT; ++it) {
+            const int e = threadIdx.x + NTHR * it;
+            if (e < nel) {
+                const int o = (e / HD4) * HDB + (e % HD4) * 4;
+                *reinterpret_cast<uint2*>(&Qs[o]) = tq[it];
+                *reinterpret_cast<uint2*>(&Ks[o]) = tk[it];
+                *reinterpret_cast<uint2*>(&Vs[o]) = tv[it];
+            }
+        }
+    }
+    __syncthreads();
+    // ---- phase A: scores, HD / 32 bf16 MFMAs per 16 x 16 tile ----------------------------------
+    constexpr int ntile = ST * ST;
+    for (int t = w; t < ntile; t += MHA_NW) {
+        const int mt = t / ST, nt = t % ST;
+        const unsigned short* qa = Qs + (mt * 16 + lr) * HDB + lq * 8;
+        const unsigned short* ka = Ks + (nt * 16 + lr) * HDB + lq * 8;
+        f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < HD / 32; ++ks)
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const mha_bf16x8_t*>(qa + ks * 32),
+                                                          *reinterpret_cast<const mha_bf16x8_t*>(ka + ks * 32), acc, 0, 0, 0);
+        const int j = nt * 16 + lr;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Pm[(mt * 16 + lq * 4 + r) * SS + j] = acc[r] * scale;
+    }
+    __syncthreads();
+    // ---- phase B: row softmax, lse, attention dropout (as mha_fwd_kernel) -----------------------
+    const uint32_t dseed = drop.p > 0.f ? cst_drop_seed(drop) : 0u;
+    for (int i0 = 4 * w; i0 < S; i0 += 4 * MHA_NW) {
+        const int i = i0 + lq;
+        const bool row_ok = i < S;
+        const int ic = row_ok ? i : S - 1;
+        float sv[ST];
+        float m = -INFINITY;
+#pragma unroll
+        for (int n = 0; n < ST; ++n) {
+            const int j = lr + 16 * n;
+            sv[n] = j < S ? Pm[ic * SS + j] : -INFINITY;
+            m = fmaxf(m, sv[n]);
+        }
+        m = row16_max(m);
+        float sum = 0.f;
+#pragma unroll
+        for (int n = 0; n < ST; ++n) {
+            sv[n] = (lr + 16 * n < S) ? expf(sv[n] - m) : 0.f;
+            sum += sv[n];
+        }
+        sum = row16_sum(sum);
+        const float inv = 1.f / sum;
+        if (row_ok) {
+            if (lr == 0) lse[((long)b * H + h) * S + i] = m + logf(sum);
+#pragma unroll
+            for (int n = 0; n < ST; ++n) {
+                const int j = lr + 16 * n;
+                float pv = sv[n] * inv;
+                if (drop.p > 0.f && j < S)
+                    pv *= cst_drop_mask(drop, dseed, (uint32_t)((((long)b * H + h) * S + i) * S + j));
+                Pm[i * SS + j] = pv;
+            }
+        }
+    }
+    __syncthreads();
+    // ---- phase C: O = Pd V on the fp32 matrix pipe, V widened from the bf16 image --------------
+    float* ob = out ? out + (long)b * S * d + h * HD : nullptr;
+    constexpr int PAIR = (NT % 2 == 0) ? 2 : 1, NP = NT / PAIR;
+    constexpr int nout = ST * NP;
+    for (int u = w; u < nout; u += MHA_NW) {
+        const int mt = u / NP, n0 = (u - mt * NP) * PAIR * 16;
+        const float* a = Pm + (mt * 16 + lr) * SS + lq * KSEG;
+        const unsigned short* bp = Vs + (lq * KSEG) * HDB + n0 + lr;
+        f32x4_t acc[PAIR];
+#pragma unroll
+        for (int q = 0; q < PAIR; ++q) acc[q] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < KSEG; ++k) {
+            const float av = a[k];
+#pragma unroll
+            for (int q = 0; q < PAIR; ++q)
+                acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, __uint_as_float((uint32_t)bp[k * HDB + q * 16] << 16), acc[q], 0, 0, 0);
+        }
+#pragma unroll
+        for (int q = 0; q < PAIR; ++q) {
+            const int n = n0 + q * 16 + lr;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int mrow = mt * 16 + lq * 4 + r;
+                if (mrow < S) {
+                    if (ob) ob[(long)mrow * d + n] = acc[q][r];
+                    if (outb) {
+                        __bf16 hh = (__bf16)acc[q][r];
+                        outb[((long)b * S + mrow) * ldob + h * HD + n] = __builtin_bit_cast(unsigned short, hh);
+                    }
+                }
+            }
+        }
+    }
+}
+
 static int mha_fwd_any(const void* qkv, int qkv_bf16, float* out, float* lse, int B, int S, int H, int hd,
                        float drop_p, uint32_t drop_seed, uint32_t drop_stream, const void* drop_seed_dev,
                        void* out_bf16, long ldob, void* stream);
@@ -241,10 +384,32 @@ static int mha_fwd_any(const void* qkv, int qkv_bf16, float* out, float* lse, in
         CST_LAUNCH_CHECK("cst_mha_fwd (long)");
         return CST_OK;
     }
-    const size_t lds = sizeof(float) * mha_fwd_lds_floats(S, hd);
-    CST_REQUIRE(lds <= 160 * 1024, "cst_mha_fwd: LDS need %zu exceeds 160 KiB", lds);
     dim3 grid(B * H), block(MHA_NW * 64);
     hipStream_t st = (hipStream_t)stream;
+    static const bool hb_off = getenv("CST_MHA_HB_OFF") != nullptr;          // A/B switch: fp32 LDS images for the bf16-input forward
+    if (qkv_bf16 && (hd == 64 || hd == 96) && !hb_off) {
+        const size_t ldsb = mha_fwd_hb_lds_bytes(S, hd);
+#define MHA_HB_LAUNCH(HDV, STV)                                                                                    \
+        {                                                                                                          \
+            if (ldsb > 64 * 1024) (void)hipFuncSetAttribute((const void*)mha_fwd_hb_kernel<HDV, STV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb); \
+            hipLaunchKernelGGL((mha_fwd_hb_kernel<HDV, STV>), grid, block, ldsb, st, (const unsigned short*)qkv, out, lse, S, H, scale, dr,     \
+                               (unsigned short*)out_bf16, ldob);                                                   \
+        }
+#define MHA_HB_CASE(HDV)                                                                                           \
+        switch ((S + 15) / 16) {                                                                                   \
+            case 1: MHA_HB_LAUNCH(HDV, 1) break;                                                                   \
+            case 2: MHA_HB_LAUNCH(HDV, 2) break;                                                                   \
+            case 3: MHA_HB_LAUNCH(HDV, 3) break;                                                                   \
+            default: MHA_HB_LAUNCH(HDV, 4) break;                                                                  \
+        }
+        if (hd == 64) { MHA_HB_CASE(64) } else { MHA_HB_CASE(96) }
+#undef MHA_HB_CASE
+#undef MHA_HB_LAUNCH
+        CST_LAUNCH_CHECK("cst_mha_fwd (bf16 images)");
+        return CST_OK;
+    }
+    const size_t lds = sizeof(float) * mha_fwd_lds_floats(S, hd);
+    CST_REQUIRE(lds <= 160 * 1024, "cst_mha_fwd: LDS need %zu exceeds 160 KiB", lds);
 #define MHA_FWD_LAUNCH(HDV, STV)                                                                                  \
     {                                                                                                             \
         if constexpr (HDV == 64 || HDV == 96) {                                                                    \
@@ -484,6 +649,182 @@ extern "C" int cst_mha_bwd(const float* qkv, const float* dout, const float* lse
     return cst_mha_bwd_b(qkv, dout, lse, dqkv, B, S, H, hd, drop_p, drop_seed, drop_stream, drop_seed_dev, nullptr, 0, stream);
 }
 
+// ---------------------------------------------------------------------------------------------
+// MHA backward, bf16 I/O (cst_mha_bwd_h), HD a multiple of 32: the LDS images of Q, K, V, dO stay bf16.
+//
+// Why (profiles/round2_kernel_stats: mha_bwd_kernel<96, 3, true> 99.5 us x 12 per step, ~22 TFLOP/s): with fp32 images the kernel
+// needs 97 KiB of LDS at S = 36, hd = 96 -- ONE workgroup per CU, so nothing hides a workgroup's load phase (27 KB of strided rows,
+// one memory round trip) or its write-out.  bf16 images are 40 KiB (61 KiB in all): two workgroups per CU, one loading while the
+// other computes.  Phase A (Q K^T and dO V^T) then runs on v_mfma_f32_16x16x32_bf16 straight from the images: the products of
+// bf16 values are exact in fp32 either way, only the summation order differs from the fp32-image kernel (results agree to a few
+// ulps, not bit for bit).  Phase C keeps the fp32 matrix pipe: its A operand (dS, Pd) is fp32 and is not rounded; its B operand
+// (K, Q, dO) is widened on the fly from the bf16 image (a shift).
+//   images: [SP][HD + 8] bf16 (208-byte rows at hd = 96: 16-byte aligned, 13 x 16 B so the 16 rows of a fragment read spread over
+//   the banks)
+// ---------------------------------------------------------------------------------------------
+__host__ __device__ inline size_t mha_bwd_hb_lds_bytes(int S, int hd) {
+    const size_t SP = (size_t)((S + 15) / 16) * 16;
+    return 4 * SP * (hd + 8) * 2 + 64 + sizeof(float) * (2 * SP * (SP + 4) + SP * 4 + SP);
+}
+
+template <int HD, int ST>
+__global__ __launch_bounds__(MHA_NW * 64) void mha_bwd_hb_kernel(const unsigned short* __restrict__ qkv, const unsigned short* __restrict__ dout,
+                                                         const float* __restrict__ lse, float* __restrict__ dqkv,
+                                                         int S, int H, float scale, CstDrop drop,
+                                                         unsigned short* __restrict__ dqkvb, long lddb) {
+    static_assert(HD % 32 == 0, "bf16 MFMA k-steps of 32");
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    constexpr int HD4 = HD / 4, HDB = HD + 8, NT = HD / 16;
+    constexpr int SP = ST * 16, SS = SP + 4, KSEG = SP / 4;
+    unsigned short* Qs = reinterpret_cast<unsigned short*>(smem_raw);      // [SP][HDB]
+    unsigned short* Ks = Qs + SP * HDB;
+    unsigned short* Vs = Ks + SP * HDB;
+    unsigned short* Os = Vs + SP * HDB;                                     // dO
+    float* Pm = reinterpret_cast<float*>(Os + SP * HDB + 32);               // [SP][SS]  Pd[i][j]
+    float* Dm = Pm + SP * SS;                                               // [SP][SS]  dS[i][j]
+    float* part = Dm + SP * SS;                                             // [SP][4]
+    float* lse_s = part + SP * 4;                                           // [SP]
+    const int b = blockIdx.x / H, h = blockIdx.x % H;
+    const int d = H * HD;
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lr = lane & 15, lq = lane >> 4;
+    const long base = (long)b * S * 3 * d + h * HD;
+    const long dob = (long)b * S * d + h * HD;
+
+    // stage Q, K, V, dO (4 bf16 = 8 bytes per load): every load is issued before the first LDS store
+    {
+        constexpr int nel = SP * HD4;
+        constexpr int NTHR = MHA_NW * 64, QIT = (nel + NTHR - 1) / NTHR;
+        uint2 tq[QIT], tk[QIT], tv[QIT], to[QIT];
+#pragma unroll
+        for (int it = 0; it < QIT; ++it) {
+            const int e = min((int)threadIdx.x + NTHR * it, nel - 1);
+            const int i = min(e / HD4, S - 1), c = (e % HD4) * 4;
+            const long src = base + (long)i * 3 * d + c;
+            tq[it] = *reinterpret_cast<const uint2*>(qkv + src);
+            tk[it] = *reinterpret_cast<const uint2*>(qkv + src + d);
+            tv[it] = *reinterpret_cast<const uint2*>(qkv + src + 2 * d);
+            to[it] = *reinterpret_cast<const uint2*>(dout + dob + (long)i * d + c);
+        }
+        if (threadIdx.x < SP) lse_s[threadIdx.x] = (int)threadIdx.x < S ? lse[((long)b * H + h) * S + threadIdx.x] : 0.f;
+#pragma unroll
+        for (int it = 0; it < QIT; ++it) {
+            const int e = threadIdx.x + NTHR * it;
+            if (e < nel) {
+                const int o = (e / HD4) * HDB + (e % HD4) * 4;
+                *reinterpret_cast<uint2*>(&Qs[o]) = tq[it];
+                *reinterpret_cast<uint2*>(&Ks[o]) = tk[it];
+                *reinterpret_cast<uint2*>(&Vs[o]) = tv[it];
+                *reinterpret_cast<uint2*>(&Os[o]) = to[it];
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- phase A: S = Q K^T and dP = dO V^T per 16 x 16 tile, HD / 32 bf16 MFMAs each ---------
+    const uint32_t dseed = drop.p > 0.f ? cst_drop_seed(drop) : 0u;
+    constexpr int ntile = ST * ST, TPW = (ntile + MHA_NW - 1) / MHA_NW;
+    f32x4_t Pf[TPW], Df[TPW];
+#pragma unroll
+    for (int tt = 0; tt < TPW; ++tt) {
+        const int t = w + MHA_NW * tt;
+        Pf[tt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        Df[tt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        if (t < ntile) {
+            const int mt = t / ST, nt = t % ST;
+            const unsigned short* qa = Qs + (mt * 16 + lr) * HDB + lq * 8;
+            const unsigned short* oa = Os + (mt * 16 + lr) * HDB + lq * 8;
+            const unsigned short* ka = Ks + (nt * 16 + lr) * HDB + lq * 8;
+            const unsigned short* va = Vs + (nt * 16 + lr) * HDB + lq * 8;
+            f32x4_t accS = {0.f, 0.f, 0.f, 0.f}, accD = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < HD / 32; ++ks) {
+                const mha_bf16x8_t q8 = *reinterpret_cast<const mha_bf16x8_t*>(qa + ks * 32);
+                const mha_bf16x8_t k8 = *reinterpret_cast<const mha_bf16x8_t*>(ka + ks * 32);
+                const mha_bf16x8_t o8 = *reinterpret_cast<const mha_bf16x8_t*>(oa + ks * 32);
+                const mha_bf16x8_t v8 = *reinterpret_cast<const mha_bf16x8_t*>(va + ks * 32);
+                accS = __builtin_amdgcn_mfma_f32_16x16x32_bf16(q8, k8, accS, 0, 0, 0);
+                accD = __builtin_amdgcn_mfma_f32_16x16x32_bf16(o8, v8, accD, 0, 0, 0);
+            }
+            const int j = nt * 16 + lr;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i = mt * 16 + lq * 4 + r;
+                const bool valid = i < S && j < S;
+                const float pv = valid ? expf(accS[r] * scale - lse_s[i]) : 0.f;
+                float mask = 1.f;
+                if (drop.p > 0.f && valid)
+                    mask = cst_drop_mask(drop, dseed, (uint32_t)((((long)b * H + h) * S + i) * S + j));
+                const float dp = valid ? accD[r] * mask : 0.f;
+                Pm[i * SS + j] = pv * mask;
+                float rs = dp * pv;
+                rs = row16_sum(rs);
+                if (lr == 0) part[i * 4 + nt] = rs;
+                Pf[tt][r] = pv;
+                Df[tt][r] = dp;
+            }
+        }
+    }
+    __syncthreads();
+    // ---- phase B -----------------------------------------------------------------------------
+#pragma unroll
+    for (int tt = 0; tt < TPW; ++tt) {
+        const int t = w + MHA_NW * tt;
+        if (t < ntile) {
+            const int mt = t / ST, nt = t % ST;
+            const int j = nt * 16 + lr;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i = mt * 16 + lq * 4 + r;
+                float delta = 0.f;
+#pragma unroll
+                for (int n = 0; n < ST; ++n) delta += part[i * 4 + n];
+                Dm[i * SS + j] = Pf[tt][r] * (Df[tt][r] - delta) * scale;
+            }
+        }
+    }
+    __syncthreads();
+    // ---- phase C: dQ = dS K, dK = dS^T Q, dV = Pd^T dO on the fp32 matrix pipe, B operand widened from the bf16 image ----
+    float* dq = dqkv ? dqkv + (long)b * S * 3 * d + h * HD : nullptr;
+    constexpr int PAIR = (NT % 2 == 0) ? 2 : 1, NP = NT / PAIR;
+    constexpr int per = ST * NP, nout = 3 * per;
+    for (int u = w; u < nout; u += MHA_NW) {
+        const int which = u / per, rem = u - which * per;
+        const int mt = rem / NP, n0 = (rem - mt * NP) * PAIR * 16;
+        const float* a = which == 0 ? Dm + (mt * 16 + lr) * SS + lq * KSEG
+                                    : (which == 1 ? Dm : Pm) + (lq * KSEG) * SS + mt * 16 + lr;
+        const int as = which == 0 ? 1 : SS;
+        const unsigned short* bp = (which == 0 ? Ks : (which == 1 ? Qs : Os)) + (lq * KSEG) * HDB + n0 + lr;
+        f32x4_t acc[PAIR];
+#pragma unroll
+        for (int q = 0; q < PAIR; ++q) acc[q] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < KSEG; ++k) {
+            const float av = a[k * as];
+#pragma unroll
+            for (int q = 0; q < PAIR; ++q)
+                acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, __uint_as_float((uint32_t)bp[k * HDB + q * 16] << 16), acc[q], 0, 0, 0);
+        }
+#pragma unroll
+        for (int q = 0; q < PAIR; ++q) {
+            const int n = n0 + q * 16 + lr;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = mt * 16 + lq * 4 + r;
+                if (m < S) {
+                    if (dq) dq[(long)m * 3 * d + which * d + n] = acc[q][r];
+                    if (dqkvb) {
+                        __bf16 hh = (__bf16)acc[q][r];
+                        dqkvb[((long)b * S + m) * lddb + which * d + h * HD + n] = __builtin_bit_cast(unsigned short, hh);
+                    }
+                }
+            }
+        }
+    }
+}
+
+
 static int mha_bwd_any(const void* qkv, const void* dout, int io_bf16, const float* lse, float* dqkv, int B, int S, int H, int hd,
                        float drop_p, uint32_t drop_seed, uint32_t drop_stream, const void* drop_seed_dev,
                        void* dqkv_bf16, long lddb, void* stream);
@@ -520,10 +861,33 @@ static int mha_bwd_any(const void* qkv, const void* dout, int io_bf16, const flo
         CST_LAUNCH_CHECK("cst_mha_bwd (long)");
         return CST_OK;
     }
-    const size_t lds = sizeof(float) * mha_bwd_lds_floats(S, hd);
-    CST_REQUIRE(lds <= 160 * 1024, "cst_mha_bwd: LDS need %zu exceeds 160 KiB", lds);
     dim3 grid(B * H), block(MHA_NW * 64);
     hipStream_t st = (hipStream_t)stream;
+    static const bool hb_off = getenv("CST_MHA_HB_OFF") != nullptr;          // A/B switch: fp32 LDS images for the bf16-I/O backward
+    if (io_bf16 && (hd == 64 || hd == 96) && !hb_off) {
+        // bf16 LDS images: two workgroups per CU (see mha_bwd_hb_kernel)
+        const size_t ldsb = mha_bwd_hb_lds_bytes(S, hd);
+#define MHA_HB_LAUNCH(HDV, STV)                                                                                    \
+        {                                                                                                          \
+            if (ldsb > 64 * 1024) (void)hipFuncSetAttribute((const void*)mha_bwd_hb_kernel<HDV, STV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb); \
+            hipLaunchKernelGGL((mha_bwd_hb_kernel<HDV, STV>), grid, block, ldsb, st, (const unsigned short*)qkv, (const unsigned short*)dout, lse, dqkv, S, H, \
+                               scale, dr, (unsigned short*)dqkv_bf16, lddb);                                       \
+        }
+#define MHA_HB_CASE(HDV)                                                                                           \
+        switch ((S + 15) / 16) {                                                                                   \
+            case 1: MHA_HB_LAUNCH(HDV, 1) break;                                                                   \
+            case 2: MHA_HB_LAUNCH(HDV, 2) break;                                                                   \
+            case 3: MHA_HB_LAUNCH(HDV, 3) break;                                                                   \
+            default: MHA_HB_LAUNCH(HDV, 4) break;                                                                  \
+        }
+        if (hd == 64) { MHA_HB_CASE(64) } else { MHA_HB_CASE(96) }
+#undef MHA_HB_CASE
+#undef MHA_HB_LAUNCH
+        CST_LAUNCH_CHECK("cst_mha_bwd (bf16 images)");
+        return CST_OK;
+    }
+    const size_t lds = sizeof(float) * mha_bwd_lds_floats(S, hd);
+    CST_REQUIRE(lds <= 160 * 1024, "cst_mha_bwd: LDS need %zu exceeds 160 KiB", lds);
 #define MHA_BWD_LAUNCH(HDV, STV)                                                                                  \
     {                                                                                                             \
         if constexpr (HDV == 64 || HDV == 96) {                                                                    \

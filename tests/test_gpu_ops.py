@@ -420,8 +420,9 @@ def test_mha(ops, B, S, H, hd, p):
 
 @pytest.mark.parametrize("B,S,H,hd,p", [(2, 36, 8, 64, 0.1), (3, 18, 8, 96, 0.1), (1, 64, 2, 64, 0.0), (2, 36, 8, 96, 0.0), (2, 7, 3, 96, 0.1)])
 def test_mha_bf16_io_equals_fp32_io_on_rounded_inputs(ops, B, S, H, hd, p):
-    """cst_mha_fwd_h / cst_mha_bwd_h: bf16 qkv and d(output) in HBM, fp32 LDS images and arithmetic -- bit for bit the fp32-I/O
-    kernels run on the bf16-rounded values, with or without the optional fp32 results."""
+    """cst_mha_fwd_h / cst_mha_bwd_h: bf16 qkv and d(output) in HBM, bf16 LDS images, Q K^T / dO V^T on the bf16 matrix pipe (exact
+    products of bf16 values), everything else fp32: the fp32-I/O kernels run on the bf16-rounded values give the same results up to
+    summation order, with or without the optional fp32 results."""
     from consistent__style_transfer_amd._lib import call
     d = H * hd
     qkv = _bf16_round(rnd(B * S, 3 * d, seed=1, scale=0.7))
@@ -436,14 +437,25 @@ def test_mha_bf16_io_equals_fp32_io_on_rounded_inputs(ops, B, S, H, hd, p):
     outb2, outb3 = torch.zeros_like(outb), torch.zeros_like(outb)
     call("cst_mha_fwd_h", qb, out2, lse2, B, S, H, hd, *drop.args(), outb2, d)
     call("cst_mha_fwd_h", qb, None, lse2, B, S, H, hd, *drop.args(), outb3, d)          # bf16 result only
-    assert torch.equal(out2, out) and torch.equal(lse2, lse) and torch.equal(outb2, outb) and torch.equal(outb3, outb)
+    def ulp_close(x, y):                                                                 # bf16 results: at most one ulp apart, rarely
+        a, b = x.view(torch.bfloat16).float(), y.view(torch.bfloat16).float()
+        assert ((a - b).abs() <= 2.0 ** -7 * b.abs() + 1e-6).all()
+        assert (a != b).float().mean().item() < 0.01
+    # bf16 LDS images, Q K^T on the bf16 matrix pipe: exact products, another summation order (a few ulps)
+    close(out2, out, 2e-5, 2e-6)
+    close(lse2, lse, 2e-6, 2e-6)
+    assert torch.equal(outb3, outb2)
+    ulp_close(outb2, outb)
     dq = torch.empty(B * S, 3 * d, device="cuda")
     dqb = torch.zeros(B * S, 3 * d, device="cuda", dtype=torch.int16)
     call("cst_mha_bwd_b", dev(qkv), dev(w), lse, dq, B, S, H, hd, *drop.args(), dqb, 3 * d)
     dq2, dqb2, dqb3 = torch.empty_like(dq), torch.zeros_like(dqb), torch.zeros_like(dqb)
     call("cst_mha_bwd_h", qb, wb, lse, dq2, B, S, H, hd, *drop.args(), dqb2, 3 * d)
     call("cst_mha_bwd_h", qb, wb, lse, None, B, S, H, hd, *drop.args(), dqb3, 3 * d)
-    assert torch.equal(dq2, dq) and torch.equal(dqb2, dqb) and torch.equal(dqb3, dqb)
+    # backward: bf16 LDS images, Q K^T and dO V^T on the bf16 matrix pipe -- exact products, another summation order (a few ulps)
+    close(dq2, dq, 2e-5, 2e-6)
+    assert torch.equal(dqb3, dqb2)
+    ulp_close(dqb2, dqb)
     with pytest.raises(RuntimeError, match="head dims 64 / 96"):
         call("cst_mha_fwd_h", qb, None, lse2, B, S, H * hd // 32, 32, *drop.args(), outb3, d)
 

@@ -28,3 +28,17 @@ for B, S, H, hd, p in [(256, 18, 8, 64, 0.1), (256, 36, 8, 64, 0.1), (256, 18, 8
     bw = t_graph(lambda: call("cst_mha_bwd", qkv, dout, lse, dqkv, B, S, H, hd, p, 1, 2, None))
     fb, bb = 4 * (qkv.numel() + out.numel()), 4 * (2 * qkv.numel() + dout.numel())
     print(f"B={B} S={S} H={H} hd={hd} p={p}: fwd {f:6.1f} us ({fb / f / 1e3:6.0f} GB/s)   bwd {bw:6.1f} us ({bb / bw / 1e3:6.0f} GB/s)")
+
+# bf16-I/O forms (the ones the bf16 precision mode runs): cst_mha_fwd_h / cst_mha_bwd_h; CST_MHA_HB_OFF=1 keeps fp32 LDS images
+print("---- bf16 I/O (cst_mha_fwd_h / cst_mha_bwd_h)" + (" [fp32 LDS images]" if os.environ.get("CST_MHA_HB_OFF") else " [bf16 LDS images in the backward]"))
+for B, S, H, hd, p in [(256, 18, 8, 96, 0.1), (256, 36, 8, 96, 0.1), (256, 18, 8, 64, 0.1), (256, 36, 8, 64, 0.1), (512, 60, 8, 64, 0.1)]:
+    d = H * hd
+    qb = torch.randn(B * S, 3 * d, device="cuda").to(torch.bfloat16).view(torch.int16)
+    wb = torch.randn(B * S, d, device="cuda").to(torch.bfloat16).view(torch.int16)
+    lse = torch.empty(B * H * S, device="cuda")
+    ob = torch.empty(B * S, d, device="cuda", dtype=torch.int16)
+    dqb = torch.empty(B * S, 3 * d, device="cuda", dtype=torch.int16)
+    f = t_graph(lambda: call("cst_mha_fwd_h", qb, None, lse, B, S, H, hd, p, 1, 2, None, ob, d))
+    bw = t_graph(lambda: call("cst_mha_bwd_h", qb, wb, lse, None, B, S, H, hd, p, 1, 2, None, dqb, 3 * d))
+    fb, bb = 2 * (qb.numel() + ob.numel()), 2 * (2 * qb.numel() + wb.numel())
+    print(f"B={B} S={S} H={H} hd={hd} p={p}: fwd {f:6.1f} us ({fb / f / 1e3:6.0f} GB/s)   bwd {bw:6.1f} us ({bb / bw / 1e3:6.0f} GB/s)")
