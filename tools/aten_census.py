@@ -9,7 +9,7 @@ from torch.utils._python_dispatch import TorchDispatchMode
 import bench
 
 bench.ONLY = sys.argv[1] if len(sys.argv) > 1 else None
-w = bench.WORKLOADS["yelp_4l_d512_b256"]
+w = bench.WORKLOADS[os.environ.get("CST_CENSUS_WORKLOAD", bench.HEADLINE)]
 dev = torch.device("cuda:0")
 stages_ = bench.build_stages(w, dev)
 batches = bench.make_batches(w, 0, dev)

@@ -148,6 +148,13 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "bf16nt":
         main_bf16()
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "rec":
+        # the decoder's per-step products (M = batch = 256): tile 64 = 2-stage ring, 66 = 4-stage ring; split-K chosen by the library
+        os.environ.setdefault("CST_BENCH_TILES", "0,64,65,66")
+        main_bf16([(256, 2048, 640, 1, 1, "dec gates fwd"), (256, 512, 1024, 1, 1, "fn_1 fwd"), (256, 10000, 512, 1, 1, "fn_2 fwd"),
+                   (256, 512, 10048, 1, 1, "fn_2 dgrad"), (256, 1024, 512, 1, 1, "fn_1 dgrad"), (256, 640, 2048, 1, 1, "gates dgrad"),
+                   (256, 10000, 128, 1, 1, "dp += dx E^T"), (4608, 512, 10048, 1, 1, "fn_2 dgrad all steps"), (4608, 1024, 512, 1, 1, "fn_1 dgrad all steps")])
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "enc":
         main_bf16(ENC_SHAPES)
         main_bf16(ENC_SHAPES[:6], out_bf16=True)
