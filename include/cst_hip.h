@@ -181,7 +181,9 @@ int cst_mha_fwd_b(const float* qkv, float* out, float* lse, int B, int S, int H,
 /* _h: the same attention core with bf16 qkv [B,S,3d] and (backward) bf16 d(attention output) [B,S,d] in HBM and optional
  * fp32 results (out / dqkv may be null when the bf16 twin is all the caller consumes): in bf16 mode the encoder layer keeps
  * qkv, the attention output, its gradient and dqkv in bf16 only, which halves-to-thirds the attention core's HBM traffic.
- * S <= 64, head dims 64 / 96.  LDS images and all arithmetic stay fp32. */
+ * S <= 64, head dims 64 / 96.  The LDS images of q, k, v, d(out) are bf16 (two to four workgroups per CU); Q K^T and dO V^T run on
+ * v_mfma_f32_16x16x32_bf16 (exact products of the bf16 inputs), softmax and every other product in fp32: results equal cst_mha_fwd_b /
+ * cst_mha_bwd_b run on the same (bf16-rounded) values up to summation order. */
 int cst_mha_fwd_h(const void* qkv_bf16, float* out, float* lse, int B, int S, int H, int hd,
                   float drop_p, uint32_t drop_seed, uint32_t drop_stream, const void* drop_seed_dev,
                   void* out_bf16, long ldob, void* stream);
