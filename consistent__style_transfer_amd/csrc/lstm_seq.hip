@@ -52,9 +52,16 @@ struct LstmSeqArgs {
     long ldw, ldh0, ldcl;
 };
 
+// W_hh tiles kept in LDS for the whole launch: the last SQ_NL of a wave's 16 fragment tiles (8 KiB each).  The recurrence is bound by
+// the W_hh stream out of L2 (512 KB per step and workgroup at ~50 GB/s per CU against ~2 us of MFMA): every tile that stays on chip
+// is one the step does not wait for.  4 waves x 4 tiles x 8 KiB = 128 KiB next to the 8 KiB h tile.
+constexpr int SQ_NL = 4;
+constexpr int SQ_FWD_LDS = 16 * SQ_HS * 2 + 4 * SQ_NL * SQ_KK * 1024;
+
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void lstm_seq_fwd_kernel(LstmSeqArgs a) {
     constexpr int H = SQ_H;
-    __shared__ __attribute__((aligned(16))) bf16_t hA[16 * SQ_HS];
+    extern __shared__ __attribute__((aligned(16))) char sq_smem[];
+    bf16_t* hA = reinterpret_cast<bf16_t*>(sq_smem);                       // [16][SQ_HS]
     const int d = blockIdx.y;
     const LstmSeqDir& D = a.dir[d];
     const int r0 = blockIdx.x * 16;
@@ -81,6 +88,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     // 64 lanes of one load instruction read one contiguous KiB (row-scattered 16-byte pieces keep the texture path busy
     // 16 cache lines per instruction and ran this kernel at 1/6 of its speed)
     const bf16_t* wfrag = D.whh + ((long)w * 16 * SQ_KK * 64 + lane) * 8;
+    // this wave's resident tiles: [tile 16 - SQ_NL ..][k step][lane][16 B], filled once
+    char* wl = sq_smem + 16 * SQ_HS * 2 + (w * SQ_NL * SQ_KK * 64 + lane) * 16;
+#pragma unroll
+    for (int i = 0; i < SQ_NL * SQ_KK; ++i)
+        *reinterpret_cast<u32x4_t*>(wl + i * 1024) = *reinterpret_cast<const u32x4_t*>(wfrag + ((long)(16 - SQ_NL) * SQ_KK + i) * 64 * 8);
 
     for (int n = 0; n < L; ++n) {
         const int t = D.reverse ? L - 1 - n : n;
@@ -92,6 +104,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         // W_hh fragments, three tiles in flight
         u32x4_t bb[3][SQ_KK];
         auto load_b = [&](int ti, u32x4_t (&dst)[SQ_KK]) {
+            if (ti >= 16 - SQ_NL) {                       // resident tile (ti is a compile-time constant once the loop is unrolled)
+                const char* ws = wl + (ti - (16 - SQ_NL)) * SQ_KK * 1024;
+#pragma unroll
+                for (int kk = 0; kk < SQ_KK; ++kk) dst[kk] = *reinterpret_cast<const u32x4_t*>(ws + kk * 1024);
+                return;
+            }
             const bf16_t* wn = wfrag + (long)ti * SQ_KK * 64 * 8;
 #pragma unroll
             for (int kk = 0; kk < SQ_KK; ++kk) dst[kk] = *reinterpret_cast<const u32x4_t*>(wn + kk * 64 * 8);
@@ -173,7 +191,12 @@ extern "C" int cst_lstm_seq_fwd(const void* whh0, const void* whh1, const float*
     a.dir[0] = LstmSeqDir{(const bf16_t*)whh0, xp0, h0, gates0, cenc0, hprev0, (bf16_t*)hprev0_bf16, c_last, 0};
     a.dir[1] = LstmSeqDir{(const bf16_t*)whh1, xp1, h0 + H, gates1, cenc1, hprev1, (bf16_t*)hprev1_bf16, c_last + H, 1};
     a.mem = mem; a.memb = (bf16_t*)mem_bf16; a.B = B; a.L = L; a.ldw = 0; a.ldh0 = ldh0; a.ldcl = ldcl;
-    hipLaunchKernelGGL(lstm_seq_fwd_kernel, dim3(B / 16, 2), dim3(256), 0, (hipStream_t)stream, a);
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void*)lstm_seq_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SQ_FWD_LDS);
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(lstm_seq_fwd_kernel, dim3(B / 16, 2), dim3(256), SQ_FWD_LDS, (hipStream_t)stream, a);
     CST_LAUNCH_CHECK("cst_lstm_seq_fwd");
     return CST_OK;
 }
@@ -204,9 +227,14 @@ struct LstmSeqBwdArgs {
     long ldcl, lddcl, lddh0;
 };
 
+// resident W_hh^T fragments: the last SQ_NLB of a wave's 32 k steps (4 KiB each): 4 waves x 7 x 4 KiB = 112 KiB next to the 32 KiB dgates tile
+constexpr int SQ_NLB = 7;
+constexpr int SQ_BWD_LDS = 16 * SQ_GS * 2 + 4 * SQ_NLB * SQ_J * 1024;
+
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void lstm_seq_bwd_kernel(LstmSeqBwdArgs a) {
     constexpr int H = SQ_H;
-    __shared__ __attribute__((aligned(16))) bf16_t gA[16 * SQ_GS];
+    extern __shared__ __attribute__((aligned(16))) char sq_smem[];
+    bf16_t* gA = reinterpret_cast<bf16_t*>(sq_smem);                       // [16][SQ_GS]
     const int d = blockIdx.y;
     const LstmSeqBwdDir& D = a.dir[d];
     const int r0 = blockIdx.x * 16;
@@ -222,6 +250,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             dhr[j][r] = 0.f;
         }
     const bf16_t* wfrag = D.wt + ((long)w * SQ_KB * SQ_J * 64 + lane) * 8;
+    char* wl = sq_smem + 16 * SQ_GS * 2 + (w * SQ_NLB * SQ_J * 64 + lane) * 16;
+#pragma unroll
+    for (int i = 0; i < SQ_NLB * SQ_J; ++i)
+        *reinterpret_cast<u32x4_t*>(wl + i * 1024) = *reinterpret_cast<const u32x4_t*>(wfrag + ((long)(SQ_KB - SQ_NLB) * SQ_J + i) * 64 * 8);
 
     for (int n = L - 1; n >= 0; --n) {
         const int t = D.reverse ? L - 1 - n : n;
@@ -263,6 +295,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         for (int j = 0; j < SQ_J; ++j) acc[j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
         u32x4_t bb[3][SQ_J];
         auto load_b = [&](int kk, u32x4_t (&dst)[SQ_J]) {
+            if (kk >= SQ_KB - SQ_NLB) {                   // resident k step
+                const char* ws = wl + (kk - (SQ_KB - SQ_NLB)) * SQ_J * 1024;
+#pragma unroll
+                for (int j = 0; j < SQ_J; ++j) dst[j] = *reinterpret_cast<const u32x4_t*>(ws + j * 1024);
+                return;
+            }
             const bf16_t* wn = wfrag + (long)kk * SQ_J * 64 * 8;
 #pragma unroll
             for (int j = 0; j < SQ_J; ++j) dst[j] = *reinterpret_cast<const u32x4_t*>(wn + j * 64 * 8);
@@ -305,7 +343,12 @@ extern "C" int cst_lstm_seq_bwd(const void* wt0, const void* wt1, const float* g
     a.dir[0] = LstmSeqBwdDir{(const bf16_t*)wt0, gates0, cenc0, c_last, dc_last, dgates0, (bf16_t*)dgates0_bf16, dh0, 0};
     a.dir[1] = LstmSeqBwdDir{(const bf16_t*)wt1, gates1, cenc1, c_last + H, dc_last + H, dgates1, (bf16_t*)dgates1_bf16, dh0 + H, 1};
     a.dmem = dmem; a.B = B; a.L = L; a.ldcl = ldcl; a.lddcl = lddcl; a.lddh0 = lddh0;
-    hipLaunchKernelGGL(lstm_seq_bwd_kernel, dim3(B / 16, 2), dim3(256), 0, (hipStream_t)stream, a);
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void*)lstm_seq_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SQ_BWD_LDS);
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(lstm_seq_bwd_kernel, dim3(B / 16, 2), dim3(256), SQ_BWD_LDS, (hipStream_t)stream, a);
     CST_LAUNCH_CHECK("cst_lstm_seq_bwd");
     return CST_OK;
 }
