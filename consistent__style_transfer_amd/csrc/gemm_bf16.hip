@@ -412,13 +412,17 @@ __device__ __forceinline__ void bgemm_write_rows(const BGemmArgs& g, uint32_t ds
 //             8 k-values with one ds_read_b64 and widens them in registers (v_cvt_pk_f32_fp8 x 4, v_cvt_pk_bf16_f32 x 4: e4m3
 //             is exactly representable in bf16) for the same v_mfma_f32_16x16x32_bf16; the per-output-channel scale rides in
 //             the epilogue (bscale).  gfx950 has no MFMA that mixes bf16 and fp8 operands.
-template <int BM, int BN, int NSTAGE, bool TT = false, bool BF8 = false>
-__global__ __launch_bounds__(256) void cst_gemm_bf16_kernel(BGemmArgs g) {
+// NW = waves per workgroup: 4 (2 x 2 wave tiles of BM/2 x BN/2) or 8 (4 x 2 wave tiles of BM/4 x BN/2).  128 x 128 / 8 waves (tile code 136)
+// keeps the 128 x 128 tile's bytes per FLOP with sixteen DMA-issuing waves per CU instead of eight.
+template <int BM, int BN, int NSTAGE, bool TT = false, bool BF8 = false, int NW = 4>
+__global__ __launch_bounds__(64 * NW) void cst_gemm_bf16_kernel(BGemmArgs g) {
     static_assert(!(TT && BF8), "fp8 B operand: NT products only");
     constexpr int A_BYTES = BM * BROW, B_BYTES = BN * (BF8 ? 64 : BROW), ST_BYTES = A_BYTES + B_BYTES;
-    constexpr int A_CH = BM / 8 / 4, B_CH = BF8 ? BN / 16 / 4 : BN / 8 / 4;   // 1-KiB chunks (8 rows; fp8 B: 16 rows) per wave per tile
+    constexpr int A_CH = BM / 8 / NW, B_CH = BF8 ? BN / 16 / NW : BN / 8 / NW;   // 1-KiB chunks (8 rows; fp8 B: 16 rows) per wave per tile
     constexpr int LOADS = A_CH + B_CH;                          // global_load_lds instructions per wave per tile
-    constexpr int TM = BM / 32, TN = BN / 32;
+    constexpr int WMR = BM / (NW / 2);                         // rows of a wave tile
+    constexpr int TM = WMR / 16, TN = BN / 32;
+    static_assert(NW == 4 || (NW == 8 && !TT && !BF8), "8 waves: NT products on bf16 operands only");
     static_assert(!TT || (BM == 128 && BN == 128), "the transposed-read image assumes 256-byte tile rows");
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -554,7 +558,7 @@ __global__ __launch_bounds__(256) void cst_gemm_bf16_kernel(BGemmArgs g) {
         auto read_half = [&](int kk) {
             if constexpr (!TT) {
 #pragma unroll
-                for (int i = 0; i < TM; ++i) af[kk][i] = lds_read128(As + blds_off(wm * (BM / 2) + i * 16 + lr, kk * 4 + lq));
+                for (int i = 0; i < TM; ++i) af[kk][i] = lds_read128(As + blds_off(wm * WMR + i * 16 + lr, kk * 4 + lq));
                 if constexpr (BF8) {
                     // row r = wn * BN/2 + 16 j + lr: swizzle key (r >> 2) & 3 = (lr >> 2) & 3; this lane's 8 k-values are bytes
                     // 32 kk + 8 lq .. + 7 of the row = 16-byte slot 2 kk + (lq >> 1), half lq & 1
@@ -633,7 +637,7 @@ __global__ __launch_bounds__(256) void cst_gemm_bf16_kernel(BGemmArgs g) {
                 if (n >= g.N) continue;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int m = m0 + wm * (BM / 2) + i * 16 + lq * 4 + r;
+                    const int m = m0 + wm * WMR + i * 16 + lq * 4 + r;
                     if (m < g.M) slab[(long)m * g.N + n] = acc[i][j][r];
                 }
             }
@@ -642,8 +646,8 @@ __global__ __launch_bounds__(256) void cst_gemm_bf16_kernel(BGemmArgs g) {
 
     // epilogue through LDS: 256-byte fp32 / 128-byte bf16 row segments per store instruction
     const uint32_t dseed = g.drop.p > 0.f ? cst_drop_seed(g.drop) : 0u;
-    constexpr int WM = BM / 2, WN = BN / 2, CLD = WN;
-    static_assert(4 * WM * CLD * 4 <= NSTAGE * ST_BYTES, "C staging must fit the ring");
+    constexpr int WM = WMR, WN = BN / 2, CLD = WN;
+    static_assert(NW * WM * CLD * 4 <= NSTAGE * ST_BYTES, "C staging must fit the ring");
     float* Cs = reinterpret_cast<float*>(smem) + wave * WM * CLD;
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -1204,24 +1208,24 @@ static int bgemm_big_launch_t(const BGemmArgs& g, hipStream_t st) {
 }
 
 
-template <int BM, int BN, int NSTAGE, bool TT = false, bool BF8 = false>
+template <int BM, int BN, int NSTAGE, bool TT = false, bool BF8 = false, int NW = 4>
 static int bgemm_launch(const BGemmArgs& g, hipStream_t st) {
     const size_t lds = (size_t)NSTAGE * (BM * BROW + BN * (BF8 ? 64 : BROW));
     static bool attr_done = false;
     if (!attr_done && lds > 64 * 1024) {
-        (void)hipFuncSetAttribute((const void*)cst_gemm_bf16_kernel<BM, BN, NSTAGE, TT, BF8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)cst_gemm_bf16_kernel<BM, BN, NSTAGE, TT, BF8, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_done = true;
     }
-    dim3 grid(cst_div_up(g.M, BM) * cst_div_up(g.N, BN), g.splits, g.A2 ? 2 : 1), block(256);
+    dim3 grid(cst_div_up(g.M, BM) * cst_div_up(g.N, BN), g.splits, g.A2 ? 2 : 1), block(64 * NW);
     if (cst_prof_on()) {
         hipEvent_t ea, eb;
         (void)hipEventCreate(&ea); (void)hipEventCreate(&eb);
         // TT products are recorded with a negative K (C = A^T B: the contraction index is the row index of both operands)
         cst_prof_push_shape(ea, eb, 2.0 * g.M * g.N * g.K, 2.0 * ((double)g.M * g.K + (double)g.N * g.K) + (g.C ? 4.0 : 0.0) * g.M * g.N + (g.Cb ? 2.0 : 0.0) * g.M * g.N, 1,
                             g.M, g.N, TT ? -g.K : g.K);
-        hipExtLaunchKernelGGL((cst_gemm_bf16_kernel<BM, BN, NSTAGE, TT, BF8>), grid, block, lds, st, ea, eb, 0, g);
+        hipExtLaunchKernelGGL((cst_gemm_bf16_kernel<BM, BN, NSTAGE, TT, BF8, NW>), grid, block, lds, st, ea, eb, 0, g);
     } else {
-        hipLaunchKernelGGL((cst_gemm_bf16_kernel<BM, BN, NSTAGE, TT, BF8>), grid, block, lds, st, g);
+        hipLaunchKernelGGL((cst_gemm_bf16_kernel<BM, BN, NSTAGE, TT, BF8, NW>), grid, block, lds, st, g);
     }
     return 0;
 }
@@ -1252,6 +1256,9 @@ extern "C" int cst_gemm_bf16(const void* A, long lda, const void* B, long ldb,
     // 128x128 + split-K for long-K products with few output tiles (wgrad), 64x128 (+split) otherwise.
     int ring = tile & 3;                         // tile code + 1 / + 2: force the 3- / 4-stage ring
     tile &= ~3;
+    static const bool w8_auto = getenv("CST_GEMM_W8") != nullptr;        // A/B switch: 128 x 128 tiles on 8 waves wherever 128 x 128 is chosen
+    bool w8 = tile == 136;                       // 136: 128 x 128 tile on 8 waves
+    if (w8) tile = 128;
     const long big = (long)cst_div_up(M, 128) * cst_div_up(N, 128);
     const long mid = (long)cst_div_up(M, 64) * cst_div_up(N, 128);
     int use_big, splits = 1;
@@ -1309,7 +1316,8 @@ extern "C" int cst_gemm_bf16(const void* A, long lda, const void* B, long ldb,
         if (tile == 256 || tile == 252) { tile = 0; }
     }
     if (ring == 0 && getenv("CST_RING4") && !use_big && tiles * splits <= 256 && g.k_per_split >= 256) ring = 2;
-    if (use_big) { if (ring == 1) bgemm_launch<128, 128, 3>(g, st); else bgemm_launch<128, 128, 2>(g, st); }
+    if (use_big && (w8 || w8_auto) && ring == 0) bgemm_launch<128, 128, 2, false, false, 8>(g, st);
+    else if (use_big) { if (ring == 1) bgemm_launch<128, 128, 3>(g, st); else bgemm_launch<128, 128, 2>(g, st); }
     else { if (ring == 2) bgemm_launch<64, 128, 4>(g, st); else if (ring == 1) bgemm_launch<64, 128, 3>(g, st); else bgemm_launch<64, 128, 2>(g, st); }
     CST_LAUNCH_CHECK("cst_gemm_bf16");
     if (splits > 1) {

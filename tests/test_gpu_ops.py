@@ -101,7 +101,7 @@ def test_cast_bf16(ops, R, C):
 
 @pytest.mark.parametrize("shape", [(37, 53, 19), (256, 512, 128), (700, 390, 100), (9216, 2048, 512), (4608, 512, 2048),
                                    (2048, 512, 9216), (256, 2048, 640), (256, 512, 1024), (130, 10000, 64), (64, 64, 10000)])
-@pytest.mark.parametrize("tile", [0, 64, 128])
+@pytest.mark.parametrize("tile", [0, 64, 128, 136])
 def test_gemm_bf16(ops, shape, tile):
     M, N, K = shape
     A, B = rnd(M, K, seed=1), rnd(N, K, seed=2)
@@ -126,6 +126,11 @@ def test_gemm_bf16(ops, shape, tile):
     ops.gemm_bf16(Ab, Bb, M, N, Cb=Cb3, bias=dev(bias), act=1, drop=d, tile=tile)
     mask = torch.from_numpy(orng.dropout_mask(11, 1002, (M, N), 0.3))
     close(Cb3.view(torch.bfloat16).float()[:, :N], torch.relu(ref + bias) * mask, 1e-2, 1e-2 * math.sqrt(K))
+    # accumulate + alpha into a strided C (the write-out's load-carrying instantiation reads the old C ahead of its stores)
+    big = torch.full((M, N + 8), 2.0, device="cuda")
+    ops.gemm_bf16(Ab, Bb, M, N, C=big[:, 4:4 + N], accumulate=True, alpha=0.5, tile=tile)
+    close(big[:, 4:4 + N], 2.0 + 0.5 * ref, 2e-3, 2e-3 * math.sqrt(K))
+    assert (big[:, :4] == 2.0).all() and (big[:, 4 + N:] == 2.0).all()
 
 
 @pytest.mark.parametrize("shape", [(256, 256, 64), (256, 256, 128), (512, 256, 192), (256, 768, 320), (4608, 2304, 768), (9216, 2048, 512),
