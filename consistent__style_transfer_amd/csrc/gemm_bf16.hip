@@ -160,12 +160,14 @@ __global__ __launch_bounds__(256) void colsum_bf16_kernel(const bf16_t* __restri
     if (w == 0 && c < N) atomicAdd(out + c, (sh[0][lane] + sh[1][lane]) + (sh[2][lane] + sh[3][lane]));
 }
 
-extern "C" int cst_colsum_bf16(const void* X, long ld, int M, int N, float* out, void* stream) {
+extern "C" int cst_colsum_bf16(const void* X, long ld, int M, int N, float* out, int accumulate, void* stream) {
     CST_REQUIRE(X && out && M > 0 && N > 0 && ld >= N, "cst_colsum_bf16: bad arguments");
     hipStream_t st = (hipStream_t)stream;
     const int cg = cst_div_up(N, 64);
     int splits = 2048 / cg; if (splits < 1) splits = 1; if (splits > M / 32) splits = M / 32; if (splits < 1) splits = 1;
-    if (cst_zero_words(out, N, st) != CST_OK) { cst_set_error("cst_colsum_bf16: zero fill failed"); return CST_ERR_LAUNCH; }
+    // the splits add into `out` with atomics: accumulate != 0 = the caller's `out` already holds what the sums are added to (zeros from its
+    // zero arena, or a running gradient)
+    if (!accumulate && cst_zero_words(out, N, st) != CST_OK) { cst_set_error("cst_colsum_bf16: zero fill failed"); return CST_ERR_LAUNCH; }
     hipLaunchKernelGGL(colsum_bf16_kernel, dim3(cg, splits), dim3(256), 0, st, (const bf16_t*)X, ld, M, N, out, cst_div_up(M, splits));
     CST_LAUNCH_CHECK("cst_colsum_bf16");
     return CST_OK;

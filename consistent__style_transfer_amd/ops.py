@@ -58,10 +58,83 @@ class Drop:
 NO_DROP = Drop()
 
 
+# ---------------------------------------------------------------------------------------------------------------------------
+# Zero arena.  A stage step needs ~110 small zero-initialised buffers (bias-gradient column sums, embedding-gradient tables,
+# d(memory) of the decoder ...).  Each used to be its own fill kernel -- ~5 us apiece on the serial replay chain, 0.55 ms per step.
+# Inside `with zero_arena(tag):` (the stage steps) they are slices of ONE persistent buffer whose used prefix is zeroed by a single
+# kernel when the scope opens; the prefix length is the high-water mark of the previous scope with the same tag (a stage at a batch
+# shape), so the first -- eager -- step of a shape runs on the per-buffer fills and every later step and every capture on the arena.
+# Rules: a slice is valid until the next scope opens (everything made from one is consumed inside its step: gradients are gathered
+# into the flat buffers before the step ends); outside a scope nothing changes (module-level use, tests, validation).
+# ---------------------------------------------------------------------------------------------------------------------------
+_ARENA_WORDS = int(os.environ.get("CST_ZERO_ARENA_MB", "256")) * (1 << 18)        # 4-byte words
+_ARENA = {}          # device -> {"buf", "off", "zeroed", "active", "tag", "hw": {tag: words}}
+
+
+def _devkey(device):
+    device = torch.device(device)
+    if device.type == "cuda" and device.index is None:
+        device = torch.device("cuda", torch.cuda.current_device())
+    return device
+
+
+class zero_arena:
+    def __init__(self, tag, device):
+        self.tag, self.device = tag, _devkey(device)
+
+    def __enter__(self):
+        if self.device.type != "cuda" or _ARENA_WORDS <= 0:
+            self.st = None
+            return self
+        st = _ARENA.get(self.device)
+        if st is None:
+            st = _ARENA[self.device] = {"buf": torch.empty(_ARENA_WORDS, device=self.device, dtype=torch.int32), "off": 0, "zeroed": 0,
+                                        "active": False, "tag": None, "hw": {}}
+        assert not st["active"], "zero_arena scopes do not nest"
+        hw = min(st["hw"].get(self.tag, 0), _ARENA_WORDS)
+        if hw > 0:
+            call("cst_zero", st["buf"], hw * 4)
+        st.update(off=0, zeroed=hw, active=True, tag=self.tag)
+        self.st = st
+        return self
+
+    def __exit__(self, *exc):
+        st = self.st
+        if st is not None:
+            st["hw"][self.tag] = max(st["hw"].get(self.tag, 0), st["off"])
+            st["active"] = False
+        return False
+
+
+def _arena_take(numel, dtype, device):
+    """A zeroed flat tensor of `numel` elements from the open scope's prefix, or None (no scope / not yet measured / full)."""
+    st = _ARENA.get(_devkey(device)) if _ARENA else None
+    if st is None or not st["active"]:
+        return None
+    esz = torch.empty(0, dtype=dtype).element_size()
+    words = (numel * esz + 3) // 4
+    words = (words + 63) // 64 * 64                      # 256-byte granules: every slice 16-byte aligned for the vector kernels
+    off = st["off"]
+    st["off"] = off + words                              # counted even when it does not fit: the next scope of this tag zeroes that much
+    if off + words > st["zeroed"]:
+        return None
+    return st["buf"][off:off + words].view(dtype)[:numel]
+
+
 def zeros(*shape, device, dtype=torch.float32):
-    """torch.zeros for buffers created inside forward / backward passes that may be captured: torch.empty + cst_zero (a kernel).
-    torch.zeros / Tensor.zero_() may lower to hipMemsetAsync, whose graph node does not keep its stream position when the
-    autograd thread issues it under segmented capture (see cst_common.h)."""
+    """torch.zeros for buffers created inside forward / backward passes that may be captured: a slice of the zero arena inside a
+    stage step, else torch.empty + cst_zero (a kernel).  torch.zeros / Tensor.zero_() may lower to hipMemsetAsync, whose graph node
+    does not keep its stream position when the autograd thread issues it under segmented capture (see cst_common.h)."""
+    device = torch.device(device)
+    if len(shape) == 1 and isinstance(shape[0], (tuple, list, torch.Size)):
+        shape = tuple(shape[0])
+    n = 1
+    for d_ in shape:
+        n *= int(d_)
+    if n > 0 and device.type == "cuda":
+        t = _arena_take(n, dtype, device)
+        if t is not None:
+            return t.view(*shape)
     t = torch.empty(*shape, device=device, dtype=dtype)
     nbytes = t.numel() * t.element_size()
     if nbytes % 4 == 0 and nbytes > 0 and t.is_cuda:
@@ -73,6 +146,11 @@ def zeros(*shape, device, dtype=torch.float32):
 
 def zeros_like(x):
     return zeros(*x.shape, device=x.device, dtype=x.dtype)
+
+
+def _zeros_or_none(n, device):
+    """fp32 [n] from the arena (already zero: the caller passes accumulate = 1 and the library skips its own fill), or None."""
+    return _arena_take(n, torch.float32, torch.device(device)) if torch.device(device).type == "cuda" else None
 
 
 def _ld(t):
@@ -256,8 +334,11 @@ def gemm_bf16_tt(Ab, Bb, M, N, C=None, accumulate=False, splitk=0):
 
 
 def colsum_bf16(xb, N):
-    out = torch.empty(N, device=xb.device, dtype=torch.float32)
-    call("cst_colsum_bf16", xb, xb.stride(0), xb.shape[0], N, out)
+    out = _zeros_or_none(N, xb.device)
+    pre = out is not None
+    if not pre:
+        out = torch.empty(N, device=xb.device, dtype=torch.float32)
+    call("cst_colsum_bf16", xb, xb.stride(0), xb.shape[0], N, out, int(pre))
     return out
 
 
@@ -292,7 +373,11 @@ def wgrad(g, x, out=None, accumulate=False):
 def colsum(x, out=None, accumulate=False):
     M, N = x.shape
     if out is None:
-        out = torch.empty(N, device=x.device, dtype=torch.float32)
+        out = _zeros_or_none(N, x.device)
+        if out is not None:
+            accumulate = True                             # pre-zeroed arena slice: the library skips its own fill
+        else:
+            out = torch.empty(N, device=x.device, dtype=torch.float32)
     call("cst_colsum", x, _ld(x), M, N, out, int(accumulate))
     return out
 
@@ -518,16 +603,25 @@ def _ln_bwd(dy, z, mean, rstd, gamma, want_param_grads, dzb_drop=None):
         ws = torch.empty(nws, device=dy.device, dtype=torch.float32)
         dzb = torch.empty(T, d, device=dy.device, dtype=torch.int16)
         if want_param_grads:
-            p3 = torch.empty(3 * d, device=dy.device, dtype=torch.float32)         # dgamma | dbeta | bias gradient of the Linear in front
-            call("cst_layernorm_bwd_b", dy, z, mean, rstd, gamma, dz, None, None, 0, ws, nws, T, d, dzb, d, *dzb_drop.args(), p3)
+            p3 = _zeros_or_none(3 * d, dy.device)                                  # dgamma | dbeta | bias gradient of the Linear in front
+            pre = p3 is not None
+            if not pre:
+                p3 = torch.empty(3 * d, device=dy.device, dtype=torch.float32)
+            call("cst_layernorm_bwd_b", dy, z, mean, rstd, gamma, dz, None, None, int(pre), ws, nws, T, d, dzb, d, *dzb_drop.args(), p3)
             return dz, p3[:d], p3[d:2 * d], dzb, p3[2 * d:]
         call("cst_layernorm_bwd_b", dy, z, mean, rstd, gamma, dz, None, None, 0, ws, nws, T, d, dzb, d, *dzb_drop.args(), None)
         return dz, None, None, dzb, None
     nws = call_plain("cst_layernorm_bwd_workspace_floats", T, d)
     ws = torch.empty(nws, device=dy.device, dtype=torch.float32)
-    dg = torch.empty(d, device=dy.device, dtype=torch.float32) if want_param_grads else None
-    db = torch.empty(d, device=dy.device, dtype=torch.float32) if want_param_grads else None
-    call("cst_layernorm_bwd", dy, z, mean, rstd, gamma, dz, dg, db, 0, ws, nws, T, d)
+    dg = db = None
+    pre = False
+    if want_param_grads:
+        both = _zeros_or_none(2 * d, dy.device)
+        pre = both is not None
+        if not pre:
+            both = torch.empty(2 * d, device=dy.device, dtype=torch.float32)
+        dg, db = both[:d], both[d:]
+    call("cst_layernorm_bwd", dy, z, mean, rstd, gamma, dz, dg, db, int(pre), ws, nws, T, d)
     return dz, dg, db
 
 

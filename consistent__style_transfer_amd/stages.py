@@ -22,6 +22,11 @@ from .model import MLM, DenoiseLSTM, Matcher, RelGAN_D, TextCNN
 from .optim import FlatGroup, FlatSlice, clip_groups
 
 
+
+def _arena_tag(stage, batch, extra=None):
+    """Key of ops.zero_arena's high-water mark: the zero-initialised scratch a step needs depends on the stage and the batch shape."""
+    return (type(stage).__name__, id(stage), tuple(tuple(t.shape) for t in batch if hasattr(t, "shape")), extra)
+
 class Fork:
     """Run independent branches of a step on forked HIP streams and join them.  Branch 0 stays on
     the current stream.  Autograd replays each branch's backward on the stream its forward ran on,
@@ -149,6 +154,10 @@ class PretrainStage(nn.Module):
         return s, c, dn
 
     def train_step(self, batch, seed=None, reducer=None):
+        with ops.zero_arena(_arena_tag(self, batch), batch[0].device):
+            return self._train_step(batch, seed, reducer)
+
+    def _train_step(self, batch, seed=None, reducer=None):
         """The three critics share nothing, so each runs forward + backward + gradient gather on its own and, under data
         parallelism, its all-reduce is started right away (deferred) while the next critic computes; only the last
         reducer call waits for all of them before the global-norm clip."""
@@ -223,6 +232,10 @@ class WarmupStage(nn.Module):
         return ops.token_ce(lg.view(-1, lg.size(-1)), x.reshape(-1), unit_grad=True)
 
     def train_step(self, batch, coins=None, seed=None, reducer=None):
+        with ops.zero_arena(_arena_tag(self, batch), batch[0].device):
+            return self._train_step(batch, coins, seed, reducer)
+
+    def _train_step(self, batch, coins=None, seed=None, reducer=None):
         loss = self.loss(batch, coins, seed)
         loss.backward()
         self.group.gather_grads(False)
@@ -315,6 +328,10 @@ class OptimizeStage(nn.Module):
         return {"loss": self.w_adv * d_loss, "D": d_loss}
 
     def train_step(self, batch, batch_idx, coins=None, seed=None, reducer=None):
+        with ops.zero_arena(_arena_tag(self, batch, batch_idx % 4 == 0), batch[0].device):
+            return self._train_step(batch, batch_idx, coins, seed, reducer)
+
+    def _train_step(self, batch, batch_idx, coins=None, seed=None, reducer=None):
         logs = {}
         # generator step
         _set_requires_grad(self._all, False)

@@ -84,8 +84,9 @@ int cst_gemm_bf16(const void* A, long lda, const void* B, long ldb,
 int cst_cast_bf16(const void* x, int x_is_bf16, long ldx, int R, int C,
                   void* out, long ldo, void* out_t, long ldot,
                   float drop_p, uint32_t drop_seed, uint32_t drop_stream, const void* drop_seed_dev, void* stream);
-/* out[c] = sum_r X[r,c] for a bf16 matrix (fp32 sums). */
-int cst_colsum_bf16(const void* X, long ld, int M, int N, float* out, void* stream);
+/* out[c] (+)= sum_r X[r,c] for a bf16 matrix (fp32 sums); accumulate != 0: `out` already holds the value the sums are added to
+ * (e.g. zeros from the caller's own arena -- the library then skips its fill kernel). */
+int cst_colsum_bf16(const void* X, long ld, int M, int N, float* out, int accumulate, void* stream);
 
 /* Fused token cross-entropy forward + backward: row_loss[r] = logsumexp(x_r) - x_r[target_r];
  * dlogits = grad_scale * (softmax(x_r) - onehot(target_r)) (may alias logits; null = forward

@@ -465,6 +465,41 @@ def test_mha_bf16_io_equals_fp32_io_on_rounded_inputs(ops, B, S, H, hd, p):
         call("cst_mha_fwd_h", qb, None, lse2, B, S, H * hd // 32, 32, *drop.args(), outb3, d)
 
 
+def test_zero_arena_hands_out_zeroed_disjoint_slices(ops):
+    """ops.zero_arena: the first scope of a tag measures (every buffer gets its own fill), later scopes zero the measured prefix with one
+    kernel and hand out disjoint slices of it -- also after the previous scope's users dirtied them; outside a scope nothing changes."""
+    dev = torch.device("cuda")
+    tag = ("test", 1)
+    x = rnd(300, 70, seed=3)
+
+    def body():
+        a = ops.zeros(5, 7, device=dev)
+        b = ops.zeros(1000, device=dev, dtype=torch.int64)
+        c = ops.colsum(dev_(x))
+        cb = ops.colsum_bf16(ops.cast_bf16(dev_(x), want_t=False)[0], 70)
+        return a, b, c, cb
+
+    dev_ = lambda t: t.to(dev)
+    with ops.zero_arena(tag, dev):
+        a0, b0, c0, cb0 = body()
+    st = ops._ARENA[ops._devkey(dev)]
+    assert st["hw"][tag] > 0 and not st["active"]
+    base, end = st["buf"].data_ptr(), st["buf"].data_ptr() + st["buf"].numel() * 4
+    assert not (base <= a0.data_ptr() < end)                                              # measuring pass: own buffers
+    st["buf"][:st["hw"][tag]].fill_(0x7F7F7F7F)                                           # dirty the prefix
+    with ops.zero_arena(tag, dev):
+        a1, b1, c1, cb1 = body()
+        ptrs = sorted((t.data_ptr(), t.numel() * t.element_size()) for t in (a1, b1, c1, cb1))
+        assert all(base <= p < end for p, _ in ptrs)
+        assert all(p0 + n0 <= p1 for (p0, n0), (p1, _) in zip(ptrs, ptrs[1:]))           # disjoint
+        assert (a1 == 0).all() and (b1 == 0).all()
+        close(c1, x.sum(0), 1e-5, 1e-4)
+        close(cb1, _bf16_round(x).sum(0), 1e-5, 1e-3)
+    assert torch.equal(c1.cpu(), c0.cpu()) or torch.allclose(c1, c0, rtol=1e-5, atol=1e-5)
+    t = ops.zeros(4, 4, device=dev)
+    assert not (base <= t.data_ptr() < end) and (t == 0).all()
+
+
 def test_mha_rejects_unsupported_lengths(ops):
     from consistent__style_transfer_amd._lib import call
     B, S, H, hd = 1, 129, 2, 64
