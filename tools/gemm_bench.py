@@ -62,7 +62,7 @@ ENC_SHAPES = [  # the encoder-layer products of the bench workloads (T = 4608 ML
 ]
 
 
-def main_bf16(shapes=None, out_bf16=False):
+def main_bf16(shapes=None, out_bf16=False, splitk=0):
     print("---- bf16-operand NT GEMM (global_load_lds ring); tile codes: 0 auto, 64/128 2-stage ring, +1 3-stage, +2 4-stage, 256 = 8-wave 256x256"
           + ("; bf16-only C" if out_bf16 else "; fp32 C"))
     for M, N, K, akm, bkm, note in (shapes or SHAPES):
@@ -75,13 +75,13 @@ def main_bf16(shapes=None, out_bf16=False):
         tiles = [int(x) for x in os.environ.get("CST_BENCH_TILES", "0,64,65,128,129,130,256").split(",")]
         for tile in tiles:
             for _ in range(3):
-                ops.gemm_bf16(Ab, Bb, M, N, C=C, Cb=Cb, tile=tile)
+                ops.gemm_bf16(Ab, Bb, M, N, C=C, Cb=Cb, tile=tile, splitk=splitk)
             torch.cuda.synchronize()
             n = 20
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
                 for _ in range(n):
-                    ops.gemm_bf16(Ab, Bb, M, N, C=C, Cb=Cb, tile=tile)
+                    ops.gemm_bf16(Ab, Bb, M, N, C=C, Cb=Cb, tile=tile, splitk=splitk)
             g.replay()
             torch.cuda.synchronize()
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -154,6 +154,9 @@ if __name__ == "__main__":
         main_bf16([(256, 2048, 640, 1, 1, "dec gates fwd"), (256, 512, 1024, 1, 1, "fn_1 fwd"), (256, 10000, 512, 1, 1, "fn_2 fwd"),
                    (256, 512, 10048, 1, 1, "fn_2 dgrad"), (256, 1024, 512, 1, 1, "fn_1 dgrad"), (256, 640, 2048, 1, 1, "gates dgrad"),
                    (256, 10000, 128, 1, 1, "dp += dx E^T"), (4608, 512, 10048, 1, 1, "fn_2 dgrad all steps"), (4608, 1024, 512, 1, 1, "fn_1 dgrad all steps")])
+        print("---- the same without split-K (one launch instead of product + reduce)")
+        main_bf16([(256, 2048, 640, 1, 1, "dec gates fwd"), (256, 512, 1024, 1, 1, "fn_1 fwd"), (256, 1024, 512, 1, 1, "fn_1 dgrad"),
+                   (256, 640, 2048, 1, 1, "gates dgrad"), (256, 512, 10048, 1, 1, "fn_2 dgrad")], splitk=1)
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "enc":
         main_bf16(ENC_SHAPES)
