@@ -555,6 +555,36 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
     }
 }
 
+// The same step with the global-norm clip folded in: g is read as g * min(1, max_norm / (sqrt(*sumsq) + 1e-6)), exactly the value
+// cst_clip_scale would have stored (same fp32 product), without the extra read-modify-write pass over the gradients.
+__global__ void adam_clipped_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                                    long n, float lr, float b1, float b2, float eps, const int* __restrict__ step_dev,
+                                    const float* __restrict__ sumsq, float max_norm) {
+    const float t = (float)(*step_dev);
+    const float bc1 = 1.f - powf(b1, t), bc2 = 1.f - powf(b2, t);
+    const float step_size = lr / bc1, rbc2 = 1.f / sqrtf(bc2);
+    const float norm = sqrtf(*sumsq);
+    const float coef = max_norm / (norm + 1e-6f);
+    const bool scale = coef < 1.f;
+    EW_LOOP(i, n) {
+        const float g0 = g[i];
+        const float gi = scale ? g0 * coef : g0;
+        const float mi = b1 * m[i] + (1.f - b1) * gi;
+        const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+        m[i] = mi; v[i] = vi;
+        p[i] -= step_size * mi / (sqrtf(vi) * rbc2 + eps);
+    }
+}
+
+extern "C" int cst_adam_step_clipped(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2, float eps,
+                                     const int* step_dev, const float* sumsq_dev, float max_norm, void* stream) {
+    CST_REQUIRE(p && g && m && v && step_dev && sumsq_dev && n > 0 && max_norm > 0.f, "cst_adam_step_clipped: bad arguments");
+    hipLaunchKernelGGL(adam_clipped_kernel, ew_grid(n), dim3(EW_THREADS), 0, (hipStream_t)stream, p, g, m, v, n, lr, beta1, beta2, eps, step_dev,
+                       sumsq_dev, max_norm);
+    CST_LAUNCH_CHECK("cst_adam_step_clipped");
+    return CST_OK;
+}
+
 extern "C" int cst_adam_step(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2, float eps,
                              const int* step_dev, void* stream) {
     CST_REQUIRE(p && g && m && v && step_dev && n > 0, "cst_adam_step: bad arguments");

@@ -10,11 +10,14 @@ per-parameter gradients autograd produced (cst_multi_accumulate), sums squares, 
 coefficient and applies Adam.  The flat gradient buffer is also what the data-parallel
 all-reduce operates on (parallel.py).
 """
+import os
 import weakref
 
 import torch
 
 from ._lib import call
+
+_FUSED_CLIP = os.environ.get("CST_FUSED_CLIP", "1") != "0"       # A/B switch: global-norm clip folded into the Adam pass
 
 MT_CHUNK = 4096
 
@@ -190,6 +193,12 @@ class FlatGroup:
         if rec is not None and not any(g is self for g in rec.stepped):
             rec.stepped.append(self)
         call("cst_add_i32", self.step_dev, 1)
+        pend, self._pending_clip = getattr(self, "_pending_clip", None), None
+        if pend is not None:
+            # the clip that preceded this step was deferred to it (clip_groups(stepping=...)): one pass instead of two
+            call("cst_adam_step_clipped", self.flat_p, self.flat_g, self.m, self.v, self.total, float(self.lr),
+                 float(self.betas[0]), float(self.betas[1]), float(self.eps), self.step_dev, pend[0], float(pend[1]))
+            return
         call("cst_adam_step", self.flat_p, self.flat_g, self.m, self.v, self.total, float(self.lr),
              float(self.betas[0]), float(self.betas[1]), float(self.eps), self.step_dev)
 
@@ -202,8 +211,11 @@ class FlatGroup:
         return self.flat_g[self.offsets[i]:self.offsets[i] + self.sizes[i]].view_as(p)
 
 
-def clip_groups(groups, max_norm, scratch):
-    """clip_grad_norm_ over every group that currently holds gradients (one global norm)."""
+def clip_groups(groups, max_norm, scratch, stepping=()):
+    """clip_grad_norm_ over every group that currently holds gradients (one global norm).  Groups listed in `stepping` take their
+    optimizer step right after this call and zero their gradients after it: their scaling is folded into that step
+    (cst_adam_step_clipped reads g * coef, the value the in-place scaling would have stored) instead of a separate pass over the
+    gradient buffer.  `scratch` must stay untouched until those steps have been issued."""
     live = [g for g in groups if g.has_grad]
     if not live or max_norm is None or max_norm <= 0:
         return
@@ -211,4 +223,7 @@ def clip_groups(groups, max_norm, scratch):
     for g in live:
         g.sumsq_into(scratch)
     for g in live:
-        g.clip(scratch, max_norm)
+        if _FUSED_CLIP and any(g is s for s in stepping):
+            g._pending_clip = (scratch, max_norm)
+        else:
+            g.clip(scratch, max_norm)

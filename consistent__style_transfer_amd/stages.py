@@ -195,7 +195,7 @@ class PretrainStage(nn.Module):
                 else:
                     reducer([self.groups[k]])
         live = [self.groups[k] for k in self.flags if self.flags[k]]
-        clip_groups(live, self.clip, self._scratch)
+        clip_groups(live, self.clip, self._scratch, stepping=live)
         for g in live:
             g.step()
             g.zero_grad()
@@ -241,7 +241,7 @@ class WarmupStage(nn.Module):
         self.group.gather_grads(False)
         if reducer is not None:
             reducer([self.group])
-        clip_groups([self.group], self.clip, self._scratch)
+        clip_groups([self.group], self.clip, self._scratch, stepping=[self.group])
         self.group.step()
         self.group.zero_grad()
         return {"dn_loss": loss, "loss": loss}
@@ -342,7 +342,7 @@ class OptimizeStage(nn.Module):
         if reducer is not None:
             reducer([self.g_group])
         self.d_group.has_grad = True                      # its (possibly all-zero) accumulated grads join the norm
-        clip_groups([self.g_group, self.d_group], self.clip, self._scratch)
+        clip_groups([self.g_group, self.d_group], self.clip, self._scratch, stepping=[self.g_group])
         self.g_group.step()
         self.g_group.zero_grad()
         logs.update(G=r["G"], STI=r["STI"], BK=r["BK"], CP_logits=r["CP_logits"], g_total=r["loss"])
@@ -360,7 +360,7 @@ class OptimizeStage(nn.Module):
             # backward; afterwards rank r holds A + g_r, and AVG over ranks gives A + mean_r(g_r) = A + the global-batch
             # gradient on every rank (all D losses are batch means over equal shards) -- exactly the one-process buffer.
             reducer([self.d_group])
-        clip_groups([self.g_group, self.d_group], self.clip, self._scratch)
+        clip_groups([self.g_group, self.d_group], self.clip, self._scratch, stepping=[self.d_group] if batch_idx % 4 == 0 else ())
         if batch_idx % 4 == 0:                                                # main_optimize.py:85-88
             self.d_group.step()
             self.d_group.zero_grad()

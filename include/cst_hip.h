@@ -396,6 +396,11 @@ int cst_sumsq_accumulate(const float* g, long n, float* out, float* partials, vo
 int cst_clip_scale(float* g, long n, const float* sumsq_dev, float max_norm, void* stream);
 int cst_adam_step(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2, float eps,
                   const int* step_dev, void* stream);
+/* cst_clip_scale + cst_adam_step in one pass for a group that steps right after the clip: every gradient is read as
+ * g * min(1, max_norm / (sqrt(*sumsq_dev) + 1e-6)) -- bit for bit what cst_clip_scale would have stored -- and is left unscaled in
+ * memory (the caller zeroes it after the step, main_pretrain.py / main_warmup.py / main_optimize.py optimizer steps). */
+int cst_adam_step_clipped(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2, float eps,
+                          const int* step_dev, const float* sumsq_dev, float max_norm, void* stream);
 int cst_add_i32(int* p, int inc, void* stream);
 /* flat[dst_off[t] + i] (+)= srcs[t][i] for all tensors in one launch (null source = skipped);
  * chunk tables (4096 elements per chunk) are built by the host once per parameter set. */
