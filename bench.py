@@ -293,6 +293,13 @@ def main():
     stages_ = build_stages(w, device)
     batches = make_batches(w, rank, device)
     reducer = GradReducer(world) if world > 1 else None
+    if world == 1 and os.environ.get("CST_RCCL_REHEARSAL"):
+        # one-rank RCCL group on the one GPU: the N > 1 launch structure (hipGraph segments, bucketed backward, async all_reduce(AVG) on
+        # RCCL's stream) with every collective really issued -- what it costs next to the single-graph step, minus the wire time
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        torch.distributed.init_process_group("nccl", rank=0, world_size=1)
+        reducer = GradReducer(1, force=True)
 
     def barrier():
         torch.cuda.synchronize()
@@ -303,7 +310,7 @@ def main():
     if os.environ.get("CST_FORCE_SEGMENTS") and reducer is None:
         reducer = lambda groups, defer=False: None     # single-GPU rehearsal of the segmented (N > 1) launch path
     use_graph = not args.no_graph
-    if use_graph and world > 1:
+    if use_graph and (world > 1 or isinstance(reducer, GradReducer)):
         # the segmented capture (graph | eager all-reduce | graph ...) is rehearsed on one GPU only; if it cannot be
         # built on this node every rank falls back to eager launches together rather than losing the measurement
         failed = 0.0
@@ -499,11 +506,11 @@ def main():
             "config": {"workload": args.workload, "per_gpu_batch": w["B"], "global_batch": w["B"] * world,
                        "seq_len": w["L"], "vocab": w["V"], "critic_layers": w["n_layer"], "d_model": w["d_model"],
                        "parallelism": f"dp{world}", "stages": "pretrain+warmup+optimize(G+D)", "weights": "random-init",
-                       "launch": ("hipGraph replay" if world == 1 else "hipGraph segments + eager all-reduce") if use_graph else "eager"},
+                       "launch": ("hipGraph replay" if reducer is None else "hipGraph segments + eager all-reduce") if use_graph else "eager"},
             "roofline": roofline, "cpu_baseline": cpu, "per_stage": per_stage, "f32_mode": f32_mode, "fp8w_mode": fp8w_mode, "workloads": others,
         }
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
 
 

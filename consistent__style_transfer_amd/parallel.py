@@ -49,8 +49,9 @@ class GradReducer:
     flight (RCCL runs them on its own stream; they overlap with the gather / sum-of-squares
     kernels of later groups)."""
 
-    def __init__(self, world, bucket_elems=16 * 1024 * 1024):
+    def __init__(self, world, bucket_elems=16 * 1024 * 1024, force=False):
         self.world = world
+        self.force = force            # run the collectives even in a one-rank group (exercises the RCCL path on a single GPU)
         self.bucket = bucket_elems
         self.avg = dist.is_initialized() and dist.get_backend() == "nccl"
         self._pending = []
@@ -59,7 +60,7 @@ class GradReducer:
         """defer=True (RCCL only): start the collectives and return -- they run on RCCL's stream next to whatever the
         caller launches next (the next critic's forward/backward); the next non-deferred call, or wait(), makes the
         current stream wait for everything outstanding."""
-        if self.world == 1:
+        if self.world == 1 and not self.force:
             return
         if self.avg:
             for g in groups:

@@ -308,3 +308,66 @@ def test_dp2_product_optimize_stage_replicas_identical_and_match_global_batch():
         assert p.exitcode == 0
     assert moved > 1e-3, moved                                  # the discriminator did train
     assert eg <= 1e-5 and ed <= 1e-5, (eg, ed)
+
+
+# --------------------------------------------------------------------------------- the RCCL branch, one rank
+def _rccl_worker(port, out):
+    """A one-rank `nccl` (= RCCL) group on the one GPU: AVG over one rank is the identity, so the reduced run must equal the plain
+    one -- what is exercised is everything no multi-GPU node was available for: communicator setup, async all_reduce(AVG) on slices
+    of the flat gradient buffers, deferred collectives next to the bucketed backward, and segmented hipGraph capture / replay with
+    RCCL's helper threads alive."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    import torch.distributed as dist
+    from consistent__style_transfer_amd import model, ops, stages
+    from consistent__style_transfer_amd.parallel import GradReducer, check_replicas, max_over_ranks
+    from consistent__style_transfer_amd.trainer import StepCache
+    from test_gpu_stages import CURVE_LR, pre_batch
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    try:
+        ops.set_precision("f32")
+        name = "tiny"
+        c = CONFIGS[name]
+
+        def build():
+            set_constants(model, c)
+            pre = stages.PretrainStage(c["V"], 2, lr=CURVE_LR[name])
+            for attr, which in (("classifier", "cls"), ("matcher", "mat"), ("denoiser", "dn")):
+                _load(getattr(pre, attr), which)
+            pre = pre.cuda().eval()
+            pre.setup_optim()
+            return pre
+
+        def run(reducer, graphed, bucketed):
+            pre = build()
+            pre.bucketed = bucketed
+            cache = StepCache(graphed, [pre], reducer)
+            for it in range(5):
+                cache.run("p", lambda *b, reducer=None: pre.train_step(b, reducer=reducer), list(cu(pre_batch(c, it))))
+            torch.cuda.synchronize()
+            return pre, cache
+
+        red = GradReducer(1, bucket_elems=4096, force=True)        # small buckets: several collectives in flight per call
+        assert red.avg
+        plain, _ = run(None, False, False)
+        dp, cache = run(red, True, True)
+        assert all(len(g.graphs) > 1 for g in cache.graphs.values())     # split at the reduce points
+        err = max(float((dp.groups[k].flat_p - plain.groups[k].flat_p).abs().max()) for k in plain.groups)
+        check_replicas([g.flat_p for g in dp.groups.values()], "one rank")
+        assert max_over_ranks(1.5, torch.device("cuda")) == 1.5
+        out.put(err)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_rccl_branch_single_rank_segmented_replay():
+    import torch.multiprocessing as mp
+    from test_dp_gloo_cpu import _collect
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_worker, args=(_free_port(), q))
+    p.start()
+    (err,) = _collect([p], q, 1, timeout=600)
+    p.join(120)
+    assert p.exitcode == 0
+    assert err <= 2e-4, err                  # Adam turns rounding-level gradient differences (atomic column sums) into lr-sized steps
