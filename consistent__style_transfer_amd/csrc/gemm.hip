@@ -530,6 +530,51 @@ static int vec_ok(const float* p, long ld, long stride) {
     return (((uintptr_t)p & 15) == 0) && (ld % 4 == 0) && (stride % 4 == 0);
 }
 
+// Tile / split-K choice of cst_gemm, shared with cst_gemm_workspace_floats so the two cannot drift: 128x128 tiles when they fill
+// the 256 CUs on their own; with a long K and a handful of big tiles, big tiles + split-K; otherwise 64x64 tiles, split along K when
+// even those are few.  Partial slabs are summed in slice order by cst_gemm_splitk_reduce.  The split count shrinks to what fits
+// `ws_floats`.
+static void gemm_plan(int M, int N, int K, int batch, int precision_f32, int tile, int splitk, bool has_ws, long ws_floats,
+                      int* use_big_out, int* splits_out, int* kps_out) {
+    const long big = (long)cst_div_up(M, 128) * cst_div_up(N, 128) * batch;
+    const long small = (long)cst_div_up(M, 64) * cst_div_up(N, 64) * batch;
+    int use_big, splits = 1;
+    tile &= ~1;
+    if (tile == 128 || (tile == 0 && big >= 192)) { use_big = 1; }
+    else if (tile == 0 && K >= 2048 && big >= 16 && has_ws && splitk == 0) {
+        use_big = 1;
+        splits = (int)((512 + big - 1) / big);
+        if (splits > K / 512) splits = K / 512;
+    } else {
+        use_big = 0;
+        if (splitk == 0 && has_ws && small < 128 && K >= 512) {
+            splits = (int)((512 + small - 1) / small);
+            if (splits > K / 128) splits = K / 128;
+        }
+    }
+    if (splitk > 1) splits = splitk;
+    if (splitk == 1) splits = 1;
+    int kps = cst_div_up(K, 64) * 64;
+    if (splits > 1) {
+        const int bk = precision_f32 ? 32 : 64;
+        kps = cst_div_up(cst_div_up(K, splits), bk) * bk;
+        splits = cst_div_up(K, kps);
+        while (splits > 1 && (long)batch * splits * M * N > ws_floats) {
+            kps += bk;
+            splits = cst_div_up(K, kps);
+        }
+    }
+    if (splits <= 1) { splits = 1; kps = cst_div_up(K, 64) * 64; }
+    *use_big_out = use_big; *splits_out = splits; *kps_out = kps;
+}
+
+extern "C" long cst_gemm_workspace_floats(int M, int N, int K, int batch, int precision_f32, int tile, int splitk) {
+    if (M <= 0 || N <= 0 || K <= 0 || batch <= 0) return 0;
+    int use_big, splits, kps;
+    gemm_plan(M, N, K, batch, precision_f32, tile, splitk, true, 0x7fffffffffffffffL, &use_big, &splits, &kps);
+    return splits > 1 ? (long)batch * splits * M * N : 0;
+}
+
 extern "C" int cst_gemm(const float* A, long lda, int a_kmajor, const float* B, long ldb, int b_kmajor,
                         float* C, long ldc, int M, int N, int K,
                         const float* bias, const float* addend, long ldadd,
@@ -558,37 +603,10 @@ extern "C" int cst_gemm(const float* A, long lda, int a_kmajor, const float* B, 
     // tile / split choice.  128x128 tiles when they fill the 256 CUs on their own; with a long K
     // and a handful of big tiles, big tiles + split-K; otherwise 64x64 tiles, split along K when
     // even those are few.  Partial slabs are summed in slice order by cst_gemm_splitk_reduce.
-    const long big = (long)cst_div_up(M, 128) * cst_div_up(N, 128) * batch;
-    const long small = (long)cst_div_up(M, 64) * cst_div_up(N, 64) * batch;
-    int use_big, splits = 1;
     const int w8 = tile & 1;                    // odd tile code 129 forces the 8-wave build, 128 the 4-wave one
     const int forced = tile != 0;
-    tile &= ~1;
-    if (tile == 128 || (tile == 0 && big >= 192)) { use_big = 1; }
-    else if (tile == 0 && K >= 2048 && big >= 16 && workspace && splitk == 0) {
-        use_big = 1;
-        splits = (int)((512 + big - 1) / big);
-        if (splits > K / 512) splits = K / 512;
-    } else {
-        use_big = 0;
-        if (splitk == 0 && workspace && small < 128 && K >= 512) {
-            splits = (int)((512 + small - 1) / small);
-            if (splits > K / 128) splits = K / 128;
-        }
-    }
-    if (splitk > 1) splits = splitk;
-    if (splitk == 1) splits = 1;
-    if (splits > 1) {
-        const int bk = precision_f32 ? 32 : 64;
-        int kps = cst_div_up(cst_div_up(K, splits), bk) * bk;
-        splits = cst_div_up(K, kps);
-        while (splits > 1 && (long)batch * splits * M * N > workspace_floats) {
-            kps += bk;
-            splits = cst_div_up(K, kps);
-        }
-        g.k_per_split = kps;
-    }
-    if (splits <= 1) { splits = 1; g.k_per_split = cst_div_up(K, 64) * 64; }
+    int use_big, splits;
+    gemm_plan(M, N, K, batch, precision_f32, tile, splitk, workspace != nullptr, workspace_floats, &use_big, &splits, &g.k_per_split);
     CST_REQUIRE(splits == 1 || workspace, "cst_gemm: split-K needs a workspace");
     g.splits = splits;
     g.slab = workspace;

@@ -1232,6 +1232,96 @@ static int bgemm_launch(const BGemmArgs& g, hipStream_t st) {
     return 0;
 }
 
+// Tile / split-K choice of cst_gemm_bf16 (and of cst_gemm_bf16_w8, which pins 64 x 128), shared with cst_gemm_bf16_workspace_floats.
+// tools/gemm_bench.py bf16nt / enc: the 2-stage ring with two or three workgroups per CU beats the deeper ones; 64x128 tiles when they
+// alone give >= 256 workgroups, 128x128 + split-K for long-K products with few output tiles, 64x128 (+ split) otherwise.
+// Round quantisation: 64x128 tiles run 3 workgroups per CU (768 slots), 128x128 tiles 2 (512 slots).  At equal round efficiency the
+// smaller tile wins; when the 128x128 grid fills its slots markedly better -- 9216 x 768 (432 of 512 against 864 of 1536),
+// 4608 x 1536 -- it is 15-30 % faster.  `tile` arrives with the ring bits cleared (64 / 128 force a tile).
+static void bgemm_plan(int M, int N, int K, int tile, int splitk, bool has_ws, long ws_floats, int* use_big_out, int* splits_out, int* kps_out) {
+    const long big = (long)cst_div_up(M, 128) * cst_div_up(N, 128);
+    const long mid = (long)cst_div_up(M, 64) * cst_div_up(N, 128);
+    int use_big, splits = 1;
+    if (tile == 128) use_big = 1;
+    else if (tile == 64) use_big = 0;
+    else {
+        use_big = (mid < 256 && K >= 2048);
+        if (!use_big && splitk <= 1 && mid >= 256 && big >= 256) {
+            const double e64 = (double)mid / (double)(cst_div_up(mid, 768) * 768);
+            const double e128 = (double)big / (double)(cst_div_up(big, 512) * 512);
+            if (e128 > e64 + 0.15) use_big = 1;
+        }
+    }
+    const long tiles = use_big ? big : mid;
+    if (splitk > 1) splits = splitk;
+    else if (splitk == 0 && has_ws && tiles < 192 && K >= 512) {
+        splits = (int)((384 + tiles - 1) / tiles);
+        if (splits > K / 256) splits = K / 256;
+    }
+    int kps = K;
+    if (splits > 1) {
+        kps = cst_div_up(cst_div_up(K, splits), 64) * 64;
+        splits = cst_div_up(K, kps);
+        while (splits > 1 && (long)splits * M * N > ws_floats) { kps += 64; splits = cst_div_up(K, kps); }
+    }
+    if (splits <= 1) { splits = 1; kps = K; }
+    *use_big_out = use_big; *splits_out = splits; *kps_out = kps;
+}
+
+extern "C" long cst_gemm_bf16_workspace_floats(int M, int N, int K, int tile, int splitk) {
+    if (M <= 0 || N <= 0 || K <= 0) return 0;
+    int use_big, splits, kps;
+    tile &= ~3;
+    if (tile == 136) tile = 128;
+    bgemm_plan(M, N, K, tile, splitk, true, 0x7fffffffffffffffL, &use_big, &splits, &kps);
+    return splits > 1 ? (long)splits * M * N : 0;
+}
+
+// split-K choice of cst_gemm_bf16_tt (128 x 128 tiles only), shared with its workspace query
+static void bgemm_tt_plan(int M, int N, int K, int splitk, bool has_ws, long ws_floats, int* splits_out, int* kps_out) {
+    const long tiles = (long)cst_div_up(M, 128) * cst_div_up(N, 128);
+    int splits = 1;
+    if (splitk > 1) splits = splitk;
+    else if (splitk == 0 && has_ws && tiles < 192 && K >= 512) {
+        splits = (int)((384 + tiles - 1) / tiles);
+        if (splits > K / 256) splits = K / 256;
+    }
+    int kps = K;
+    if (splits > 1) {
+        kps = cst_div_up(cst_div_up(K, splits), 64) * 64;
+        splits = cst_div_up(K, kps);
+        while (splits > 1 && (long)splits * M * N > ws_floats) { kps += 64; splits = cst_div_up(K, kps); }
+    }
+    if (splits <= 1) { splits = 1; kps = K; }
+    *splits_out = splits; *kps_out = kps;
+}
+
+extern "C" long cst_gemm_bf16_tt_workspace_floats(int M, int N, int K, int splitk) {
+    if (M <= 0 || N <= 0 || K <= 0) return 0;
+    int splits, kps;
+    bgemm_tt_plan(M, N, K, splitk, true, 0x7fffffffffffffffL, &splits, &kps);
+    return splits > 1 ? (long)splits * M * N : 0;
+}
+
+// split-K choice of the recurrent products (cst_gemm_bf16_lstm / _lstm_bwd / _lstm_attn: 64 x 128 tiles, slabs only), shared with
+// their workspace query
+static void bgemm_lstm_plan(int M, int N, int K, int problems, int splitk, int* splits_out, int* kps_out) {
+    const long tiles = (long)cst_div_up(M, 64) * cst_div_up(N, 128) * problems;
+    int splits = splitk > 0 ? splitk : (int)((384 + tiles - 1) / tiles);
+    if (splits > K / 128) splits = K / 128;
+    if (splits < 1) splits = 1;
+    const int kps = cst_div_up(cst_div_up(K, splits), 64) * 64;
+    *splits_out = cst_div_up(K, kps); *kps_out = kps;
+}
+
+/* N = 4H gate columns; problems = 2 when both encoder directions go in one launch */
+extern "C" long cst_gemm_bf16_lstm_workspace_floats(int M, int N, int K, int problems, int splitk) {
+    if (M <= 0 || N <= 0 || K <= 0 || problems <= 0) return 0;
+    int splits, kps;
+    bgemm_lstm_plan(M, N, K, problems, splitk, &splits, &kps);
+    return (long)problems * splits * M * N;
+}
+
 extern "C" int cst_gemm_bf16(const void* A, long lda, const void* B, long ldb,
                              float* C, long ldc, void* Cb, long ldcb, int M, int N, int K,
                              const float* bias, const float* addend, long ldadd, const void* aux, long ldaux,
@@ -1261,36 +1351,9 @@ extern "C" int cst_gemm_bf16(const void* A, long lda, const void* B, long ldb,
     static const bool w8_auto = getenv("CST_GEMM_W8") != nullptr;        // A/B switch: 128 x 128 tiles on 8 waves wherever 128 x 128 is chosen
     bool w8 = tile == 136;                       // 136: 128 x 128 tile on 8 waves
     if (w8) tile = 128;
-    const long big = (long)cst_div_up(M, 128) * cst_div_up(N, 128);
-    const long mid = (long)cst_div_up(M, 64) * cst_div_up(N, 128);
-    int use_big, splits = 1;
-    if (tile == 128) use_big = 1;
-    else if (tile == 64) use_big = 0;
-    else {
-        use_big = (mid < 256 && K >= 2048);
-        // Round quantisation (measured, tools/gemm_bench.py enc): 64x128 tiles run 3 workgroups per CU (768 slots), 128x128 tiles 2
-        // (512 slots).  At equal round efficiency the smaller tile wins (more independent workgroups hide the first-touch latency of
-        // each K-tile); when the 128x128 grid fills its slots markedly better -- 9216 x 768 (432 of 512 against 864 of 1536),
-        // 4608 x 1536 -- it is 15-30 % faster.
-        if (!use_big && splitk <= 1 && mid >= 256 && big >= 256) {
-            const double e64 = (double)mid / (double)(cst_div_up(mid, 768) * 768);
-            const double e128 = (double)big / (double)(cst_div_up(big, 512) * 512);
-            if (e128 > e64 + 0.15) use_big = 1;
-        }
-    }
-    const long tiles = use_big ? big : mid;
-    if (splitk > 1) splits = splitk;
-    else if (splitk == 0 && workspace && tiles < 192 && K >= 512) {
-        splits = (int)((384 + tiles - 1) / tiles);
-        if (splits > K / 256) splits = K / 256;
-    }
-    if (splits > 1) {
-        int kps = cst_div_up(cst_div_up(K, splits), 64) * 64;
-        splits = cst_div_up(K, kps);
-        while (splits > 1 && (long)splits * M * N > workspace_floats) { kps += 64; splits = cst_div_up(K, kps); }
-        g.k_per_split = kps;
-    }
-    if (splits <= 1) { splits = 1; g.k_per_split = K; }
+    int use_big, splits;
+    bgemm_plan(M, N, K, tile, splitk, workspace != nullptr, workspace_floats, &use_big, &splits, &g.k_per_split);
+    const long tiles = use_big ? (long)cst_div_up(M, 128) * cst_div_up(N, 128) : (long)cst_div_up(M, 64) * cst_div_up(N, 128);
     CST_REQUIRE(splits == 1 || workspace, "cst_gemm_bf16: split-K needs a workspace");
     g.splits = splits; g.slab = workspace;
     hipStream_t st = (hipStream_t)stream;
@@ -1347,20 +1410,8 @@ extern "C" int cst_gemm_bf16_tt(const void* A, long lda, const void* B, long ldb
     g.M = M; g.N = N; g.K = K; g.act = 0; g.alpha = 1.f; g.gate_scale = 1.f; g.accumulate = accumulate;
     g.slab_only = 0;
     g.drop = cst_make_drop(0.f, 0, 0, nullptr);
-    const long tiles = (long)cst_div_up(M, 128) * cst_div_up(N, 128);
-    int splits = 1;
-    if (splitk > 1) splits = splitk;
-    else if (splitk == 0 && workspace && tiles < 192 && K >= 512) {
-        splits = (int)((384 + tiles - 1) / tiles);
-        if (splits > K / 256) splits = K / 256;
-    }
-    int kps = K;
-    if (splits > 1) {
-        kps = cst_div_up(cst_div_up(K, splits), 64) * 64;
-        splits = cst_div_up(K, kps);
-        while (splits > 1 && (long)splits * M * N > workspace_floats) { kps += 64; splits = cst_div_up(K, kps); }
-    }
-    if (splits <= 1) { splits = 1; kps = K; }
+    int splits, kps;
+    bgemm_tt_plan(M, N, K, splitk, workspace != nullptr, workspace_floats, &splits, &kps);
     CST_REQUIRE(splits == 1 || workspace, "cst_gemm_bf16_tt: split-K needs a workspace");
     g.splits = splits; g.k_per_split = kps; g.slab = workspace;
     hipStream_t st = (hipStream_t)stream;
@@ -1437,21 +1488,8 @@ extern "C" int cst_gemm_bf16_w8(const void* A, long lda, const void* Bq, long ld
     g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.ldcb = ldcb; g.ldadd = ldadd; g.ldaux = ldaux;
     g.M = M; g.N = N; g.K = K; g.act = act; g.alpha = alpha; g.gate_scale = gate_scale; g.accumulate = accumulate;
     g.drop = cst_make_drop(drop_p, drop_seed, drop_stream, drop_seed_dev);
-    const long tiles = (long)cst_div_up(M, 64) * cst_div_up(N, 128);
-    int splits = 1;
-    if (splitk > 1) splits = splitk;
-    else if (splitk == 0 && workspace && tiles < 192 && K >= 512) {
-        splits = (int)((384 + tiles - 1) / tiles);
-        if (splits > K / 256) splits = K / 256;
-    }
-    g.k_per_split = K;
-    if (splits > 1) {
-        int kps = cst_div_up(cst_div_up(K, splits), 64) * 64;
-        splits = cst_div_up(K, kps);
-        while (splits > 1 && (long)splits * M * N > workspace_floats) { kps += 64; splits = cst_div_up(K, kps); }
-        g.k_per_split = kps;
-    }
-    if (splits <= 1) { splits = 1; g.k_per_split = K; }
+    int use_big_unused, splits;
+    bgemm_plan(M, N, K, 64, splitk, workspace != nullptr, workspace_floats, &use_big_unused, &splits, &g.k_per_split);       // 64 x 128 tiles only
     CST_REQUIRE(splits == 1 || workspace, "cst_gemm_bf16_w8: split-K needs a workspace");
     g.splits = splits; g.slab = workspace;
     hipStream_t st = (hipStream_t)stream;
@@ -1558,12 +1596,8 @@ static int lstm_gemm_front(const char* who, BGemmArgs& g, const void* A, const v
     g.drop = cst_make_drop(0.f, 0, 0, nullptr);
     g.slab_only = 1;
     const int np = A2 ? 2 : 1;
-    const long tiles = (long)cst_div_up(M, 64) * cst_div_up(N, 128) * np;
-    int splits = splitk > 0 ? splitk : (int)((384 + tiles - 1) / tiles);
-    if (splits > K / 128) splits = K / 128;
-    if (splits < 1) splits = 1;
-    int kps = cst_div_up(cst_div_up(K, splits), 64) * 64;
-    splits = cst_div_up(K, kps);
+    int splits, kps;
+    bgemm_lstm_plan(M, N, K, np, splitk, &splits, &kps);
     CST_REQUIRE((long)np * splits * M * N <= workspace_floats, "%s: workspace too small", who);
     g.splits = splits; g.k_per_split = kps; g.slab = workspace;
     bgemm_launch<64, 128, 2>(g, st);

@@ -13,7 +13,8 @@
  *     are int64 (loader.py:63-68 builds torch.long tensors);
  *   - `stream` is a hipStream_t passed as void*; calls are asynchronous and ordered only by
  *     that stream; nothing synchronises, allocates or frees (graph-capture safe);
- *   - the caller owns every buffer; workspace sizes come from the *_workspace_floats twins;
+ *   - the caller owns every buffer; workspace sizes come from the *_workspace_floats twins (every entry point that takes a
+ *     workspace has one);
  *   - return value: 0 ok, 1 argument error, 2 launch error; cst_last_error() gives the text;
  *     nothing throws across the boundary;
  *   - dropout: (p, seed, stream_id, seed_dev) -- keep(idx) <=> (mix32(seed + *seed_dev,
@@ -53,6 +54,9 @@ int cst_gemm(const float* A, long lda, int a_kmajor, const float* B, long ldb, i
              int batch, long sA, long sB, long sC, long sBias, long sAdd, long sAux,
              float drop_p, uint32_t drop_seed, uint32_t drop_stream, const void* drop_seed_dev,
              int tile, int splitk, float* workspace, long workspace_floats, void* stream);
+/* Floats of split-K workspace cst_gemm would use for this problem when given an unlimited one (0: single pass).  A smaller
+ * workspace is never an error: the library lowers the split count to what fits. */
+long cst_gemm_workspace_floats(int M, int N, int K, int batch, int precision_f32, int tile, int splitk);
 
 /* Kernel-precise timing of the two GEMM kernels for roofline reporting: while enabled every launch
  * carries a start and a stop HIP event bound to the dispatch (hipExtLaunchKernelGGL); the read call
@@ -79,6 +83,8 @@ int cst_gemm_bf16(const void* A, long lda, const void* B, long ldb,
                   int act, float gate_scale, float alpha, int accumulate,
                   float drop_p, uint32_t drop_seed, uint32_t drop_stream, const void* drop_seed_dev,
                   int tile, int splitk, float* workspace, long workspace_floats, void* stream);
+/* The same query for cst_gemm_bf16 (and cst_gemm_bf16_w8: pass tile = 64). */
+long cst_gemm_bf16_workspace_floats(int M, int N, int K, int tile, int splitk);
 /* out[r, 0..ldo) = bf16(x[r,:] * dropmask) zero-padded, out_t[c, 0..ldot) = the transpose zero-padded
  * (either may be null); x is fp32, or bf16 when x_is_bf16 (pure transpose). */
 int cst_cast_bf16(const void* x, int x_is_bf16, long ldx, int R, int C,
@@ -241,6 +247,7 @@ int cst_gemm_bf16_w8(const void* A, long lda, const void* Bq, long ldb, const fl
  * split-K as cst_gemm_bf16. */
 int cst_gemm_bf16_tt(const void* A, long lda, const void* B, long ldb, float* C, long ldc, int M, int N, int K,
                      int accumulate, int splitk, float* workspace, long workspace_floats, void* stream);
+long cst_gemm_bf16_tt_workspace_floats(int M, int N, int K, int splitk);
 
 /* All L time steps of both directions of the BiLSTM encoder (rnn.py:25-27, called at rnn.py:57, :62) in ONE launch: a
  * workgroup takes 16 batch rows of one direction through the whole sequence (recurrences are independent across batch
@@ -292,6 +299,10 @@ int cst_gemm_bf16_lstm(const void* A, long lda, const void* B, long ldb, int M, 
                        float* gates2, const float* c_prev2, float* h_out_2, float* c_out2, float* h_out2_2,
                        void* h_bf16_p2, void* h_bf16_2_p2,
                        int splitk, float* workspace, long workspace_floats, void* stream);
+/* Workspace of the recurrent products (cst_gemm_bf16_lstm / _lstm_bwd / _lstm_attn), which always write their partial sums to it:
+ * N = 4H gate columns (the K of _lstm_bwd's product for that entry point), problems = 2 when both encoder directions go in one
+ * launch.  These entry points REQUIRE at least this much. */
+long cst_gemm_bf16_lstm_workspace_floats(int M, int N, int K, int problems, int splitk);
 /* The decoder's variant of the forward step (rnn.py:75-79): gates product (bias only), cell, then the single-query
  * attention of cst_dot_attn_fwd with h_t as the query (D = H) and the FFN-input dropout, all in the second launch
  * (one workgroup per batch row).  Arguments as cst_gemm_bf16_lstm / cst_dot_attn_fwd. */

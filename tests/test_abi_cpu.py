@@ -35,6 +35,34 @@ def test_argument_errors_are_status_codes_not_exceptions():
     assert L.fn["cst_layernorm_bwd_workspace_floats"](4608, 512) == 2 * 1024 * 512
 
 
+def test_workspace_queries_state_the_split_k_need():
+    """Every entry point that takes a workspace has a *_workspace_floats twin: shape-only, callable without a GPU.  They
+    return what the library would use given an unlimited workspace -- splits x M x N floats (x batch / problems), 0 for one pass."""
+    L = _lib.lib()
+    q = L.fn
+    # encoder-layer products fill the chip by themselves: no split
+    assert q["cst_gemm_bf16_workspace_floats"](9216, 2048, 768, 0, 0) == 0
+    assert q["cst_gemm_workspace_floats"](9216, 2048, 768, 1, 0, 0, 0) == 0
+    # a decoder-step product (M = batch): few tiles, split along K -- a whole number of [M, N] slabs, at most K / 256 of them
+    need = q["cst_gemm_bf16_workspace_floats"](256, 512, 1024, 0, 0)
+    assert need > 0 and need % (256 * 512) == 0 and need // (256 * 512) <= 1024 // 256
+    assert q["cst_gemm_bf16_workspace_floats"](256, 512, 1024, 0, 1) == 0                 # split-K forbidden by the caller
+    assert q["cst_gemm_bf16_workspace_floats"](256, 512, 1024, 64, 4) == 4 * 256 * 512     # forced
+    # weight gradient with a long contraction: dW[2304, 768] over 9216 tokens
+    need = q["cst_gemm_bf16_tt_workspace_floats"](2304, 768, 9216, 0)
+    assert need > 0 and need % (2304 * 768) == 0
+    # recurrent products always write slabs: both encoder directions, 4H = 1024 gate columns, forced 2-way split
+    assert q["cst_gemm_bf16_lstm_workspace_floats"](256, 1024, 256, 2, 2) == 2 * 2 * 256 * 1024
+    need = q["cst_gemm_workspace_floats"](256, 512, 2048, 1, 0, 0, 0)
+    assert need > 0 and need % (256 * 512) == 0
+    assert q["cst_relconv_bwd_weight_workspace_floats"](256, 18, 3, 128, 300) > 0
+    # the package's per-device workspace (ops.WS_FLOATS) covers every product of the benchmark workloads at its preferred split
+    from consistent__style_transfer_amd import ops
+    for M, N, K in [(256, 2048, 640), (256, 512, 1024), (256, 10000, 512), (256, 512, 10048), (256, 640, 2048), (4608, 512, 10048),
+                    (512, 2048, 640), (512, 10000, 512)]:
+        assert q["cst_gemm_bf16_workspace_floats"](M, N, K, 0, 0) <= ops.WS_FLOATS, (M, N, K)
+
+
 def test_fused_entry_points_validate_their_limits():
     """The fused kernels state their shape limits as status 1 + message (the host wrappers fall back before that)."""
     L = _lib.lib()
