@@ -81,3 +81,90 @@ def test_three_stages_cli(tmp_path, graph):
         assert os.path.exists(log / ver / "meta_tags.csv")
     finally:
         _restore_constants()
+
+
+# ------------------------------------------------------------------------------ data-parallel transfer writer (main_optimize --mode test)
+def _prepare_transfer_dirs(root):
+    """Corpus + tokenizer + random-init checkpoints under the reference's file names: enough for `--mode test`."""
+    from consistent__style_transfer_amd.model import MLM, DenoiseLSTM, Matcher, TextCNN
+    from consistent__style_transfer_amd.vocab import BPETokenizer
+    data, dump = root / "data" / "yelp", root / "dump" / "yelp"
+    os.makedirs(data)
+    os.makedirs(dump / "pretrain")
+    os.makedirs(dump / "warmup")
+    for lab in (0, 1):
+        src = os.path.join(G, f"yelp_dev_sample.{lab}")
+        lines = open(src, encoding="utf-8").read().split("\n")[:37 + 6 * lab]          # 37 + 43 = 80 sentences: not a multiple of 32
+        for split in ("train", "test"):
+            with open(data / f"style.{split}.{lab}", "w", encoding="utf-8") as f:
+                f.write("\n".join(lines) + "\n")
+    shutil.copy(os.path.join(G, "yelp_sample-vocab.json"), dump / "yelp-vocab.json")
+    shutil.copy(os.path.join(G, "yelp_sample-merges.txt"), dump / "yelp-merges.txt")
+    vocab = BPETokenizer.load(str(dump / "yelp-vocab.json"), str(dump / "yelp-merges.txt"))
+    from consistent__style_transfer_amd.model import match, mlm
+    mlm.d_model = match.d_model = 64                           # what --d_model / --n_head / --n_layer below will set (arguments.apply_model_constants)
+    mlm.n_head = match.n_head = 4
+    mlm.n_layer = match.n_layer = 1
+    torch.manual_seed(5)
+    V = len(vocab)
+    torch.save(TextCNN(V, n_class=2).state_dict(), dump / "pretrain" / "cls.pth")
+    torch.save(Matcher(V).state_dict(), dump / "pretrain" / "mat.pth")
+    torch.save(MLM(V, 2).state_dict(), dump / "pretrain" / "dn.pth")
+    torch.save(DenoiseLSTM(V, 2, 18).state_dict(), dump / "warmup" / "G.pth")
+
+
+def _transfer_args(root, out):
+    return ["--dataset", "yelp", "--data_dir", str(root / "data"), "--dump_dir", str(root / "dump"), "--log_dir", str(root / "log"),
+            "--out_dir", str(root / out), "--n_layer", "1", "--d_model", "64", "--n_head", "4", "--batch_size", "32", "--ver", "v0",
+            "--mode", "test"]
+
+
+def _transfer_worker(rank, world, port, root):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0",
+                      CST_DIST_BACKEND="gloo")
+    import torch.distributed as dist
+    from consistent__style_transfer_amd import main_optimize
+    _small_constants()
+    try:
+        main_optimize.main(_transfer_args(root, "out2"))
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+
+
+def test_transfer_writer_two_ranks_equals_one(tmp_path):
+    """main_optimize.py:157-174 under data parallelism: two ranks (gloo, one GPU) decode their halves of every global batch and rank 0
+    merges the part files -- the same sentences in the same order as the one-process run, nothing dropped (80 sentences per split,
+    batches of 32: the last batch is short and odd-sized shards get padded), no part files left behind."""
+    import socket
+
+    import torch.multiprocessing as mp
+    from consistent__style_transfer_amd import main_optimize
+    from consistent__style_transfer_amd import ops as _ops
+    root = tmp_path
+    _small_constants()
+    try:
+        _prepare_transfer_dirs(root)
+        main_optimize.main(_transfer_args(root, "out1"))
+        _ops.set_precision("bf16")
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+        ctx = mp.get_context("spawn")
+        procs = [ctx.Process(target=_transfer_worker, args=(r, 2, port, root)) for r in range(2)]
+        for p in procs:
+            p.start()
+        for p in procs:
+            p.join(600)
+            assert p.exitcode == 0
+        for split in ("train", "test"):
+            for lab, n in ((0, 37), (1, 43)):
+                a = open(root / "out1" / "yelp-v0" / f"style.{split}.{lab}.tsf", encoding="utf-8").read().split("\n")
+                b = open(root / "out2" / "yelp-v0" / f"style.{split}.{lab}.tsf", encoding="utf-8").read().split("\n")
+                assert len(a) - 1 == n and len(b) - 1 == n
+                same = sum(x == y for x, y in zip(a, b))
+                assert same >= n - 1, (split, lab, same, n)        # exact-fp32 ids; a different shard size may reorder one split-K sum
+        assert not [f for f in os.listdir(root / "out2" / "yelp-v0") if ".part" in f]
+    finally:
+        _restore_constants()
