@@ -226,3 +226,70 @@ def test_prefetched_batches_equal_inline_batches_and_label_cache_replays_them(tm
         assert all(torch.equal(x, y) for x, y in zip(a, b))
     with pytest.raises(KeyError):
         back.get(7, 0, 64)
+
+
+# ------------------------------------------------------------------------------ offline quality metrics
+def test_evaluate_metric_arithmetic():
+    """Hand-computed cases of the three metrics (evaluate/auto/transfer_intensity.py, content_preserve.py, naturalness.py)."""
+    from consistent__style_transfer_amd import evaluate as ev
+    from consistent__style_transfer_amd.wmd import WordVectors
+    # STI: unit-ground-distance EMD = total variation, signed by the target class's probability going up or down
+    assert ev.unit_emd([0.9, 0.1], [0.2, 0.8]) == pytest.approx(0.7)
+    assert ev.direction_corrected_emd([0.9, 0.1], [0.2, 0.8], 1) == pytest.approx(0.7)
+    assert ev.direction_corrected_emd([0.9, 0.1], [0.2, 0.8], 0) == pytest.approx(-0.7)
+    assert ev.direction_corrected_emd([0.5, 0.5], [0.5, 0.5], 1) == 0.0            # no change counts as "not worse": factor +1
+    assert ev.unit_emd([0.2, 0.3, 0.5], [0.5, 0.3, 0.2]) == pytest.approx(0.3)
+    probs = {"bad food": [0.9, 0.1], "great food": [0.1, 0.9], "ok": [0.5, 0.5]}
+    stis = ev.calculate_STIs(["bad food", "great food"], ["great food", "ok"], [1, 0], lambda ts: [probs[t] for t in ts])
+    assert stis == pytest.approx([0.8, 0.4])
+    # tokenizer classes and masking
+    assert ev.tokenize("don't go -- it's over-priced !!! 12 $5") == ["don't", "go", "--", "it's", "over-priced", "!!!", "12", "$", "5"]
+    assert ev.mask_style_words(["The food was Great !", "bad"], {"great", "bad"}) == ["The food was MASK !", "MASK"]
+    # CP through the restated WMD: identical masked sentences -> 0, disjoint vocabulary -> the vector distance
+    wv = WordVectors(["food", "service", "MASK"], [[1.0, 0.0], [0.0, 1.0], [1.0, 1.0]])
+    d = ev.calculate_wmd_scores(["food MASK", "food"], ["food MASK", "service"], wv)
+    assert d[0] == pytest.approx(0.0, abs=1e-9) and d[1] == pytest.approx(2 ** 0.5)
+    assert ev.finite_mean([1.0, float("inf"), 3.0]) == (2.0, 1)
+    # NT: a success unless the input scored strictly higher
+    j = ev.generate_judgments([0.9, 0.2, 0.5], [0.1, 0.8, 0.5])
+    assert j == [1, 0, None] and ev.aggregate_judgments(j) == pytest.approx(2 / 3)
+    # lexicon rule: non-zero weights beyond two standard deviations of the non-zero weights
+    w = [0.0] * 20 + [0.1, -0.1, 0.12, -0.09, 0.08, 0.11, -0.12, 0.1, -0.1, 0.09, 3.0, -2.5]
+    vocab = {f"w{i}": i for i in range(len(w))}
+    assert ev.lexicon_from_weights(w, vocab) == [("w31", -2.5), ("w30", 3.0)]
+
+
+def test_evaluate_prepare_and_eval_pipeline(tmp_path):
+    """prepare + eval end to end on the dev-sample fixture with a fake 'model' whose transfers flip a few sentiment words: every dump
+    is built, the three numbers come out finite and in range, and a stronger edit scores a higher STI than the identity transfer."""
+    pytest.importorskip("sklearn")
+    from consistent__style_transfer_amd import evaluate as ev
+    G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    data, root = tmp_path / "data" / "yelp", tmp_path
+    os.makedirs(data)
+    lines = {lab: [l for l in open(os.path.join(G, f"yelp_dev_sample.{lab}"), encoding="utf-8").read().split("\n") if l.strip()] for lab in (0, 1)}
+    for lab in (0, 1):
+        for split, sl in (("train", slice(0, 110)), ("dev", slice(110, 130)), ("test", slice(130, 150))):
+            with open(data / f"style.{split}.{lab}", "w", encoding="utf-8") as f:
+                f.write("\n".join(lines[lab][sl]) + "\n")
+    swap = {"good": "bad", "great": "terrible", "love": "hate", "best": "worst", "delicious": "awful", "friendly": "rude", "amazing": "horrible"}
+    swap.update({v: k for k, v in list(swap.items())})
+    flip = lambda s: " ".join(swap.get(t, t) for t in s.split())
+    for name, fn in (("flip", flip), ("same", lambda s: s)):
+        out = root / "output" / f"yelp-{name}"
+        os.makedirs(out)
+        for split in ("train", "test"):
+            for lab in (0, 1):
+                src = open(data / f"style.{split}.{lab}", encoding="utf-8").read().split("\n")[:-1]
+                with open(out / f"style.{split}.{lab}.tsf", "w", encoding="utf-8") as f:
+                    f.write("\n".join(fn(s) for s in src) + "\n")
+    res = {}
+    for name in ("flip", "same"):
+        P = ev.prepare("yelp", name, base_dir=str(root), eval_dir=str(root / "evaluate"), w2v_dim=16, log=lambda *_: None)
+        assert all(os.path.exists(P[k]) for k in ("clf", "lexicon", "vectorizer", "w2v", "adv"))
+        res[name] = ev.evaluate("yelp", name, base_dir=str(root), eval_dir=str(root / "evaluate"), log=lambda *_: None)
+        assert -1.0 <= res[name]["STI"] <= 1.0 and 0.0 <= res[name]["NT"] <= 1.0 and res[name]["CP"] >= 0.0
+    assert res["same"]["STI"] == pytest.approx(0.0, abs=1e-12) and res["same"]["CP"] == pytest.approx(0.0, abs=1e-9)
+    assert res["same"]["NT"] == 1.0                                    # identical texts tie: every pair is a success
+    assert res["flip"]["STI"] > 0.0                                     # flipping sentiment words moves probability to the target class
+    assert ev.main(["eval"]) == 2
