@@ -191,6 +191,7 @@ struct BGemmArgs {
     int splits, k_per_split;        // k_per_split multiple of 64
     int slab_only;                  // write the raw partial product(s) to the slab even when splits == 1
     float* slab;
+    int gn;                         // tile columns per XCD strip (0: the default, 8)
     int abl;                        // timing ablations (CST_GB_ABL, tools/gemm_bench.py abl): 1 no DMA, 2 no MFMA, 4 no fragment reads, 8 no write-out
 };
 
@@ -434,7 +435,10 @@ __global__ __launch_bounds__(64 * NW) void cst_gemm_bf16_kernel(BGemmArgs g) {
         const int nblk = gridDim.x, q = nblk >> 3, r = nblk & 7, xcd = blockIdx.x & 7;
         id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (blockIdx.x >> 3);
     }
-    constexpr int GN = 4;
+    // an XCD (consecutive ids) works on a strip GN tile columns wide: every A panel is then fetched by tilesN / GN XCDs instead of all
+    // eight, while the strip's B panels (GN x BN rows of K) stay in its L2.  Sweep (tools/gemm_bench.py enc, CST_GEMM_GN = 2/4/8/16): 8 is
+    // 5-10 % ahead of 4 on the long shapes (book FFN1, vocabulary projection), level on the d=768 ones; 16 overflows the L2 on the book shapes.
+    const int GN = g.gn > 0 ? g.gn : 8;
     const int grp = id / (GN * tilesM);
     const int gw = min(GN, tilesN - grp * GN);
     const int local = id - grp * GN * tilesM;
@@ -1342,6 +1346,7 @@ extern "C" int cst_gemm_bf16(const void* A, long lda, const void* B, long ldb,
     g.M = M; g.N = N; g.K = K; g.act = act; g.alpha = alpha; g.gate_scale = gate_scale; g.accumulate = accumulate;
     g.slab_only = 0;
     { const char* ab = getenv("CST_GB_ABL"); g.abl = ab ? atoi(ab) : 0; }       // bench-only timing ablations (wrong results)
+    { static const int gn_env = getenv("CST_GEMM_GN") ? atoi(getenv("CST_GEMM_GN")) : 0; g.gn = gn_env; }
     g.drop = cst_make_drop(drop_p, drop_seed, drop_stream, drop_seed_dev);
     // tile / ring / split choice (tools/gemm_bench.py bf16nt): the 2-stage ring with two workgroups per
     // CU beats the 3-stage one at these sizes; 64x128 tiles when they alone give >= 256 workgroups,
