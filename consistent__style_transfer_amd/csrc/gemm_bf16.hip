@@ -1353,7 +1353,9 @@ extern "C" int cst_gemm_bf16(const void* A, long lda, const void* B, long ldb,
     // 128x128 + split-K for long-K products with few output tiles (wgrad), 64x128 (+split) otherwise.
     int ring = tile & 3;                         // tile code + 1 / + 2: force the 3- / 4-stage ring
     tile &= ~3;
-    static const bool w8_auto = getenv("CST_GEMM_W8") != nullptr;        // A/B switch: 128 x 128 tiles on 8 waves wherever 128 x 128 is chosen
+    // 128 x 128 tiles run on 8 waves (sixteen DMA-issuing waves per CU) unless the 4-wave form is asked for: 0.15 ms per step at the
+    // headline workload (25.48 against 25.63 ms, two A/B pairs in one session); CST_GEMM_W4 = 1 keeps the A/B switch
+    static const bool w8_auto = getenv("CST_GEMM_W4") == nullptr;
     bool w8 = tile == 136;                       // 136: 128 x 128 tile on 8 waves
     if (w8) tile = 128;
     int use_big, splits;
