@@ -376,7 +376,7 @@ static int mha_fwd_any(const void* qkv, int qkv_bf16, float* out, float* lse, in
     CST_REQUIRE(qkv && lse, "cst_mha_fwd: null pointer");
     CST_REQUIRE(B > 0 && S > 0 && S <= MHA_SMAX_LONG && H > 0, "cst_mha_fwd: S=%d unsupported (max %d)", S, MHA_SMAX_LONG);
     CST_REQUIRE(((uintptr_t)qkv & 15) == 0 && hd % 4 == 0, "cst_mha_fwd: qkv must be 16-byte aligned, hd a multiple of 4");
-    CstDrop dr = cst_make_drop(drop_p, drop_seed, drop_stream, drop_seed_dev);
+    CstDrop dr = cst_make_drop(drop_p, drop_seed, drop_stream, drop_seed_dev, (long)B * H * S * S);
     const float scale = 1.0f / sqrtf((float)hd);
     if (S > MHA_SMAX) {
         const int rc = cst_mha_fwd_long((const float*)qkv, out, lse, B, S, H, hd, scale, dr, out_bf16, ldob, (hipStream_t)stream);
@@ -853,7 +853,7 @@ static int mha_bwd_any(const void* qkv, const void* dout, int io_bf16, const flo
     CST_REQUIRE(qkv && dout && lse, "cst_mha_bwd: null pointer");
     CST_REQUIRE(B > 0 && S > 0 && S <= MHA_SMAX_LONG && H > 0, "cst_mha_bwd: S=%d unsupported (max %d)", S, MHA_SMAX_LONG);
     CST_REQUIRE((((uintptr_t)qkv | (uintptr_t)dout) & 15) == 0 && hd % 4 == 0, "cst_mha_bwd: qkv / dout must be 16-byte aligned, hd a multiple of 4");
-    CstDrop dr = cst_make_drop(drop_p, drop_seed, drop_stream, drop_seed_dev);
+    CstDrop dr = cst_make_drop(drop_p, drop_seed, drop_stream, drop_seed_dev, (long)B * H * S * S);
     const float scale = 1.0f / sqrtf((float)hd);
     if (S > MHA_SMAX) {
         const int rc = cst_mha_bwd_long((const float*)qkv, (const float*)dout, lse, dqkv, B, S, H, hd, scale, dr, dqkv_bf16, lddb, (hipStream_t)stream);
@@ -1011,7 +1011,7 @@ extern "C" int cst_dot_attn_fwd(const float* q, long ldq, const float* mem, floa
     CST_REQUIRE(B > 0 && L > 0 && L <= MHA_SMAX && D > 0 && D % 4 == 0, "cst_dot_attn_fwd: L=%d (max %d) or D=%d unsupported", L, MHA_SMAX, D);
     const size_t lds = sizeof(float) * ((size_t)L * D + D + 64);
     CST_REQUIRE(lds <= 160 * 1024, "cst_dot_attn_fwd: memory tile of %zu bytes exceeds the 160 KiB LDS", lds);
-    CstDrop dr = cst_make_drop(drop_p, drop_seed, drop_stream, drop_seed_dev);
+    CstDrop dr = cst_make_drop(drop_p, drop_seed, drop_stream, drop_seed_dev, (long)B * 2 * D);
     if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)dot_attn_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(dot_attn_fwd_kernel, dim3(B), dim3(B <= 1024 ? 1024 : 256), lds, (hipStream_t)stream, q, ldq, mem, out, ldo, p, L, D,
                        1.0f / sqrtf((float)D), dropped, lddrop, (unsigned short*)dropped_bf16, lddropb, dr);
@@ -1114,7 +1114,7 @@ __global__ __launch_bounds__(1024) void dot_attn_bwd_steps_kernel(float* __restr
         if (tid < 2 * D) {
             float gd = graw;
             if (drop.p > 0.f)
-                gd *= ((cst_mix32(dseed, drop.stream + (uint32_t)s, (uint32_t)((long)b * 2 * D + tid)) >> 8) >= drop.thresh) ? drop.scale : 0.0f;
+                gd *= ((cst_mix32(dseed, drop.stream + (uint32_t)s, (uint32_t)((long)b * 2 * D + tid) + drop.base) >> 8) >= drop.thresh) ? drop.scale : 0.0f;
             if (tid >= D) gs[tid - D] = gd; else gh = gd;
         }
         if (tid < D) qs[tid] = qv;
@@ -1163,7 +1163,7 @@ extern "C" int cst_dot_attn_bwd_steps(float* diffn, long ldrow, long gstep, cons
     const size_t lds = sizeof(float) * ((size_t)2 * L * D + 2 * D + 128);
     CST_REQUIRE(lds <= 160 * 1024, "cst_dot_attn_bwd_steps: tiles of %zu bytes exceed the 160 KiB LDS", lds);
     if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)dot_attn_bwd_steps_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    CstDrop dr = cst_make_drop(drop_p, drop_seed, drop_stream, drop_seed_dev);
+    CstDrop dr = cst_make_drop(drop_p, drop_seed, drop_stream, drop_seed_dev, (long)B * 2 * D);
     hipLaunchKernelGGL(dot_attn_bwd_steps_kernel, dim3(B), dim3(1024), lds, (hipStream_t)stream, diffn, ldrow, gstep, q, ldq, qstep, mem, p,
                        dmem, B, T, L, D, 1.0f / sqrtf((float)D), dr);
     CST_LAUNCH_CHECK("cst_dot_attn_bwd_steps");

@@ -15,3 +15,12 @@ void cst_set_error(const char* fmt, ...) {
 extern "C" const char* cst_last_error() { return g_err; }
 
 extern "C" int cst_abi_version() { return 1; }
+
+// Data-parallel rank of this process for the dropout index contract (cst_common.h, CstDrop::base).  One process per GPU.
+static uint32_t g_drop_shard_rank = 0;
+uint32_t cst_drop_shard_rank() { return g_drop_shard_rank; }
+extern "C" int cst_set_drop_shard(int rank) {
+    CST_REQUIRE(rank >= 0, "cst_set_drop_shard: rank=%d must be >= 0", rank);
+    g_drop_shard_rank = (uint32_t)rank;
+    return CST_OK;
+}

@@ -56,9 +56,16 @@ struct CstDrop {          // p == 0 -> disabled
     uint32_t seed;        // host part of the seed
     uint32_t stream;      // call-site id
     const uint32_t* seed_dev;   // optional device word added to seed (graph replay)
+    uint32_t base;        // added to every element index: (data-parallel rank) x (elements of this rank's mask tensor), see cst_set_drop_shard
 };
 
-static inline CstDrop cst_make_drop(float p, uint32_t seed, uint32_t stream, const void* seed_dev) {
+// Data-parallel dropout contract: every mask tensor is batch-major, so element (global batch row, ...) of the one-process global
+// batch has linear index rank * numel_local + local index on the rank that holds the row.  With the rank registered through
+// cst_set_drop_shard() a shard draws exactly the masks the one-process run draws for its rows.  0 (default) = unsharded.
+uint32_t cst_drop_shard_rank();
+
+// numel = number of elements of the (local) tensor the mask applies to = the extent of the kernel's index space
+static inline CstDrop cst_make_drop(float p, uint32_t seed, uint32_t stream, const void* seed_dev, long numel) {
     CstDrop d;
     d.p = p;
     d.scale = p > 0.f ? 1.0f / (1.0f - p) : 1.0f;
@@ -66,6 +73,7 @@ static inline CstDrop cst_make_drop(float p, uint32_t seed, uint32_t stream, con
     d.seed = seed;
     d.stream = stream;
     d.seed_dev = (const uint32_t*)seed_dev;
+    d.base = p > 0.f ? cst_drop_shard_rank() * (uint32_t)numel : 0u;
     return d;
 }
 
@@ -74,7 +82,7 @@ __device__ __forceinline__ uint32_t cst_drop_seed(const CstDrop& d) {
 }
 
 __device__ __forceinline__ float cst_drop_mask(const CstDrop& d, uint32_t seed, uint32_t idx) {
-    return ((cst_mix32(seed, d.stream, idx) >> 8) >= d.thresh) ? d.scale : 0.0f;
+    return ((cst_mix32(seed, d.stream, idx + d.base) >> 8) >= d.thresh) ? d.scale : 0.0f;
 }
 
 // ---- wave / block reductions -----------------------------------------------------------------

@@ -534,10 +534,17 @@ static int vec_ok(const float* p, long ld, long stride) {
 // the 256 CUs on their own; with a long K and a handful of big tiles, big tiles + split-K; otherwise 64x64 tiles, split along K when
 // even those are few.  Partial slabs are summed in slice order by cst_gemm_splitk_reduce.  The split count shrinks to what fits
 // `ws_floats`.
+//
+// Exact mode (precision_f32): an output element is a k-ordered fma chain per K slice plus the slices in order, so its bits depend on
+// the split count and on nothing else.  north_star asks for bit-exact greedy ids, also when the batch is sharded over data-parallel
+// ranks: the split count of the exact mode is therefore chosen from (N, K, batch) for a NOMINAL 256-row product, never from M, and a
+// product whose slabs do not fit the workspace is cut into row blocks (cst_gemm) instead of getting fewer, M-dependent slices.
+constexpr int GEMM_EXACT_NOMINAL_M = 256;
 static void gemm_plan(int M, int N, int K, int batch, int precision_f32, int tile, int splitk, bool has_ws, long ws_floats,
-                      int* use_big_out, int* splits_out, int* kps_out) {
-    const long big = (long)cst_div_up(M, 128) * cst_div_up(N, 128) * batch;
-    const long small = (long)cst_div_up(M, 64) * cst_div_up(N, 64) * batch;
+                      int* use_big_out, int* splits_out, int* kps_out, bool fit_rows = false) {
+    const int Mp = precision_f32 ? GEMM_EXACT_NOMINAL_M : M;
+    const long big = (long)cst_div_up(Mp, 128) * cst_div_up(N, 128) * batch;
+    const long small = (long)cst_div_up(Mp, 64) * cst_div_up(N, 64) * batch;
     int use_big, splits = 1;
     tile &= ~1;
     if (tile == 128 || (tile == 0 && big >= 192)) { use_big = 1; }
@@ -554,12 +561,14 @@ static void gemm_plan(int M, int N, int K, int batch, int precision_f32, int til
     }
     if (splitk > 1) splits = splitk;
     if (splitk == 1) splits = 1;
+    // the TILE may follow the real row count (it does not enter the summation order): big tiles once they fill the chip
+    if (precision_f32 && (tile & ~1) == 0 && (long)cst_div_up(M, 128) * cst_div_up(N, 128) * batch >= 192) use_big = 1;
     int kps = cst_div_up(K, 64) * 64;
     if (splits > 1) {
         const int bk = precision_f32 ? 32 : 64;
         kps = cst_div_up(cst_div_up(K, splits), bk) * bk;
         splits = cst_div_up(K, kps);
-        while (splits > 1 && (long)batch * splits * M * N > ws_floats) {
+        while (!fit_rows && splits > 1 && (long)batch * splits * M * N > ws_floats) {
             kps += bk;
             splits = cst_div_up(K, kps);
         }
@@ -599,30 +608,46 @@ extern "C" int cst_gemm(const float* A, long lda, int a_kmajor, const float* B, 
     g.M = M; g.N = N; g.K = K; g.act = act; g.accumulate = accumulate;
     g.vecA = vec_ok(A, lda, sA); g.vecB = vec_ok(B, ldb, sB);
     g.alpha = alpha; g.gate_scale = gate_scale;
-    g.drop = cst_make_drop(drop_p, drop_seed, drop_stream, drop_seed_dev);
+    g.drop = cst_make_drop(drop_p, drop_seed, drop_stream, drop_seed_dev, (long)batch * M * N);
     // tile / split choice.  128x128 tiles when they fill the 256 CUs on their own; with a long K
     // and a handful of big tiles, big tiles + split-K; otherwise 64x64 tiles, split along K when
     // even those are few.  Partial slabs are summed in slice order by cst_gemm_splitk_reduce.
     const int w8 = tile & 1;                    // odd tile code 129 forces the 8-wave build, 128 the 4-wave one
     const int forced = tile != 0;
     int use_big, splits;
-    gemm_plan(M, N, K, batch, precision_f32, tile, splitk, workspace != nullptr, workspace_floats, &use_big, &splits, &g.k_per_split);
+    // exact mode, one problem, no dropout (its index is the row number inside the launch): row blocks instead of fewer K slices
+    const bool fit_rows = precision_f32 && batch == 1 && drop_p <= 0.f;
+    gemm_plan(M, N, K, batch, precision_f32, tile, splitk, workspace != nullptr, workspace_floats, &use_big, &splits, &g.k_per_split, fit_rows);
     CST_REQUIRE(splits == 1 || workspace, "cst_gemm: split-K needs a workspace");
     g.splits = splits;
     g.slab = workspace;
     hipStream_t st = (hipStream_t)stream;
     const int pf = precision_f32 ? 1 : 0, ak = a_kmajor ? 1 : 0, bk_ = b_kmajor ? 1 : 0;
-    // measured (tools/gemm_bench.py): two K-major operands run best with 4 waves per workgroup, any
-    // MN-major operand (dgrad / wgrad: many scalar staging loads) with 8
-    if (use_big && (forced ? w8 : !(ak && bk_))) launch_cfg<128, 128, 8>(g, pf, ak, bk_, batch, st);
-    else if (use_big) launch_cfg<128, 128, 4>(g, pf, ak, bk_, batch, st);
-    else launch_cfg<64, 64, 4>(g, pf, ak, bk_, batch, st);
-    CST_LAUNCH_CHECK("cst_gemm");
-    if (splits > 1) {
-        long mn = (long)M * N;
-        int rb = (int)((mn + 255) / 256); if (rb > 2048) rb = 2048;
-        hipLaunchKernelGGL(cst_gemm_splitk_reduce, dim3(rb, 1, batch), dim3(256), 0, st, g);
-        CST_LAUNCH_CHECK("cst_gemm_splitk_reduce");
+    int rows_per_launch = M;
+    if (splits > 1 && (long)batch * splits * M * N > workspace_floats) {          // only reachable with fit_rows
+        rows_per_launch = (int)(workspace_floats / ((long)splits * N)) / 128 * 128;
+        CST_REQUIRE(rows_per_launch >= 128, "cst_gemm: workspace of %ld floats cannot hold %d K slices of a 128-row block (N=%d)", workspace_floats, splits, N);
+    }
+    for (int m0 = 0; m0 < M; m0 += rows_per_launch) {
+        GemmArgs h = g;
+        h.M = M - m0 < rows_per_launch ? M - m0 : rows_per_launch;
+        h.A = A + (a_kmajor ? (long)m0 * lda : (long)m0);
+        h.C = C + (long)m0 * ldc;
+        if (addend) h.addend = addend + (long)m0 * ldadd;
+        if (aux) h.aux = aux + (long)m0 * ldaux;
+        h.vecA = vec_ok(h.A, lda, sA);
+        // measured (tools/gemm_bench.py): two K-major operands run best with 4 waves per workgroup, any
+        // MN-major operand (dgrad / wgrad: many scalar staging loads) with 8
+        if (use_big && (forced ? w8 : !(ak && bk_))) launch_cfg<128, 128, 8>(h, pf, ak, bk_, batch, st);
+        else if (use_big) launch_cfg<128, 128, 4>(h, pf, ak, bk_, batch, st);
+        else launch_cfg<64, 64, 4>(h, pf, ak, bk_, batch, st);
+        CST_LAUNCH_CHECK("cst_gemm");
+        if (splits > 1) {
+            long mn = (long)h.M * N;
+            int rb = (int)((mn + 255) / 256); if (rb > 2048) rb = 2048;
+            hipLaunchKernelGGL(cst_gemm_splitk_reduce, dim3(rb, 1, batch), dim3(256), 0, st, h);
+            CST_LAUNCH_CHECK("cst_gemm_splitk_reduce");
+        }
     }
     return CST_OK;
 }

@@ -123,7 +123,7 @@ extern "C" int cst_cast_bf16(const void* x, int x_is_bf16, long ldx, int R, int 
     CST_REQUIRE(!out_t || ldot >= R, "cst_cast_bf16: ldot < R");
     // padded extents: every column of `out` up to ldo and every column of `out_t` up to ldot is written
     const int Cp = out ? (int)ldo : C, Rp = out_t ? (int)ldot : R;
-    CstDrop dr = cst_make_drop(drop_p, drop_seed, drop_stream, drop_seed_dev);
+    CstDrop dr = cst_make_drop(drop_p, drop_seed, drop_stream, drop_seed_dev, (long)R * C);
     dim3 grid(cst_div_up(Cp > C ? Cp : C, 64), cst_div_up(Rp > R ? Rp : R, 64)), block(256);
     hipStream_t st = (hipStream_t)stream;
     const bool vec = !x_is_bf16 && drop_p <= 0.f && C % 4 == 0 && ldx % 4 == 0 && (((uintptr_t)x) & 15) == 0 &&
@@ -1347,7 +1347,7 @@ extern "C" int cst_gemm_bf16(const void* A, long lda, const void* B, long ldb,
     g.slab_only = 0;
     { const char* ab = getenv("CST_GB_ABL"); g.abl = ab ? atoi(ab) : 0; }       // bench-only timing ablations (wrong results)
     { static const int gn_env = getenv("CST_GEMM_GN") ? atoi(getenv("CST_GEMM_GN")) : 0; g.gn = gn_env; }
-    g.drop = cst_make_drop(drop_p, drop_seed, drop_stream, drop_seed_dev);
+    g.drop = cst_make_drop(drop_p, drop_seed, drop_stream, drop_seed_dev, (long)M * N);
     // tile / ring / split choice (tools/gemm_bench.py bf16nt): the 2-stage ring with two workgroups per
     // CU beats the 3-stage one at these sizes; 64x128 tiles when they alone give >= 256 workgroups,
     // 128x128 + split-K for long-K products with few output tiles (wgrad), 64x128 (+split) otherwise.
@@ -1416,7 +1416,7 @@ extern "C" int cst_gemm_bf16_tt(const void* A, long lda, const void* B, long ldb
     g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.ldcb = 0; g.ldadd = 0; g.ldaux = 0;
     g.M = M; g.N = N; g.K = K; g.act = 0; g.alpha = 1.f; g.gate_scale = 1.f; g.accumulate = accumulate;
     g.slab_only = 0;
-    g.drop = cst_make_drop(0.f, 0, 0, nullptr);
+    g.drop = cst_make_drop(0.f, 0, 0, nullptr, 0);
     int splits, kps;
     bgemm_tt_plan(M, N, K, splitk, workspace != nullptr, workspace_floats, &splits, &kps);
     CST_REQUIRE(splits == 1 || workspace, "cst_gemm_bf16_tt: split-K needs a workspace");
@@ -1494,7 +1494,7 @@ extern "C" int cst_gemm_bf16_w8(const void* A, long lda, const void* Bq, long ld
     g.bias = bias; g.addend = addend; g.aux = (const bf16_t*)aux; g.bscale = bscale;
     g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.ldcb = ldcb; g.ldadd = ldadd; g.ldaux = ldaux;
     g.M = M; g.N = N; g.K = K; g.act = act; g.alpha = alpha; g.gate_scale = gate_scale; g.accumulate = accumulate;
-    g.drop = cst_make_drop(drop_p, drop_seed, drop_stream, drop_seed_dev);
+    g.drop = cst_make_drop(drop_p, drop_seed, drop_stream, drop_seed_dev, (long)M * N);
     int use_big_unused, splits;
     bgemm_plan(M, N, K, 64, splitk, workspace != nullptr, workspace_floats, &use_big_unused, &splits, &g.k_per_split);       // 64 x 128 tiles only
     CST_REQUIRE(splits == 1 || workspace, "cst_gemm_bf16_w8: split-K needs a workspace");
@@ -1600,7 +1600,7 @@ static int lstm_gemm_front(const char* who, BGemmArgs& g, const void* A, const v
     g.C = nullptr; g.Cb = nullptr; g.bias = nullptr; g.addend = nullptr; g.aux = nullptr;
     g.lda = lda; g.ldb = ldb; g.ldc = 0; g.ldcb = 0; g.ldadd = 0; g.ldaux = 0;
     g.M = M; g.N = N; g.K = K; g.act = 0; g.alpha = 1.f; g.gate_scale = 1.f; g.accumulate = 0;
-    g.drop = cst_make_drop(0.f, 0, 0, nullptr);
+    g.drop = cst_make_drop(0.f, 0, 0, nullptr, 0);
     g.slab_only = 1;
     const int np = A2 ? 2 : 1;
     int splits, kps;
@@ -1866,7 +1866,7 @@ extern "C" int cst_gemm_bf16_lstm_attn(const void* A, long lda, const void* B, l
     q.h_out = h_out; q.ldh = ldh; q.c_out = c_out; q.ldc = ldc; q.h_out2 = h_out2; q.ldh2 = ldh2; q.hb2 = (bf16_t*)h_bf16_2; q.ldhb2 = ldhb2;
     q.mem = mem; q.att = att_out; q.ldo = ldo; q.p = p; q.L = L; q.scale = 1.0f / sqrtf((float)H);
     q.dropped = dropped; q.lddrop = lddrop; q.dropped_b = (bf16_t*)dropped_bf16; q.lddropb = lddropb;
-    q.drop = cst_make_drop(drop_p, drop_seed, drop_stream, drop_seed_dev);
+    q.drop = cst_make_drop(drop_p, drop_seed, drop_stream, drop_seed_dev, (long)M * 2 * H);
     if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)cst_gemm_bf16_lstm_attn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(cst_gemm_bf16_lstm_attn_kernel, dim3(M), dim3(1024), lds, st, q);
     CST_LAUNCH_CHECK("cst_gemm_bf16_lstm_attn_kernel");

@@ -121,7 +121,7 @@ extern "C" int cst_embed_gather(const int64_t* ids_a, const int64_t* ids_b, long
                                 void* out_bf16, long ldob, int R, int E, int V,
                                 float drop_p, uint32_t drop_seed, uint32_t drop_stream, const void* drop_seed_dev, void* stream) {
     CST_REQUIRE((ids_a || ids_b) && table && out && R > 0 && E > 0, "cst_embed_gather: bad arguments");
-    CstDrop dr = cst_make_drop(drop_p, drop_seed, drop_stream, drop_seed_dev);
+    CstDrop dr = cst_make_drop(drop_p, drop_seed, drop_stream, drop_seed_dev, (long)R * E);
     hipLaunchKernelGGL(embed_gather_kernel, ew_grid((long)R * E), dim3(EW_THREADS), 0, (hipStream_t)stream,
                        ids_a, ids_b, ldb, coin_dev, table, ldt, transposed, out, ldo, (bf16_t*)out_bf16, ldob, R, E, V, dr);
     CST_LAUNCH_CHECK("cst_embed_gather");
@@ -147,7 +147,7 @@ extern "C" int cst_embed_scatter_add(const int64_t* ids_a, const int64_t* ids_b,
                                      const float* dout, long ldo, float* dtable, long ldt, int transposed, int R, int E, int V,
                                      float drop_p, uint32_t drop_seed, uint32_t drop_stream, const void* drop_seed_dev, void* stream) {
     CST_REQUIRE((ids_a || ids_b) && dout && dtable && R > 0 && E > 0, "cst_embed_scatter_add: bad arguments");
-    CstDrop dr = cst_make_drop(drop_p, drop_seed, drop_stream, drop_seed_dev);
+    CstDrop dr = cst_make_drop(drop_p, drop_seed, drop_stream, drop_seed_dev, (long)R * E);
     hipLaunchKernelGGL(embed_scatter_add_kernel, ew_grid((long)R * E), dim3(EW_THREADS), 0, (hipStream_t)stream,
                        ids_a, ids_b, ldb, coin_dev, dout, ldo, dtable, ldt, transposed, R, E, V, dr);
     CST_LAUNCH_CHECK("cst_embed_scatter_add");
@@ -171,7 +171,7 @@ __global__ void embed_scatter_steps_kernel(const int64_t* __restrict__ ids_a, co
         if (id < 0 || id >= V) continue;
         float g = dout[(long)r * ldo + c];
         if (drop.p > 0.f)
-            g *= ((cst_mix32(dseed, drop.stream + (uint32_t)s, (uint32_t)(b * E + c)) >> 8) >= drop.thresh) ? drop.scale : 0.0f;
+            g *= ((cst_mix32(dseed, drop.stream + (uint32_t)s, (uint32_t)(b * E + c) + drop.base) >> 8) >= drop.thresh) ? drop.scale : 0.0f;
         atomicAdd(&dtable[id * ldt + c], g);
     }
 }
@@ -181,7 +181,7 @@ extern "C" int cst_embed_scatter_add_steps(const int64_t* ids_a, const int64_t* 
                                            float drop_p, uint32_t drop_seed, uint32_t drop_stream, const void* drop_seed_dev, void* stream) {
     CST_REQUIRE(ids_a && dout && dtable && S > 0 && B > 0 && E > 0 && ldo >= E && ldt >= E, "cst_embed_scatter_add_steps: bad arguments");
     CST_REQUIRE((long)S * B * E < (1L << 31), "cst_embed_scatter_add_steps: S*B*E too large");
-    CstDrop dr = cst_make_drop(drop_p, drop_seed, drop_stream, drop_seed_dev);
+    CstDrop dr = cst_make_drop(drop_p, drop_seed, drop_stream, drop_seed_dev, (long)B * E);
     hipLaunchKernelGGL(embed_scatter_steps_kernel, ew_grid((long)S * B * E), dim3(EW_THREADS), 0, (hipStream_t)stream,
                        ids_a, ids_b, ldb, coins_dev, dout, ldo, dtable, ldt, S, B, E, V, dr);
     CST_LAUNCH_CHECK("cst_embed_scatter_add_steps");
@@ -378,7 +378,7 @@ __global__ void dropout_kernel(const float* __restrict__ x, long ldx, float* __r
 extern "C" int cst_dropout(const float* x, long ldx, float* out, long ldo, int R, int C,
                            float drop_p, uint32_t drop_seed, uint32_t drop_stream, const void* drop_seed_dev, void* stream) {
     CST_REQUIRE(x && out && R > 0 && C > 0, "cst_dropout: bad arguments");
-    CstDrop dr = cst_make_drop(drop_p, drop_seed, drop_stream, drop_seed_dev);
+    CstDrop dr = cst_make_drop(drop_p, drop_seed, drop_stream, drop_seed_dev, (long)R * C);
     hipLaunchKernelGGL(dropout_kernel, ew_grid((long)R * C), dim3(EW_THREADS), 0, (hipStream_t)stream, x, ldx, out, ldo, R, C, dr);
     CST_LAUNCH_CHECK("cst_dropout");
     return CST_OK;

@@ -299,11 +299,11 @@ __global__ __launch_bounds__(ROW_THREADS) void softmax_tau_generic_kernel(const 
 
 static GatherTail make_tail(const float* table, long ldt, int E, float* out, long ldo, void* out_bf16, long ldob,
                             const int64_t* ids_b, long ldb, const int* coin_dev, int V,
-                            float drop_p, uint32_t drop_seed, uint32_t drop_stream, const void* drop_seed_dev) {
+                            float drop_p, uint32_t drop_seed, uint32_t drop_stream, const void* drop_seed_dev, int R) {
     GatherTail t;
     t.table = table; t.ldt = ldt; t.out = out; t.ldo = ldo; t.outb = (unsigned short*)out_bf16; t.ldob = ldob;
     t.ids_b = ids_b; t.ldb = ldb; t.coin = coin_dev; t.E = E; t.V = V;
-    t.drop = cst_make_drop(drop_p, drop_seed, drop_stream, drop_seed_dev);
+    t.drop = cst_make_drop(drop_p, drop_seed, drop_stream, drop_seed_dev, (long)R * E);      // mask index space: the gathered (R, E) rows
     t.pb = nullptr; t.ldpb = 0; t.wpb = 0;
     return t;
 }
@@ -333,7 +333,7 @@ static int softmax_tau_launch(const float* logits, long ld, float inv_tau, float
 
 extern "C" int cst_softmax_tau(const float* logits, long ld, float inv_tau, float* p, long ldp,
                                int64_t* argmax_out, int R, int V, void* stream) {
-    GatherTail none = make_tail(nullptr, 0, 0, nullptr, 0, nullptr, 0, nullptr, 0, nullptr, 0, 0.f, 0, 0, nullptr);
+    GatherTail none = make_tail(nullptr, 0, 0, nullptr, 0, nullptr, 0, nullptr, 0, nullptr, 0, 0.f, 0, 0, nullptr, 0);
     return softmax_tau_launch(logits, ld, inv_tau, p, ldp, argmax_out, R, V, none, stream);
 }
 
@@ -344,7 +344,7 @@ extern "C" int cst_softmax_tau_gather(const float* logits, long ld, float inv_ta
                                       float drop_p, uint32_t drop_seed, uint32_t drop_stream, const void* drop_seed_dev,
                                       void* stream) {
     CST_REQUIRE(table && out && E > 0 && ldt >= E && ldo >= E, "cst_softmax_tau_gather: bad gather arguments");
-    GatherTail t = make_tail(table, ldt, E, out, ldo, out_bf16, ldob, ids_b, ldb, coin_dev, V, drop_p, drop_seed, drop_stream, drop_seed_dev);
+    GatherTail t = make_tail(table, ldt, E, out, ldo, out_bf16, ldob, ids_b, ldb, coin_dev, V, drop_p, drop_seed, drop_stream, drop_seed_dev, R);
     return softmax_tau_launch(logits, ld, inv_tau, p, ldp, argmax_out, R, V, t, stream);
 }
 
@@ -356,7 +356,7 @@ extern "C" int cst_softmax_tau_gather_b(const float* logits, long ld, float inv_
                                         void* stream) {
     CST_REQUIRE(p_bf16, "cst_softmax_tau_gather_b: null bf16 output");
     CST_REQUIRE(!table || (out && E > 0 && ldt >= E && ldo >= E), "cst_softmax_tau_gather_b: bad gather arguments");
-    GatherTail t = make_tail(table, ldt, E, out, ldo, out_bf16, ldob, ids_b, ldb, coin_dev, V, drop_p, drop_seed, drop_stream, drop_seed_dev);
+    GatherTail t = make_tail(table, ldt, E, out, ldo, out_bf16, ldob, ids_b, ldb, coin_dev, V, drop_p, drop_seed, drop_stream, drop_seed_dev, R);
     t.pb = (unsigned short*)p_bf16; t.ldpb = ldpb; t.wpb = wpb;
     return softmax_tau_launch(logits, ld, inv_tau, p, ldp, argmax_out, R, V, t, stream);
 }
@@ -468,7 +468,7 @@ static int argmax_launch(const float* x, long ld, int R, int V, int64_t* out, co
 }
 
 extern "C" int cst_argmax_rows(const float* x, long ld, int R, int V, int64_t* out, void* stream) {
-    GatherTail none = make_tail(nullptr, 0, 0, nullptr, 0, nullptr, 0, nullptr, 0, nullptr, 0, 0.f, 0, 0, nullptr);
+    GatherTail none = make_tail(nullptr, 0, 0, nullptr, 0, nullptr, 0, nullptr, 0, nullptr, 0, 0.f, 0, 0, nullptr, 0);
     return argmax_launch(x, ld, R, V, out, none, stream);
 }
 
@@ -478,7 +478,7 @@ extern "C" int cst_argmax_rows_gather(const float* x, long ld, int R, int V, int
                                       float drop_p, uint32_t drop_seed, uint32_t drop_stream, const void* drop_seed_dev,
                                       void* stream) {
     CST_REQUIRE(table && gout && E > 0 && ldt >= E && ldo >= E, "cst_argmax_rows_gather: bad gather arguments");
-    GatherTail t = make_tail(table, ldt, E, gout, ldo, out_bf16, ldob, ids_b, ldb, coin_dev, V, drop_p, drop_seed, drop_stream, drop_seed_dev);
+    GatherTail t = make_tail(table, ldt, E, gout, ldo, out_bf16, ldob, ids_b, ldb, coin_dev, V, drop_p, drop_seed, drop_stream, drop_seed_dev, R);
     return argmax_launch(x, ld, R, V, out, t, stream);
 }
 
@@ -609,7 +609,7 @@ extern "C" int cst_add_layernorm_fwd_b(const float* x, const float* res, const f
     CST_REQUIRE(x && gamma && beta && y && mean && rstd, "cst_add_layernorm_fwd: null pointer");
     CST_REQUIRE(T > 0 && d > 0 && d <= 64 * LN_MAXE, "cst_add_layernorm_fwd: d=%d unsupported (max %d)", d, 64 * LN_MAXE);
     CST_REQUIRE(!y_bf16 || ldyb >= d, "cst_add_layernorm_fwd: bf16 leading dimension < d");
-    CstDrop dr = cst_make_drop(drop_p, drop_seed, drop_stream, drop_seed_dev);
+    CstDrop dr = cst_make_drop(drop_p, drop_seed, drop_stream, drop_seed_dev, (long)T * d);
     const uintptr_t al = (uintptr_t)x | (uintptr_t)res | (uintptr_t)gamma | (uintptr_t)beta | (uintptr_t)z | (uintptr_t)y;
     if (d % 256 == 0 && d <= 1024 && (al & 15) == 0 && (!y_bf16 || (ldyb % 4 == 0 && (((uintptr_t)y_bf16) & 7) == 0))) {
 #define LN_FWD_V(NV) hipLaunchKernelGGL(add_layernorm_fwd_vec_kernel<NV>, dim3(cst_div_up(T, 4)), dim3(256), 0, (hipStream_t)stream, \
@@ -880,7 +880,7 @@ extern "C" int cst_layernorm_bwd_b(const float* dy, const float* z, const float*
     CST_REQUIRE(workspace_floats >= need, "cst_layernorm_bwd: workspace too small (%ld < %ld)", workspace_floats, need);
     const int rpb = cst_div_up(T, nblk);
     hipStream_t st = (hipStream_t)stream;
-    CstDrop bd = cst_make_drop(drop_p, drop_seed, drop_stream, drop_seed_dev);
+    CstDrop bd = cst_make_drop(drop_p, drop_seed, drop_stream, drop_seed_dev, (long)T * d);
     const uintptr_t al = (uintptr_t)dy | (uintptr_t)z | (uintptr_t)gamma | (uintptr_t)dz;
     const bool vec = d % 256 == 0 && d <= 1024 && (al & 15) == 0 && (!dz_bf16 || (lddzb % 4 == 0 && (((uintptr_t)dz_bf16) & 7) == 0));
 #define LN_BWD_V(NV) hipLaunchKernelGGL(layernorm_bwd_vec_kernel<NV>, dim3(nblk), dim3(256), 0, st, dy, z, mean, rstd, gamma, dz, workspace, T, rpb, \

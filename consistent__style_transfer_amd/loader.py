@@ -195,6 +195,12 @@ class PretrainCollate:
         self.vocab, self.label_fn, self.label_cache = vocab, label_fn, label_cache
         self.position = (0, 0)
 
+    def without_cache(self):
+        """The collate for anything that is NOT the seeded training stream the cache was made for (validation: Trainer.fit).  The cache
+        is keyed by (epoch, batch index) of the TRAINING sampler only; read through it, validation batch i would silently get the
+        labels of training batch i of epoch 0 (same row count), and those targets decide best_eval, the freeze flags and mat.pth."""
+        return PretrainCollate(self.vocab, self.label_fn, None) if self.label_cache is not None else self
+
     def __call__(self, batch_samples):
         sentences, labels = zip(*batch_samples)
         noised_1 = transfer_noise(sentences, p=0.15)
@@ -235,8 +241,11 @@ def collate_optimize(batch_samples):
 
 
 class GlobalBatchSampler:
-    """Index batches of the GLOBAL batch size, identical on every rank (seeded by epoch), dropping
-    nothing: the last batch may be short, and is trimmed to a multiple of `world` rows."""
+    """Index batches of the GLOBAL batch size, identical on every rank (seeded by epoch).  The last batch may be short; under data
+    parallelism (world > 1) it is TRIMMED to a multiple of `world` rows so that every rank gets the same number of rows (every loss
+    is a batch mean over equal shards): up to world - 1 sentences of the LAST batch of an epoch are not trained on in that epoch
+    (at most 7 of ~444 000 at 8 ranks; with shuffle they are different sentences every epoch).  The transfer writer
+    (main_optimize --mode test) does not use this trimming: it pads the last shard instead and drops nothing."""
 
     def __init__(self, n, global_batch, shuffle, seed=0, world=1):
         self.n, self.bs, self.shuffle, self.seed, self.world = n, global_batch, shuffle, seed, world

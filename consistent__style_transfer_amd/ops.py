@@ -189,13 +189,21 @@ def _workspace(dev):
     return ws
 
 
+# Products this small (2 M N K) run on the exact fp32 matrix pipe in EVERY precision mode: the output heads next to the losses (Matcher
+# hidden2logits 768 -> 1, TextCNN out 384 -> 2, RelGAN_D out2logits 100 -> 1 and their gradients).  A launch of this size is latency
+# (~3 us) whatever pipe it uses, and rounding a head's 768-term input to bf16 is what the `CP` column of the optimize curve (the mean
+# Matcher logit) saw first.  CST_EXACT_SMALL_MFLOP=0 restores bf16 operands for them (A/B switch of the parity probe).
+EXACT_SMALL_FLOP = float(os.environ.get("CST_EXACT_SMALL_MFLOP", "8")) * 1e6
+
+
 def gemm(A, a_kmajor, B, b_kmajor, C, M, N, K, bias=None, addend=None, aux=None, act=0, gate_scale=1.0,
          accumulate=False, alpha=1.0, drop=NO_DROP, tile=0, splitk=0):
     """C[M,N] = epi(alpha * op(A) op(B)); A, B, C, addend, aux are row-major 2-D views."""
     ws = _workspace(C.device)
+    exact = _STATE["f32"] or 2.0 * M * N * K <= EXACT_SMALL_FLOP
     call("cst_gemm", _f32(A), _ld(A), int(a_kmajor), _f32(B), _ld(B), int(b_kmajor), _f32(C), _ld(C), M, N, K,
          bias, addend, _ld(addend) if addend is not None else 0, aux, _ld(aux) if aux is not None else 0,
-         act, float(gate_scale), int(accumulate), float(alpha), int(_STATE["f32"]),
+         act, float(gate_scale), int(accumulate), float(alpha), int(exact),
          1, 0, 0, 0, 0, 0, 0, *drop.args(), tile, splitk, ws, WS_FLOATS)
     return C
 

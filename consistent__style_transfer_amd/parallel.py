@@ -4,7 +4,9 @@ all-reduce (average) over RCCL/xGMI on the flat gradient buffers of optim.FlatGr
 The reference has no distributed code; this is new.  Contract:
   * the GLOBAL batch is built on the host exactly as collate_* does (noise functions mix tokens
     across the whole batch), padded to the global maximum length, then rows are split evenly
-    (shard_batch); scheduled-sampling coins are identical on every rank, dropout streams differ;
+    (shard_batch); scheduled-sampling coins and dropout seeds are identical on every rank, and every kernel indexes its
+    dropout mask by the GLOBAL batch row (init_distributed registers the rank: cst_set_drop_shard), so the shards together draw
+    exactly the masks the one-process global-batch run draws;
   * each FlatGroup's gradient buffer is all-reduced in buckets; the global grad-norm clip and Adam
     then run on identical, already averaged gradients on every rank.
 """
@@ -28,6 +30,9 @@ def init_distributed(backend=None):
             # one process per GPU; ranks may only share a device in single-GPU rehearsals (gloo)
             torch.cuda.set_device(local % torch.cuda.device_count())
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    if world > 1:
+        from ._lib import call_plain
+        call_plain("cst_set_drop_shard", rank)     # shard_batch gives rank r the rows [r*n, (r+1)*n): mask indices start at r * numel_local
     return rank, local, world
 
 

@@ -123,11 +123,14 @@ class Trainer:
         val_sampler = GlobalBatchSampler(len(val_ds), batch_size, shuffle=False, world=self.world)
         train_sampler = GlobalBatchSampler(len(train_ds), batch_size, shuffle=True, seed=args.seed, world=self.world)
 
+        # validation never reads the label cache of the seeded TRAINING stream (loader.PretrainCollate.without_cache)
+        val_collate = collate.without_cache() if hasattr(collate, "without_cache") else collate
+
         def validate(limit=None):
             stage.eval()
             outs = []
             with torch.no_grad():
-                for bi, batch in iterate_batches(val_ds, val_sampler, collate, seed=args.seed + 99):
+                for bi, batch in iterate_batches(val_ds, val_sampler, val_collate, seed=args.seed + 99):
                     if limit is not None and bi >= limit:
                         break
                     outs.append(stage.validation_step(self, self.put(batch)))
@@ -200,6 +203,11 @@ class StepCache:
         if g is None:
             while len(self.graphs) >= max(1, self.capacity):
                 _, old = self.graphs.popitem(last=False)
+                # replays are asynchronous: the evicted graph's last replay (and collectives it deferred) may still be reading its
+                # pinned pointer tables, which release() hands back to the pool for the next capture
+                if self.reducer is not None and hasattr(self.reducer, "wait"):
+                    self.reducer.wait()
+                torch.cuda.current_stream().synchronize()
                 old.release()
                 self.evictions += 1
             if self.pool is None:

@@ -32,6 +32,14 @@ extern "C" {
 const char* cst_last_error(void);
 int cst_abi_version(void);
 
+/* Data-parallel dropout contract (new work: the reference has no distributed code).  Every tensor a
+ * dropout mask applies to is batch-major, so the element the one-process global batch indexes as idx sits at
+ * rank * numel_local + idx_local on the rank that holds its batch row.  After cst_set_drop_shard(rank) every kernel of this
+ * process adds rank * (elements of its local mask tensor) to its element indices: a shard draws exactly the masks the
+ * one-process run draws for the same sentences (rnn.py:40,59,79,96; classifier.py:20,37; discriminator.py:29,48; the dropouts
+ * inside nn.TransformerEncoderLayer, mlm.py:20-22 / match.py:18-20).  rank 0 (the default) = unsharded.  Process-global. */
+int cst_set_drop_shard(int rank);
+
 /* C[M,N] = epilogue(alpha * op(A)[M,K] . op(B)[K,N]) on the matrix cores.
  * a_kmajor: A is [M,lda] (1) or [K,lda] (0);  b_kmajor: B is [N,ldb] (1, a torch Linear weight
  * used as in F.linear) or [K,ldb] (0).  Epilogue order: +bias[n], +addend[m,n], act

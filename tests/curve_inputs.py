@@ -26,4 +26,10 @@ def pre_batch(c, it):
 
 HP = dict(w_s=0.1, w_c=0.5, w_adv=1.0, w_bt=1.0, tau=0.1, gap=0.0)
 
-CURVE_LR = {"tiny": 1e-3, "ref": 1e-5, "b16": 1e-5, "long": 1e-3}      # as tests/golden/make_golden.py
+CURVE_LR = {"tiny": 1e-3, "ref": 1e-5, "long": 1e-3, "b16": {"optimize": 1e-4, "warmup": 1e-4, "pretrain": 1e-5}}      # as tests/golden/make_golden.py
+
+
+def curve_lr(name, stage):
+    """Learning rate of the `stage` ("optimize" | "warmup" | "pretrain") curve fixture of configuration `name`."""
+    v = CURVE_LR[name]
+    return v[stage] if isinstance(v, dict) else v

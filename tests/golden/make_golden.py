@@ -290,7 +290,17 @@ def step_goldens(name, c):
     return out
 
 
-CURVE_LR = {"tiny": 1e-3, "ref": 1e-5, "b16": 1e-5, "long": 1e-3}      # toy widths: raised so the optimiser dynamics show; reference widths: the reference's own lr
+# toy widths: raised so the optimiser dynamics show; `ref` (B = 2): the reference's own rates.  b16 (the fast-path shapes, 20 steps):
+# per stage, the largest rate of a decade sweep at which 20 steps move the losses in the second decimal and rounding-level
+# differences are not yet amplified chaotically (optimize / warmup at 1e-4: BK 5.35 -> 5.18, CP -0.71 -> -0.55, warmup 5.35 -> 5.10;
+# pretrain at 1e-5: c_loss 2.23 -> 0.26, dn_loss 5.58 -> 4.81 -- at 1e-4 the Matcher's MSE jumps 2.2 -> 8.2 -> 1.1 within three steps)
+CURVE_LR = {"tiny": 1e-3, "ref": 1e-5, "long": 1e-3, "b16": {"optimize": 1e-4, "warmup": 1e-4, "pretrain": 1e-5}}
+CURVE_STEPS = {"tiny": 20, "long": 4, "ref": 6, "b16": 20}
+
+
+def lr_of(name, stage):
+    v = CURVE_LR[name]
+    return v[stage] if isinstance(v, dict) else v
 
 
 def curve_goldens(name, c, steps):
@@ -327,7 +337,7 @@ def curve_goldens(name, c, steps):
     # ---- optimize ------------------------------------------------------------------------
     G, C, Mt, Dn, D = build(c)
     allm = (G, C, Mt, Dn, D)
-    lr = CURVE_LR[name]
+    lr = lr_of(name, "optimize")
     og = torch.optim.Adam(G.parameters(), lr=lr)
     od = torch.optim.Adam(D.parameters(), lr=lr)
     rows = []
@@ -372,7 +382,7 @@ def curve_goldens(name, c, steps):
     G, C, Mt, Dn, D = build(c)
     for p in G.parameters():
         p.requires_grad_(True)
-    ow = torch.optim.Adam(G.parameters(), lr=lr)
+    ow = torch.optim.Adam(G.parameters(), lr=lr_of(name, "warmup"))
     rows = []
     for it in range(steps):
         x, labels = batch_of(it)
@@ -393,7 +403,7 @@ def curve_goldens(name, c, steps):
     ps = list(C.parameters()) + list(Mt.parameters()) + list(Dn.parameters())
     for p in ps:
         p.requires_grad_(True)
-    op = torch.optim.Adam(ps, lr=lr)
+    op = torch.optim.Adam(ps, lr=lr_of(name, "pretrain"))
     rows = []
     for it in range(steps):
         x, labels = batch_of(it)
@@ -458,8 +468,13 @@ def main():
         # host.json + the sample tokenizer: regenerated only on request -- BPE training breaks frequency ties in hash
         # order, so a re-run yields a different (equally valid) merge table and the committed pair must stay together
         host_goldens()
+    curves_only = "--curves-only" in sys.argv[1:]         # rewrite curves_<name>.npz only (a new learning rate / step count)
     for name, c in CONFIGS.items():
         if only and name not in only:
+            continue
+        if curves_only:
+            np.savez_compressed(os.path.join(HERE, f"curves_{name}.npz"), **curve_goldens(name, c, CURVE_STEPS[name]))
+            print(name, "curves rewritten")
             continue
         mg = module_goldens(name, c)
         # keep fixtures small: big gradient arrays are replaced by their L2 norm and a
@@ -483,7 +498,7 @@ def main():
                       f, indent=0, sort_keys=True)
         sg = step_goldens(name, c)
         np.savez_compressed(os.path.join(HERE, f"steps_{name}.npz"), **sg)
-        cg = curve_goldens(name, c, {"tiny": 20, "long": 4}.get(name, 6))
+        cg = curve_goldens(name, c, CURVE_STEPS[name])
         np.savez_compressed(os.path.join(HERE, f"curves_{name}.npz"), **cg)
         print(name, "modules:", len(mg), "arrays;", "steps:", len(sg), "arrays")
 

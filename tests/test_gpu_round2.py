@@ -29,7 +29,7 @@ GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
 # --------------------------------------------------------------------------------- full-size configs
-@pytest.mark.parametrize("workload", ["yelp_6l_d768_b256", "book_6l_d512_b512", "yelp_6l_d512_b256"])
+@pytest.mark.parametrize("workload", ["yelp_4l_d512_b256", "yelp_6l_d768_b256", "book_6l_d512_b512", "yelp_6l_d512_b256"])
 def test_full_size_stage_steps(workload):
     import bench
     from consistent__style_transfer_amd import model, ops
@@ -255,7 +255,7 @@ def _free_port():
     return p
 
 
-def _dp_worker(rank, world, port, out, steps):
+def _dp_worker(rank, world, port, out, steps, train_mode=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
                       CST_DIST_BACKEND="gloo")
     import torch.distributed as dist
@@ -268,18 +268,26 @@ def _dp_worker(rank, world, port, out, steps):
     name = "tiny"
     c = CONFIGS[name]
     B = 4
+    from consistent__style_transfer_amd._lib import call_plain
     st = make_opt(name, lr=1e-3)
     broadcast_tensors(st.replicated_tensors())
     reducer = GradReducer(world)
     full = make_opt(name, lr=1e-3) if rank == 0 else None
+    if train_mode:                       # dropout ON everywhere (generator 0.1, critics 0.1 / 0.5, discriminator 0.25), seeded per batch
+        st.train()
+        if full is not None:
+            full.train()
     try:
         for it in range(steps):
             x = det_tokens(B, c["L"], c["V"], 100 + it).cuda()
             lab = torch.tensor([0, 1, 1, 0], device="cuda")
             coins = torch.tensor([(it + k) % 2 for k in range(c["L"])], dtype=torch.int32, device="cuda")
-            st.train_step(shard_batch((x, lab), rank, world), it, coins=coins, reducer=reducer)
+            seed = 7000 + 10 * it if train_mode else None
+            st.train_step(shard_batch((x, lab), rank, world), it, coins=coins, seed=seed, reducer=reducer)
             if full is not None:
-                full.train_step((x, lab), it, coins=coins)
+                call_plain("cst_set_drop_shard", 0)            # the one-process reference run draws the global batch's masks
+                full.train_step((x, lab), it, coins=coins, seed=seed)
+                call_plain("cst_set_drop_shard", rank)
         check_replicas(st.replicated_tensors(), "product optimize stage")     # raises on every rank if any bit differs
         if rank == 0:
             eg = float((st.g_group.flat_p - full.g_group.flat_p).abs().max())
@@ -291,15 +299,20 @@ def _dp_worker(rank, world, port, out, steps):
         dist.destroy_process_group()
 
 
-def test_dp2_product_optimize_stage_replicas_identical_and_match_global_batch():
+@pytest.mark.parametrize("train_mode", [False, True])
+def test_dp2_product_optimize_stage_replicas_identical_and_match_global_batch(train_mode):
     """8 batches: 0 and 4 step the discriminator, in between its gradients accumulate and pass through both clips of every
-    batch (stages.OptimizeStage.train_step reduces them every batch for that reason)."""
+    batch (stages.OptimizeStage.train_step reduces them every batch for that reason).
+    train_mode: the same with dropout ON in every module -- each rank registers its data-parallel rank with the library
+    (parallel.init_distributed -> cst_set_drop_shard), so its kernels index the masks by GLOBAL batch row and the two shards
+    together draw exactly the masks of the one-process global-batch run (round-2 verdict: every rank used to draw the same
+    masks for its local rows)."""
     import torch.multiprocessing as mp
     from test_dp_gloo_cpu import _collect
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, q, 8)) for r in range(2)]
+    procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, q, 8, train_mode)) for r in range(2)]
     for p in procs:
         p.start()
     (eg, ed, moved), = _collect(procs, q, 1, timeout=600)
@@ -321,7 +334,7 @@ def _rccl_worker(port, out):
     from consistent__style_transfer_amd import model, ops, stages
     from consistent__style_transfer_amd.parallel import GradReducer, check_replicas, max_over_ranks
     from consistent__style_transfer_amd.trainer import StepCache
-    from test_gpu_stages import CURVE_LR, pre_batch
+    from test_gpu_stages import curve_lr, pre_batch
     torch.cuda.set_device(0)
     dist.init_process_group("nccl", rank=0, world_size=1)
     try:
@@ -331,7 +344,7 @@ def _rccl_worker(port, out):
 
         def build():
             set_constants(model, c)
-            pre = stages.PretrainStage(c["V"], 2, lr=CURVE_LR[name])
+            pre = stages.PretrainStage(c["V"], 2, lr=curve_lr(name, "pretrain"))
             for attr, which in (("classifier", "cls"), ("matcher", "mat"), ("denoiser", "dn")):
                 _load(getattr(pre, attr), which)
             pre = pre.cuda().eval()

@@ -226,6 +226,16 @@ def test_prefetched_batches_equal_inline_batches_and_label_cache_replays_them(tm
         assert all(torch.equal(x, y) for x, y in zip(a, b))
     with pytest.raises(KeyError):
         back.get(7, 0, 64)
+    # validation must not read the TRAINING stream's cache (advisor, round 2: validation batch i used to get the labels of training
+    # batch i of epoch 0): Trainer.fit validates through collate.without_cache(), which computes labels and ignores `position`
+    seen = []
+    vc = collate_pretrain(vocab, label_fn=lambda a, b, v: seen.append(len(a)) or [0.25] * len(a), label_cache=back).without_cache()
+    assert vc.label_cache is None
+    val_sampler = GlobalBatchSampler(len(ds), 64, shuffle=False)                 # never calls set_epoch: epoch 0, as Trainer.fit's does
+    vb = list(iterate_batches(ds, val_sampler, vc, seed=3 + 99))
+    assert seen == [b[0].shape[0] for _, b in vb] and all(float(b[5][0]) == 0.25 for _, b in vb)
+    plain = collate_pretrain(vocab, label_fn=lambda a, b, v: [0.0] * len(a))
+    assert plain.without_cache() is plain
 
 
 # ------------------------------------------------------------------------------ offline quality metrics

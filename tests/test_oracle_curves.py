@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 import torch
 
-from curve_inputs import CURVE_LR, HP, opt_batch, pre_batch, warm_batch
+from curve_inputs import HP, curve_lr, opt_batch, pre_batch, warm_batch
 from helpers import CONFIGS, det_params, load_golden
 from oracle import train as T
 
@@ -15,7 +15,7 @@ torch.set_num_threads(4)
 def test_optimize_curve(name):
     c, G = CONFIGS[name], load_golden("curves", name)
     P = {k: det_params(name, k) for k in ("G", "cls", "mat", "dn", "disc")}
-    tr = T.OracleOptimize(P["G"], P["cls"], P["mat"], P["dn"], P["disc"], HP, c["n_head"], c["max_len"], lr=CURVE_LR[name])
+    tr = T.OracleOptimize(P["G"], P["cls"], P["mat"], P["dn"], P["disc"], HP, c["n_head"], c["max_len"], lr=curve_lr(name, "optimize"))
     steps = G["optimize.curve"].shape[0] if name in ("tiny", "long") else 3
     rows = [tr.step(opt_batch(c, it), it, G["optimize.coins"][it]) for it in range(steps)]
     np.testing.assert_allclose(np.array(rows), G["optimize.curve"][:steps], rtol=2e-3, atol=1e-3)
