@@ -10,7 +10,7 @@ import sys
 
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB = os.path.join(CSRC, "libcst_hip.so")
-SOURCES = ["common.hip", "gemm.hip", "gemm_bf16.hip", "rowwise.hip", "attention.hip", "attention_long.hip", "pointwise.hip", "relconv.hip", "lstm_seq.hip"]
+SOURCES = ["common.hip", "gemm.hip", "gemm_bf16.hip", "rowwise.hip", "attention.hip", "attention_long.hip", "pointwise.hip", "relconv.hip", "lstm_seq.hip", "decode.hip"]
 ARCH = "gfx950"
 
 
@@ -38,6 +38,8 @@ def build_lib(force=False, verbose=True):
         objs.append(obj)
         if force or _stale(obj, [src] + hdrs):
             cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-fPIC", "-std=c++17", "-c", src, "-o", obj]
+            if os.environ.get("CST_BENCH_VARIANTS") == "1":          # bench-only GEMM variants + timing ablations (gemm_bf16.hip)
+                cmd.insert(-4, "-DCST_BENCH_VARIANTS")
             if verbose:
                 print(" ".join(cmd), flush=True)
             subprocess.check_call(cmd)

@@ -1,0 +1,413 @@
+// Decoder-step kernels for gfx950: the attention-LSTM decode loop of DenoiseLSTM.forward (reference src/model/rnn.py:72-97) as FOUR
+// dependent launches per step instead of six, none of them a split-K reduce:
+//
+//   cst_dec_gates        token choice + embedding (+ dropout) of x_t, gates = [x_t | h_{t-1}] [W_ih | W_hh]^T + b, LSTM cell   (rnn.py:74, :88-96)
+//   cst_dot_attn_fwd     single-query attention of h_t over the encoder states, dropout of [h_t | a_t]                          (rnn.py:76-79, attention.hip)
+//   cst_gemm_bf16_skinny fn_1 + LeakyReLU                                                                                       (rnn.py:79-80)
+//   cst_gemm_bf16_argmax fn_2 into the stacked (B, T, V) output; its epilogue also leaves each row's arg-max                    (rnn.py:80, :83-92)
+//
+// Why this shape.  The step is a chain of M = batch = 256 products whose kernels are bound by what they wait for, not by arithmetic
+// (profiles/round3_decode_step.txt): a launch costs ~3 us before its first useful cycle, a K-tile fetched one tile ahead of a
+// 0.25 us MFMA block costs a full L2 round trip, and a split-K product pays a second launch for its reduce.  So:
+//   * the small products take their WHOLE K into LDS at once -- every DMA piece of both operands is requested before the first wait
+//     (32 x 64 / 32 x 32 output tiles: 120-128 KiB of LDS, one workgroup per CU, 128-256 workgroups) -- one exposed round trip per
+//     launch instead of one per K-tile, and no K split, hence no slab round trip and no reduce launch;
+//   * the gate columns of a tile are PERMUTED: tile column 16 q + j is gate q of hidden unit 16 n + j, so a workgroup holds all four
+//     gate pre-activations of its 32 rows x 16 units and finishes the LSTM cell itself; h_t leaves the kernel in bf16, already the A
+//     operand of the next step;
+//   * the scheduled-sampling / straight-through feedback needs only the arg-max of the previous step's vocabulary row.  The fn_2
+//     product's epilogue reduces every 64-column row piece it writes and folds it into one packed word per row with a 64-bit
+//     atomic max (value in the high half, inverted column index in the low half: the largest logit, the FIRST index among equals, in
+//     any arrival order); the next step's cst_dec_gates reads 8 bytes per row and gathers the embedding itself.  The softmax of the
+//     soft decode (rnn.py:83) is off the recurrence's critical path: it runs once, after the loop, over all T steps.
+//
+// E = 128 (one row of the embedding table per 8 lanes), K = E + H_dec a multiple of 64, H_dec a multiple of 16; any batch size.
+#include "cst_common.h"
+
+typedef unsigned short bf16_t;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef __attribute__((address_space(1))) const void* gbl_ptr_t;
+
+__device__ __forceinline__ bf16_t dk_f2bf(float v) { __bf16 h = (__bf16)v; return __builtin_bit_cast(unsigned short, h); }
+__device__ __forceinline__ unsigned dk_pack2(float a, float b) { return (unsigned)dk_f2bf(a) | ((unsigned)dk_f2bf(b) << 16); }
+// byte offset of 16-byte slot `slot` (8 bf16 of k) of row `row` inside one K-tile image [rows][128 B] (the swizzle of gemm_bf16.hip)
+__device__ __forceinline__ int dk_off(int row, int slot) { return row * 128 + ((slot ^ (row & 7)) << 4); }
+// hardware exp / reciprocal forms (v_exp_f32, v_rcp_f32: ~1e-6 relative), as the whole-sequence encoder kernels use (lstm_seq.hip)
+__device__ __forceinline__ float dk_sigmoid(float x) { return __frcp_rn(1.f + __expf(-x)); }
+__device__ __forceinline__ float dk_tanh(float x) { return 2.f * __frcp_rn(1.f + __expf(-2.f * x)) - 1.f; }
+constexpr int DK_AMAX_GROUPS = 32;     // = CST_AMAX_GROUPS of gemm_bf16.hip (cst_argmax_groups())
+
+// Whole-K panel [ROWS][K] bf16 -> LDS as K-tile images [kt][ROWS][128 B], by LDS-DMA: one wave instruction moves 8 rows x 128 B
+// (lane l lands at row 8c + l / 8, physical slot l % 8 and therefore fetches logical slot (l % 8) ^ (row & 7)).  `rowptr(r)` = global
+// address of tile row r.  Chunks kt0 * ROWS / 8 .. go round-robin over the NW waves; nothing waits here.
+template <int ROWS, int NW, typename RowPtr>
+__device__ __forceinline__ void dk_issue_panel(char* region, int kt0, int nkt, int wave, int lane, RowPtr rowptr) {
+    constexpr int CPT = ROWS / 8;                           // chunks per K-tile
+    const int lrow = lane >> 3, lps = lane & 7;
+    for (int ch = kt0 * CPT + wave; ch < nkt * CPT; ch += NW) {
+        const int kt = ch / CPT, rc = ch - kt * CPT;
+        const int r = rc * 8 + lrow;
+        const bf16_t* src = rowptr(r) + kt * 64 + ((lps ^ (r & 7)) << 3);
+        __builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)(region + kt * ROWS * 128 + rc * 1024), 16, 0, 0);
+    }
+}
+
+// acc[j] (+)= A[16 rows of wave row wm] . B[16 columns j of wave column wn]^T over the whole K; TN column tiles per wave
+template <int BM, int BN, int TN, int NWN>
+__device__ __forceinline__ void dk_mfma_tile(const char* As, const char* Bs, int kt, int wm, int wn, int lr, int lq, f32x4_t (&acc)[TN]) {
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+        const u32x4_t a = *reinterpret_cast<const u32x4_t*>(As + kt * BM * 128 + dk_off(16 * wm + lr, kk * 4 + lq));
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const u32x4_t b = *reinterpret_cast<const u32x4_t*>(Bs + kt * BN * 128 + dk_off(wn * (BN / NWN) + 16 * j + lr, kk * 4 + lq));
+            acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), acc[j], 0, 0, 0);
+        }
+    }
+}
+// A wave has ~2 MFMAs per three 16-byte LDS reads here: the loop is LDS-latency-bound unless several K-tiles' reads are in flight.  With
+// the tile count known at compile time (the reference's widths: K = 640 / 1024 / 512) the loop is fully unrolled and hipcc hoists the
+// reads as far as the register file allows; other widths take the rolled loop (four tiles per trip).
+template <int BM, int BN, int TN, int NWN, int KSTEP = 1>
+__device__ __forceinline__ void dk_mfma_all(const char* As, const char* Bs, int nkt, int wm, int wn, int lane, f32x4_t (&acc)[TN], int kt0 = 0) {
+    const int lr = lane & 15, lq = lane >> 4;
+    if (nkt == 10) {
+#pragma unroll
+        for (int kt = 0; kt < 10; kt += KSTEP) dk_mfma_tile<BM, BN, TN, NWN>(As, Bs, kt0 + kt, wm, wn, lr, lq, acc);
+    } else if (nkt == 16) {
+#pragma unroll
+        for (int kt = 0; kt < 16; kt += KSTEP) dk_mfma_tile<BM, BN, TN, NWN>(As, Bs, kt0 + kt, wm, wn, lr, lq, acc);
+    } else if (nkt == 8) {
+#pragma unroll
+        for (int kt = 0; kt < 8; kt += KSTEP) dk_mfma_tile<BM, BN, TN, NWN>(As, Bs, kt0 + kt, wm, wn, lr, lq, acc);
+    } else {
+#pragma unroll 4
+        for (int kt = kt0; kt < nkt; kt += KSTEP) dk_mfma_tile<BM, BN, TN, NWN>(As, Bs, kt, wm, wn, lr, lq, acc);
+    }
+}
+
+// =============================================================================================
+// cst_dec_gates
+// =============================================================================================
+struct DecGatesArgs {
+    const bf16_t* A; long lda;                 // [B, K] bf16: [x_t | h_{t-1}]; the x part is only read when amax == null
+    const bf16_t* W; long ldw;                 // [4 Hd, K] bf16, K contiguous: [W_ih | W_hh]
+    const unsigned long long* amax;            // [DK_AMAX_GROUPS][B] packed arg-max words of the previous step's vocabulary rows, or null
+    const int64_t* ids_t; long ldids;          // teacher tokens x[:, t-1] (column view) or null
+    const int* coin;                           // device word: != 0 feeds the arg-max back, 0 the teacher token; null = always feed back
+    const float* table; long ldtab; int V;     // token embedding [V, E] fp32
+    CstDrop drop;                              // dropout of x_t over the (B, E) index space
+    bf16_t* xb_out; long ldxb;                 // bf16 x_t kept for the weight-gradient product (may be A's own x columns)
+    const float* bias;                         // [4 Hd] b_ih + b_hh
+    const float* c_prev; long ldcp;
+    float* gates; long ldg;                    // [B, 4 Hd] ACTIVATED gates i, f, g, o (what the backward pass reads)
+    float* c_out; long ldc;
+    float* h_out; long ldh;
+    bf16_t* hb_next; long ldhb;                // bf16 h_t: the h columns of the next step's A (null at the last step)
+    int B, E, Hd, K;
+};
+
+// 512 threads: 8 waves issue the DMA pieces (15 each at K = 640: a piece costs its wave 60-180 cycles to issue), then wave (wm, q) =
+// (wave >> 2, wave & 3) multiplies rows 16 wm .. + 15 by the 16 columns of gate q.
+__global__ __launch_bounds__(512) void dec_gates_kernel(DecGatesArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char dk_smem[];
+    const int nkt = a.K >> 6;
+    char* As = dk_smem;                                     // [nkt][32][128 B]
+    char* Bs = dk_smem + nkt * 32 * 128;                    // [nkt][64][128 B]
+    const int m0 = blockIdx.x * 32, ny = blockIdx.y;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int kt_x = a.amax ? (a.E >> 6) : 0;               // K-tiles of x_t filled by the gather below instead of DMA
+    // weights: tile row 16 q + j = gate q of hidden unit 16 ny + j
+    dk_issue_panel<64, 8>(Bs, 0, nkt, wave, lane, [&](int r) { return a.W + (long)((r >> 4) * a.Hd + 16 * ny + (r & 15)) * a.ldw; });
+    // rows past the batch re-read the last valid row (their results are never stored)
+    dk_issue_panel<32, 8>(As, kt_x, nkt, wave, lane, [&](int r) { return a.A + (long)min(m0 + r, a.B - 1) * a.lda; });
+    if (a.amax) {
+        // x_t = dropout(E[token]): 16 lanes per batch row, 8 elements each (E == 128); lane j of a row also owns group j of the row's
+        // DK_AMAX_GROUPS packed arg-max words (j and j + 16)
+        const int row = threadIdx.x >> 4, j = threadIdx.x & 15, c0 = j * 8;
+        const bool live = m0 + row < a.B;
+        const int b = min(m0 + row, a.B - 1);
+        // the words that decide the token are requested together (one round trip, not three dependent ones; absent operands read a
+        // valid dummy address instead of branching around their load: a branch would put one full wait per load)
+        const int64_t* tp = a.ids_t ? a.ids_t + (long)b * a.ldids : reinterpret_cast<const int64_t*>(a.amax + b);
+        const int* cp = a.coin ? a.coin : reinterpret_cast<const int*>(a.amax);
+        unsigned long long pk = a.amax[(long)j * a.B + b], pk2 = a.amax[(long)(j + 16) * a.B + b];
+        long tid = *tp;
+        int coin_raw = *cp;
+        asm volatile("" : "+v"(pk), "+v"(pk2), "+v"(tid), "+v"(coin_raw));      // all in registers before any of them is looked at
+        pk = pk2 > pk ? pk2 : pk;
+        static_assert(DK_AMAX_GROUPS == 32, "two group words per lane, 16 lanes per row");
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) {                            // max over the 16 group words (16 consecutive lanes)
+            const unsigned lo = __shfl_xor((unsigned)pk, o, 64), hi = __shfl_xor((unsigned)(pk >> 32), o, 64);
+            const unsigned long long other = ((unsigned long long)hi << 32) | lo;
+            pk = other > pk ? other : pk;
+        }
+        const int coin = a.coin ? coin_raw : 1;
+        const long id = (a.ids_t && !coin) ? tid : (long)(0xFFFFFFFFu - (unsigned)(pk & 0xFFFFFFFFull));
+        const bool ok = id >= 0 && id < a.V;
+        const float4* trow = reinterpret_cast<const float4*>(a.table + (ok ? id : 0) * a.ldtab + c0);
+        float4 v[2];
+        v[0] = trow[0]; v[1] = trow[1];                               // unconditional (row 0 when the id is out of range), select after
+        if (!ok) { v[0] = make_float4(0.f, 0.f, 0.f, 0.f); v[1] = v[0]; }
+        if (a.drop.p > 0.f) {
+            const uint32_t dseed = cst_drop_seed(a.drop);
+            const uint32_t di = (uint32_t)((long)b * a.E + c0);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                v[i].x *= cst_drop_mask(a.drop, dseed, di + 4 * i);     v[i].y *= cst_drop_mask(a.drop, dseed, di + 4 * i + 1);
+                v[i].z *= cst_drop_mask(a.drop, dseed, di + 4 * i + 2); v[i].w *= cst_drop_mask(a.drop, dseed, di + 4 * i + 3);
+            }
+        }
+        u32x4_t q;
+        q.x = dk_pack2(v[0].x, v[0].y); q.y = dk_pack2(v[0].z, v[0].w); q.z = dk_pack2(v[1].x, v[1].y); q.w = dk_pack2(v[1].z, v[1].w);
+        *reinterpret_cast<u32x4_t*>(As + (c0 >> 6) * 32 * 128 + dk_off(row, (c0 & 63) >> 3)) = q;
+        if (ny == 0 && a.xb_out && live) *reinterpret_cast<u32x4_t*>(a.xb_out + (long)b * a.ldxb + c0) = q;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every DMA piece of this wave has landed ...
+    __syncthreads();                                       // ... and every other wave's
+    const int wm = wave >> 2, q = wave & 3;
+    const int lr = lane & 15, lq = lane >> 4;
+    f32x4_t acc[1] = {(f32x4_t){0.f, 0.f, 0.f, 0.f}};
+    dk_mfma_all<32, 64, 1, 4>(As, Bs, nkt, wm, q, lane, acc);
+    __syncthreads();                                       // all fragment reads done: the A region becomes the exchange buffer
+    // wave (wm, q) holds gate q of (row 16 wm + 4 lq + r, unit 16 ny + lr)
+    float* ex = reinterpret_cast<float*>(dk_smem);         // [32 rows][16 units][4 gates]
+#pragma unroll
+    for (int r = 0; r < 4; ++r) ex[((16 * wm + 4 * lq + r) * 16 + lr) * 4 + q] = acc[0][r];
+    __syncthreads();
+    {
+        const int row = threadIdx.x >> 4, ul = threadIdx.x & 15;          // one (row, unit) per thread
+        const long b = m0 + row;
+        if (b < a.B) {
+            const int u = 16 * ny + ul, Hd = a.Hd;
+            const float4 pre = *reinterpret_cast<const float4*>(ex + (row * 16 + ul) * 4);
+            const float gi = dk_sigmoid(pre.x + a.bias[u]), gf = dk_sigmoid(pre.y + a.bias[Hd + u]);
+            const float gg = dk_tanh(pre.z + a.bias[2 * Hd + u]), go = dk_sigmoid(pre.w + a.bias[3 * Hd + u]);
+            const float c = gf * a.c_prev[b * a.ldcp + u] + gi * gg;
+            const float h = go * dk_tanh(c);
+            float* g = a.gates + b * a.ldg + u;
+            g[0] = gi; g[Hd] = gf; g[2 * Hd] = gg; g[3 * Hd] = go;
+            a.c_out[b * a.ldc + u] = c;
+            a.h_out[b * a.ldh + u] = h;
+            if (a.hb_next) a.hb_next[b * a.ldhb + u] = dk_f2bf(h);
+        }
+    }
+}
+
+extern "C" long cst_dec_gates_lds_bytes(int E, int Hd) { return (long)((E + Hd) / 64) * (32 + 64) * 128; }
+
+extern "C" int cst_dec_gates(const void* A, long lda, const void* W, long ldw,
+                             const void* amax_prev, const int64_t* ids_teacher, long ldids, const int* coin_dev,
+                             const float* table, long ldtab, int V,
+                             float drop_p, uint32_t drop_seed, uint32_t drop_stream, const void* drop_seed_dev,
+                             void* x_bf16_out, long ldxb, const float* bias, const float* c_prev, long ldcp,
+                             float* gates, long ldg, float* c_out, long ldc, float* h_out, long ldh, void* h_bf16_next, long ldhb,
+                             int B, int E, int Hd, void* stream) {
+    CST_REQUIRE(A && W && bias && c_prev && gates && c_out && h_out, "cst_dec_gates: null pointer");
+    const int K = E + Hd;
+    CST_REQUIRE(B > 0 && Hd > 0 && Hd % 16 == 0 && E == 128 && K % 64 == 0,
+                "cst_dec_gates: needs Hd %% 16 == 0, E == 128, (E + Hd) %% 64 == 0 (B=%d, E=%d, Hd=%d)", B, E, Hd);
+    CST_REQUIRE(lda >= K && ldw >= K && lda % 8 == 0 && ldw % 8 == 0 && ((((uintptr_t)A) | ((uintptr_t)W)) & 15) == 0,
+                "cst_dec_gates: operands must be 16-byte aligned with leading dimensions >= K, multiples of 8");
+    CST_REQUIRE(!amax_prev || (table && ldtab >= E && ldtab % 4 == 0 && (((uintptr_t)table) & 15) == 0 && V > 0 && (((uintptr_t)amax_prev) & 7) == 0),
+                "cst_dec_gates: the gather needs a 16-byte aligned embedding table (ldtab %% 4 == 0) and 8-byte aligned arg-max words");
+    CST_REQUIRE(!x_bf16_out || (ldxb % 8 == 0 && (((uintptr_t)x_bf16_out) & 15) == 0), "cst_dec_gates: x_bf16_out must be 16-byte aligned, ldxb %% 8 == 0");
+    const long lds = cst_dec_gates_lds_bytes(E, Hd);
+    CST_REQUIRE(lds <= 160 * 1024, "cst_dec_gates: K=%d needs %ld bytes of LDS (max 160 KiB)", K, lds);
+    DecGatesArgs a;
+    a.A = (const bf16_t*)A; a.lda = lda; a.W = (const bf16_t*)W; a.ldw = ldw;
+    a.amax = (const unsigned long long*)amax_prev; a.ids_t = ids_teacher; a.ldids = ldids; a.coin = coin_dev;
+    a.table = table; a.ldtab = ldtab; a.V = V;
+    a.drop = cst_make_drop(amax_prev ? drop_p : 0.f, drop_seed, drop_stream, drop_seed_dev, (long)B * E);
+    a.xb_out = (bf16_t*)x_bf16_out; a.ldxb = ldxb; a.bias = bias; a.c_prev = c_prev; a.ldcp = ldcp;
+    a.gates = gates; a.ldg = ldg; a.c_out = c_out; a.ldc = ldc; a.h_out = h_out; a.ldh = ldh;
+    a.hb_next = (bf16_t*)h_bf16_next; a.ldhb = ldhb; a.B = B; a.E = E; a.Hd = Hd; a.K = K;
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void*)dec_gates_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(dec_gates_kernel, dim3((B + 31) / 32, Hd / 16), dim3(512), (size_t)lds, (hipStream_t)stream, a);
+    CST_LAUNCH_CHECK("cst_dec_gates");
+    return CST_OK;
+}
+
+// =============================================================================================
+// cst_dec_attn: single-query dot attention of one decode step (rnn.py:46-50, :76) + dropout of the FFN input (rnn.py:79)
+//
+// One workgroup per batch row, thread t owns dimensions 2t, 2t + 1 of the 512: every encoder state of the row is requested straight
+// into registers in ONE burst (L' independent 8-byte loads per thread, no LDS staging: the tile is read once and used twice -- for the
+// scores and for the weighted sum), the L' scores are reduced by DPP + one LDS exchange, every thread finishes the softmax itself.
+// One memory round trip and two barriers where cst_dot_attn_fwd stages the tile through LDS behind five.
+// =============================================================================================
+template <int LMAX>
+__global__ __launch_bounds__(256) void dec_attn_kernel(const float* __restrict__ q, long ldq, const float* __restrict__ mem,
+                                                       float* __restrict__ out, long ldo, float* __restrict__ p, int L, float scale,
+                                                       bf16_t* __restrict__ dropped_b, long lddropb, CstDrop drop) {
+    constexpr int D = 512;
+    __shared__ float red[4][LMAX];
+    const int b = blockIdx.x, t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const float2 qv = *reinterpret_cast<const float2*>(q + (long)b * ldq + 2 * t);
+    const float* mb = mem + (long)b * L * D + 2 * t;
+    float2 m[LMAX];
+#pragma unroll
+    for (int j = 0; j < LMAX; ++j) m[j] = j < L ? *reinterpret_cast<const float2*>(mb + (long)j * D) : make_float2(0.f, 0.f);
+#pragma unroll
+    for (int j = 0; j < LMAX; ++j) {
+        if (j < L) {                                       // wave-uniform
+            const float s = wave_sum(qv.x * m[j].x + qv.y * m[j].y);
+            if (lane == 0) red[w][j] = s;
+        }
+    }
+    __syncthreads();
+    float sc[LMAX], mx = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < LMAX; ++j) {
+        sc[j] = j < L ? ((red[0][j] + red[1][j]) + (red[2][j] + red[3][j])) * scale : -INFINITY;
+        mx = fmaxf(mx, sc[j]);
+    }
+    float sum = 0.f;
+#pragma unroll
+    for (int j = 0; j < LMAX; ++j) { sc[j] = j < L ? __expf(sc[j] - mx) : 0.f; sum += sc[j]; }
+    const float inv = 1.f / sum;
+    float2 o = make_float2(0.f, 0.f);
+#pragma unroll
+    for (int j = 0; j < LMAX; ++j) {
+        const float pj = sc[j] * inv;
+        o.x += pj * m[j].x; o.y += pj * m[j].y;
+        if (t == j && j < L) p[(long)b * L + j] = pj;
+    }
+    *reinterpret_cast<float2*>(out + (long)b * ldo + 2 * t) = o;
+    if (dropped_b) {                                       // dropout index space is the (B, 2D) matrix [q | out]
+        float hq0 = qv.x, hq1 = qv.y, ho0 = o.x, ho1 = o.y;
+        if (drop.p > 0.f) {
+            const uint32_t dseed = cst_drop_seed(drop);
+            const uint32_t i0 = (uint32_t)((long)b * 2 * D + 2 * t);
+            hq0 *= cst_drop_mask(drop, dseed, i0); hq1 *= cst_drop_mask(drop, dseed, i0 + 1);
+            ho0 *= cst_drop_mask(drop, dseed, i0 + D); ho1 *= cst_drop_mask(drop, dseed, i0 + D + 1);
+        }
+        unsigned* db = reinterpret_cast<unsigned*>(dropped_b + (long)b * lddropb);
+        db[t] = dk_pack2(hq0, hq1);
+        db[D / 2 + t] = dk_pack2(ho0, ho1);
+    }
+}
+
+extern "C" int cst_dec_attn(const float* q, long ldq, const float* mem, float* out, long ldo, float* p, int B, int L, int D,
+                            void* dropped_bf16, long lddropb,
+                            float drop_p, uint32_t drop_seed, uint32_t drop_stream, const void* drop_seed_dev, void* stream) {
+    CST_REQUIRE(q && mem && out && p && B > 0, "cst_dec_attn: null pointer");
+    CST_REQUIRE(D == 512 && L > 0 && L <= 64, "cst_dec_attn: needs D == 512 and L <= 64 (D=%d, L=%d)", D, L);
+    CST_REQUIRE(ldq % 2 == 0 && ldo % 2 == 0 && lddropb % 2 == 0 && ((((uintptr_t)q) | ((uintptr_t)mem) | ((uintptr_t)out)) & 7) == 0 &&
+                (((uintptr_t)dropped_bf16) & 3) == 0, "cst_dec_attn: rows must be 8-byte aligned");
+    CstDrop dr = cst_make_drop(drop_p, drop_seed, drop_stream, drop_seed_dev, (long)B * 2 * D);
+    const float scale = 1.0f / sqrtf((float)D);
+    hipStream_t st = (hipStream_t)stream;
+    if (L <= 24) hipLaunchKernelGGL(dec_attn_kernel<24>, dim3(B), dim3(256), 0, st, q, ldq, mem, out, ldo, p, L, scale, (bf16_t*)dropped_bf16, lddropb, dr);
+    else if (L <= 40) hipLaunchKernelGGL(dec_attn_kernel<40>, dim3(B), dim3(256), 0, st, q, ldq, mem, out, ldo, p, L, scale, (bf16_t*)dropped_bf16, lddropb, dr);
+    else hipLaunchKernelGGL(dec_attn_kernel<64>, dim3(B), dim3(256), 0, st, q, ldq, mem, out, ldo, p, L, scale, (bf16_t*)dropped_bf16, lddropb, dr);
+    CST_LAUNCH_CHECK("cst_dec_attn");
+    return CST_OK;
+}
+
+// =============================================================================================
+// cst_gemm_bf16_skinny: C / Cb [M, N] = act(A[M, K] . B[N, K]^T + bias), whole K in LDS, 32 x 32 tiles, no K split
+// =============================================================================================
+struct SkinnyArgs {
+    const bf16_t* A; long lda; const bf16_t* B; long ldb;
+    float* C; long ldc; bf16_t* Cb; long ldcb;
+    const float* bias; int act;               // 0 none, 1 relu, 2 LeakyReLU(0.1)
+    int M, N, K;
+};
+
+// 512 threads: 8 waves issue the DMA pieces; wave (kh, wm, wn) = (wave >> 2, (wave >> 1) & 1, wave & 1) multiplies the 16 x 16 output
+// tile (wm, wn) over the K-tiles of parity kh, and the two halves are added through LDS in a fixed order (kh = 0 first).
+__global__ __launch_bounds__(512) void gemm_bf16_skinny_kernel(SkinnyArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char dk_smem[];
+    const int nkt = a.K >> 6;
+    char* As = dk_smem;
+    char* Bs = dk_smem + nkt * 32 * 128;
+    const int m0 = blockIdx.x * 32, n0 = blockIdx.y * 32;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    dk_issue_panel<32, 8>(Bs, 0, nkt, wave, lane, [&](int r) { return a.B + (long)(n0 + r) * a.ldb; });
+    dk_issue_panel<32, 8>(As, 0, nkt, wave, lane, [&](int r) { return a.A + (long)min(m0 + r, a.M - 1) * a.lda; });
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    const int kh = wave >> 2, wm = (wave >> 1) & 1, wn = wave & 1;
+    const int lr = lane & 15, lq = lane >> 4;
+    f32x4_t acc[1] = {(f32x4_t){0.f, 0.f, 0.f, 0.f}};
+    if (nkt & 1) {                                         // odd tile count: the generic loop, wave half kh takes tiles kh, kh + 2, ...
+        for (int kt = kh; kt < nkt; kt += 2) dk_mfma_tile<32, 32, 1, 2>(As, Bs, kt, wm, wn, lr, lq, acc);
+    } else {
+        dk_mfma_all<32, 32, 1, 2, 2>(As, Bs, nkt, wm, wn, lane, acc, kh);
+    }
+    __syncthreads();                                       // fragment reads done: reuse the A region
+    float* ex = reinterpret_cast<float*>(dk_smem);         // [4 tiles][64 lanes][4]
+    if (kh == 1) *reinterpret_cast<f32x4_t*>(ex + ((wave & 3) * 64 + lane) * 4) = acc[0];
+    __syncthreads();
+    if (kh == 1) return;
+    const f32x4_t hi = *reinterpret_cast<const f32x4_t*>(ex + ((wave & 3) * 64 + lane) * 4);
+    const int n = n0 + 16 * wn + lr;
+    const float bv = a.bias ? a.bias[n] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const long m = m0 + 16 * wm + 4 * lq + r;
+        if (m >= a.M) continue;
+        float v = (acc[0][r] + hi[r]) + bv;
+        if (a.act == 1) v = v > 0.f ? v : 0.f;
+        else if (a.act == 2) v = v > 0.f ? v : 0.1f * v;
+        if (a.C) a.C[m * a.ldc + n] = v;
+        if (a.Cb) a.Cb[m * a.ldcb + n] = dk_f2bf(v);
+    }
+}
+
+extern "C" int cst_gemm_bf16_skinny(const void* A, long lda, const void* B, long ldb, float* C, long ldc, void* Cb, long ldcb,
+                                    int M, int N, int K, const float* bias, int act, void* stream) {
+    CST_REQUIRE(A && B && (C || Cb), "cst_gemm_bf16_skinny: null operand");
+    CST_REQUIRE(M > 0 && N > 0 && K > 0 && N % 32 == 0 && K % 64 == 0, "cst_gemm_bf16_skinny: N=%d must be a multiple of 32, K=%d of 64 (M=%d)", N, K, M);
+    CST_REQUIRE((long)(K / 64) * 64 * 128 <= 160 * 1024, "cst_gemm_bf16_skinny: K=%d does not fit the LDS whole (max 1280)", K);
+    CST_REQUIRE(lda >= K && ldb >= K && lda % 8 == 0 && ldb % 8 == 0 && ((((uintptr_t)A) | ((uintptr_t)B)) & 15) == 0,
+                "cst_gemm_bf16_skinny: operands must be 16-byte aligned with leading dimensions >= K, multiples of 8");
+    CST_REQUIRE((!C || ldc >= N) && (!Cb || ldcb >= N) && act >= 0 && act <= 2, "cst_gemm_bf16_skinny: bad output leading dimension or activation");
+    SkinnyArgs a;
+    a.A = (const bf16_t*)A; a.lda = lda; a.B = (const bf16_t*)B; a.ldb = ldb; a.C = C; a.ldc = ldc; a.Cb = (bf16_t*)Cb; a.ldcb = ldcb;
+    a.bias = bias; a.act = act; a.M = M; a.N = N; a.K = K;
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void*)gemm_bf16_skinny_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(gemm_bf16_skinny_kernel, dim3((M + 31) / 32, N / 32), dim3(512), (size_t)(K / 64) * 64 * 128, (hipStream_t)stream, a);
+    CST_LAUNCH_CHECK("cst_gemm_bf16_skinny");
+    return CST_OK;
+}
+
+// =============================================================================================
+// packed arg-max words -> token ids
+// =============================================================================================
+__global__ void unpack_argmax_kernel(const unsigned long long* __restrict__ packed, int64_t* __restrict__ ids, long n) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    packed += (long)blockIdx.y * DK_AMAX_GROUPS * n;      // step blockIdx.y
+    unsigned long long best = 0ull;
+#pragma unroll
+    for (int g = 0; g < DK_AMAX_GROUPS; ++g) {
+        const unsigned long long w = packed[(long)g * n + i];
+        best = w > best ? w : best;
+    }
+    ids[(long)blockIdx.y * n + i] = (int64_t)(0xFFFFFFFFu - (unsigned)(best & 0xFFFFFFFFull));
+}
+
+// packed: `steps` blocks of [cst_argmax_groups()][n] words (one block per cst_gemm_bf16_argmax product), ids [steps][n]
+extern "C" int cst_unpack_argmax(const void* packed, int64_t* ids, long n, int steps, void* stream) {
+    CST_REQUIRE(packed && ids && n > 0 && steps > 0 && steps < 65536, "cst_unpack_argmax: bad arguments");
+    hipLaunchKernelGGL(unpack_argmax_kernel, dim3((unsigned)((n + 255) / 256), (unsigned)steps), dim3(256), 0, (hipStream_t)stream,
+                       (const unsigned long long*)packed, ids, n);
+    CST_LAUNCH_CHECK("cst_unpack_argmax");
+    return CST_OK;
+}

@@ -191,9 +191,26 @@ struct BGemmArgs {
     int splits, k_per_split;        // k_per_split multiple of 64
     int slab_only;                  // write the raw partial product(s) to the slab even when splits == 1
     float* slab;
+    unsigned long long* amax;       // optional [AMAX_GROUPS][M]: packed arg-max words of every output row, folded in with 64-bit atomic max (cst_gemm_bf16_argmax)
     int gn;                         // tile columns per XCD strip (0: the default, 8)
     int abl;                        // timing ablations (CST_GB_ABL, tools/gemm_bench.py abl): 1 no DMA, 2 no MFMA, 4 no fragment reads, 8 no write-out
 };
+
+// Bench-only code (tools/gemm_bench.py): the timing ablations and the kernel variants that were measured and never dispatch (256-wide
+// tiles, the loader / consumer kernel, 3- and 4-stage rings) are compiled only with -DCST_BENCH_VARIANTS (CST_BENCH_VARIANTS=1 python -m
+// consistent__style_transfer_amd.build --force); the shipped library holds neither, so a leaked CST_GB_ABL cannot corrupt a run.
+#ifdef CST_BENCH_VARIANTS
+#define BGEMM_ABL(g) ((g).abl)
+#else
+#define BGEMM_ABL(g) 0
+#endif
+extern "C" int cst_bench_variants() {
+#ifdef CST_BENCH_VARIANTS
+    return 1;
+#else
+    return 0;
+#endif
+}
 
 constexpr int BBK = 64;             // bf16 elements of K per tile = 128 bytes per row
 constexpr int BROW = 128;
@@ -228,6 +245,32 @@ __device__ __forceinline__ u32x2_t lds_read64_tr(unsigned addr) {
 // byte offset of 16-byte chunk ch (0..15) of row `row` in the [64 k][128 x bf16] transposed-read image
 __device__ __forceinline__ int tlds_off(int row, int ch) { return row * 256 + 16 * (ch ^ (((row & 3) << 2) | ((row >> 2) & 3))); }
 
+// Arg-max of a row as ONE 64-bit word that an atomic max can maintain in any arrival order: the high half orders like the float
+// (sign-flipped bits), the low half is the inverted column index, so among equal values the FIRST column wins -- torch.argmax's answer
+// (rnn.py:53, :92).  A zeroed word is below every real entry.
+__device__ __forceinline__ unsigned long long bgemm_pack_max(float v, int idx) {
+    unsigned u = __float_as_uint(v);
+    u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+    return ((unsigned long long)u << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)idx);
+}
+template <int CTRL>
+__device__ __forceinline__ int cst_dpp_i(int v, int old) { return __builtin_amdgcn_update_dpp(old, v, CTRL, 0xf, 0xf, false); }
+__device__ __forceinline__ int row16_min_i(int v) {
+    v = min(v, cst_dpp_i<0xB1>(v, v));
+    v = min(v, cst_dpp_i<0x4E>(v, v));
+    v = min(v, cst_dpp_i<0x141>(v, v));
+    v = min(v, cst_dpp_i<0x140>(v, v));
+    return v;
+}
+
+// One word per row would put all 2 * N / 128 atomics of a row -- and of its seven neighbours -- on ONE 64-byte line: 40 000 atomics of a
+// 256 x 10 000 product on 32 lines, serialised at the memory side (+6 us on a 13 us launch; +3 us with 16 words per row).  So a row owns
+// CST_AMAX_GROUPS words, one per group of column tiles (128-column tile index mod 32), group-major [group][M]: the consumer takes the max.
+#define CST_AMAX_GROUPS 32
+__device__ __forceinline__ unsigned long long* bgemm_amax_word(const BGemmArgs& g, int m, int n) {
+    return g.amax + (long)((n >> 7) & (CST_AMAX_GROUPS - 1)) * g.M + m;
+}
+
 __device__ __forceinline__ void bgemm_store(const BGemmArgs& g, uint32_t dseed, int m, int n, float acc) {
     if (g.bscale) acc *= g.bscale[n];
     float v = g.alpha * acc + (g.bias ? g.bias[n] : 0.f);
@@ -239,6 +282,7 @@ __device__ __forceinline__ void bgemm_store(const BGemmArgs& g, uint32_t dseed, 
     if (g.drop.p > 0.f) v *= cst_drop_mask(g.drop, dseed, (uint32_t)((long)m * g.N + n));
     if (g.C) { float* cp = g.C + (long)m * g.ldc + n; if (g.accumulate) v += *cp; *cp = v; }
     if (g.Cb) g.Cb[(long)m * g.ldcb + n] = f2bf16(v);
+    if (g.amax) atomicMax(bgemm_amax_word(g, m, n), bgemm_pack_max(v, n));
 }
 
 // Which of the epilogue's streams can move as 16-byte (fp32) / 8-byte (bf16) vectors: four
@@ -285,6 +329,12 @@ __device__ __forceinline__ void bgemm_store4(const BGemmArgs& g, uint32_t dseed,
         u.x = (uint32_t)f2bf16(o[0]) | ((uint32_t)f2bf16(o[1]) << 16);
         u.y = (uint32_t)f2bf16(o[2]) | ((uint32_t)f2bf16(o[3]) << 16);
         *reinterpret_cast<uint2*>(g.Cb + (long)m * g.ldcb + n) = u;
+    }
+    if (g.amax) {
+        float bv = o[0]; int bi = n;
+#pragma unroll
+        for (int e = 1; e < 4; ++e) if (o[e] > bv) { bv = o[e]; bi = n + e; }
+        atomicMax(bgemm_amax_word(g, m, n), bgemm_pack_max(bv, bi));
     }
 }
 
@@ -388,6 +438,16 @@ __device__ __forceinline__ void bgemm_write_rows_t(const BGemmArgs& g, uint32_t 
                 u.x = (uint32_t)f2bf16(o[0]) | ((uint32_t)f2bf16(o[1]) << 16);
                 u.y = (uint32_t)f2bf16(o[2]) | ((uint32_t)f2bf16(o[3]) << 16);
                 *reinterpret_cast<uint2*>(cbp + i * cb4) = u;
+            }
+            if (g.amax) {
+                // the 16 lanes of a DPP row hold the 64 columns of one output row: reduce to (largest value, first column) and
+                // fold the piece into the row's packed word (all 64 lanes are active here: the sub-tile is whole)
+                float bv = o[0]; int bi = n;
+#pragma unroll
+                for (int e = 1; e < 4; ++e) if (o[e] > bv) { bv = o[e]; bi = n + e; }
+                const float rm = row16_max(bv);
+                const int ri = row16_min_i(bv == rm ? bi : 0x7fffffff);
+                if ((lane & 15) == 0) atomicMax(bgemm_amax_word(g, m0 + r4 + 4 * (b0 + i), n0), bgemm_pack_max(rm, ri));
             }
         }
         if (cp) cp += NB * c4;
@@ -502,7 +562,7 @@ __global__ __launch_bounds__(64 * NW) void cst_gemm_bf16_kernel(BGemmArgs g) {
     const int nk = (kend - kbeg) / BBK;
 
     auto issue = [&](int t) {
-        if (g.abl & 1) return;
+        if (BGEMM_ABL(g) & 1) return;
         char* st = smem + (t % NSTAGE) * ST_BYTES;
         const int k = kbeg + t * BBK;
         const long ka = TT ? (long)k * g.lda : k, kb = TT ? (long)k * g.ldb : k;     // TT: k advances rows
@@ -602,16 +662,16 @@ __global__ __launch_bounds__(64 * NW) void cst_gemm_bf16_kernel(BGemmArgs g) {
         };
         // NT: both 32-wide k halves are requested before the first MFMA (the second half's reads retire under
         // the first half's MFMAs); TT issues twice as many (64-bit) reads, more than lgkmcnt can count: half by half
-        if (!(g.abl & 4)) read_half(0);
+        if (!(BGEMM_ABL(g) & 4)) read_half(0);
         if constexpr (!TT) {
-            if (!(g.abl & 4)) read_half(1);
+            if (!(BGEMM_ABL(g) & 4)) read_half(1);
             asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(TM + TN) : "memory");      // first half landed
         } else {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
         __builtin_amdgcn_sched_barrier(0);
         widen(0);
-        if (!(g.abl & 2))
+        if (!(BGEMM_ABL(g) & 2))
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -622,7 +682,7 @@ __global__ __launch_bounds__(64 * NW) void cst_gemm_bf16_kernel(BGemmArgs g) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
         widen(1);
-        if (!(g.abl & 2))
+        if (!(BGEMM_ABL(g) & 2))
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -631,7 +691,7 @@ __global__ __launch_bounds__(64 * NW) void cst_gemm_bf16_kernel(BGemmArgs g) {
                                                                     __builtin_bit_cast(bf16x8_t, bfr[1][j]), acc[i][j], 0, 0, 0);
     }
     __syncthreads();                                  // all tile reads done before smem is reused for C
-    if (g.abl & 8) return;
+    if (BGEMM_ABL(g) & 8) return;
 
     if (g.splits > 1 || g.slab_only) {
         float* slab = g.slab + (((long)blockIdx.z * g.splits + blockIdx.y) * g.M) * g.N;
@@ -731,6 +791,7 @@ extern bool cst_prof_on();
 extern void cst_prof_push(hipEvent_t a, hipEvent_t b, double flops, double bytes, int which);
 extern void cst_prof_push_shape(hipEvent_t a, hipEvent_t b, double flops, double bytes, int which, int m, int n, int k);
 
+#ifdef CST_BENCH_VARIANTS
 // =============================================================================================
 // 256 x 256 tile, 8 waves, K-tiles of 32 in a 4-stage ring (after cdna_hip_programming.md section 5, "The 256^2 8-phase
 // template"): the encoder-layer products with N >= 1536 (packed QKV, FFN1, and the dgrad of FFN2).
@@ -1214,6 +1275,8 @@ static int bgemm_big_launch_t(const BGemmArgs& g, hipStream_t st) {
 }
 
 
+#endif   // CST_BENCH_VARIANTS
+
 template <int BM, int BN, int NSTAGE, bool TT = false, bool BF8 = false, int NW = 4>
 static int bgemm_launch(const BGemmArgs& g, hipStream_t st) {
     const size_t lds = (size_t)NSTAGE * (BM * BROW + BN * (BF8 ? 64 : BROW));
@@ -1326,12 +1389,12 @@ extern "C" long cst_gemm_bf16_lstm_workspace_floats(int M, int N, int K, int pro
     return (long)problems * splits * M * N;
 }
 
-extern "C" int cst_gemm_bf16(const void* A, long lda, const void* B, long ldb,
-                             float* C, long ldc, void* Cb, long ldcb, int M, int N, int K,
-                             const float* bias, const float* addend, long ldadd, const void* aux, long ldaux,
-                             int act, float gate_scale, float alpha, int accumulate,
-                             float drop_p, uint32_t drop_seed, uint32_t drop_stream, const void* drop_seed_dev,
-                             int tile, int splitk, float* workspace, long workspace_floats, void* stream) {
+static int bgemm_entry(const void* A, long lda, const void* B, long ldb,
+                       float* C, long ldc, void* Cb, long ldcb, int M, int N, int K,
+                       const float* bias, const float* addend, long ldadd, const void* aux, long ldaux,
+                       int act, float gate_scale, float alpha, int accumulate,
+                       float drop_p, uint32_t drop_seed, uint32_t drop_stream, const void* drop_seed_dev,
+                       int tile, int splitk, float* workspace, long workspace_floats, void* stream, unsigned long long* amax) {
     CST_REQUIRE(A && B && (C || Cb), "cst_gemm_bf16: null operand");
     CST_REQUIRE(M > 0 && N > 0 && K > 0 && K % 64 == 0, "cst_gemm_bf16: K=%d must be a positive multiple of 64 (zero-padded operands)", K);
     CST_REQUIRE(lda >= K && ldb >= K && lda % 8 == 0 && ldb % 8 == 0, "cst_gemm_bf16: lda/ldb must be >= K and multiples of 8");
@@ -1345,7 +1408,12 @@ extern "C" int cst_gemm_bf16(const void* A, long lda, const void* B, long ldb,
     g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.ldcb = ldcb; g.ldadd = ldadd; g.ldaux = ldaux;
     g.M = M; g.N = N; g.K = K; g.act = act; g.alpha = alpha; g.gate_scale = gate_scale; g.accumulate = accumulate;
     g.slab_only = 0;
-    { const char* ab = getenv("CST_GB_ABL"); g.abl = ab ? atoi(ab) : 0; }       // bench-only timing ablations (wrong results)
+    g.amax = amax;
+#ifdef CST_BENCH_VARIANTS
+    { const char* ab = getenv("CST_GB_ABL"); g.abl = ab ? atoi(ab) : 0; }       // timing ablations (tools/gemm_bench.py abl): WRONG results
+#else
+    g.abl = 0;
+#endif
     { static const int gn_env = getenv("CST_GEMM_GN") ? atoi(getenv("CST_GEMM_GN")) : 0; g.gn = gn_env; }
     g.drop = cst_make_drop(drop_p, drop_seed, drop_stream, drop_seed_dev, (long)M * N);
     // tile / ring / split choice (tools/gemm_bench.py bf16nt): the 2-stage ring with two workgroups per
@@ -1364,6 +1432,10 @@ extern "C" int cst_gemm_bf16(const void* A, long lda, const void* B, long ldb,
     CST_REQUIRE(splits == 1 || workspace, "cst_gemm_bf16: split-K needs a workspace");
     g.splits = splits; g.slab = workspace;
     hipStream_t st = (hipStream_t)stream;
+#ifndef CST_BENCH_VARIANTS
+    if (tile == 256 || tile == 252 || tile == 248) tile = 0;     // bench-only kernels: not in this build
+    ring = 0;
+#else
     // 256 x 256 / 8-wave kernel: tile code 256 forces it; by itself it takes the products whose 256^2 tiles fill at least
     // half the chip and at most one round of it, or several rounds (measured rule, tools/gemm_bench.py bf16nt)
     {
@@ -1388,9 +1460,16 @@ extern "C" int cst_gemm_bf16(const void* A, long lda, const void* B, long ldb,
         if (tile == 256 || tile == 252) { tile = 0; }
     }
     if (ring == 0 && getenv("CST_RING4") && !use_big && tiles * splits <= 256 && g.k_per_split >= 256) ring = 2;
+#endif
+    (void)tiles;
     if (use_big && (w8 || w8_auto) && ring == 0) bgemm_launch<128, 128, 2, false, false, 8>(g, st);
-    else if (use_big) { if (ring == 1) bgemm_launch<128, 128, 3>(g, st); else bgemm_launch<128, 128, 2>(g, st); }
-    else { if (ring == 2) bgemm_launch<64, 128, 4>(g, st); else if (ring == 1) bgemm_launch<64, 128, 3>(g, st); else bgemm_launch<64, 128, 2>(g, st); }
+#ifdef CST_BENCH_VARIANTS
+    else if (use_big && ring == 1) bgemm_launch<128, 128, 3>(g, st);
+    else if (!use_big && ring == 2) bgemm_launch<64, 128, 4>(g, st);
+    else if (!use_big && ring == 1) bgemm_launch<64, 128, 3>(g, st);
+#endif
+    else if (use_big) bgemm_launch<128, 128, 2>(g, st);
+    else bgemm_launch<64, 128, 2>(g, st);
     CST_LAUNCH_CHECK("cst_gemm_bf16");
     if (splits > 1) {
         long mn = ((long)M * N + 3) / 4;          // four columns per thread on the vector path
@@ -1401,6 +1480,29 @@ extern "C" int cst_gemm_bf16(const void* A, long lda, const void* B, long ldb,
         CST_LAUNCH_CHECK("cst_gemm_bf16_reduce");
     }
     return CST_OK;
+}
+
+extern "C" int cst_gemm_bf16(const void* A, long lda, const void* B, long ldb,
+                             float* C, long ldc, void* Cb, long ldcb, int M, int N, int K,
+                             const float* bias, const float* addend, long ldadd, const void* aux, long ldaux,
+                             int act, float gate_scale, float alpha, int accumulate,
+                             float drop_p, uint32_t drop_seed, uint32_t drop_stream, const void* drop_seed_dev,
+                             int tile, int splitk, float* workspace, long workspace_floats, void* stream) {
+    return bgemm_entry(A, lda, B, ldb, C, ldc, Cb, ldcb, M, N, K, bias, addend, ldadd, aux, ldaux, act, gate_scale, alpha, accumulate,
+                       drop_p, drop_seed, drop_stream, drop_seed_dev, tile, splitk, workspace, workspace_floats, stream, nullptr);
+}
+
+extern "C" int cst_argmax_groups() { return CST_AMAX_GROUPS; }
+
+// C[M, N] = A[M, K] . B[N, K]^T (fp32, no epilogue operands) and, per row, the packed arg-max word of bgemm_pack_max folded into
+// amax_packed[group][m] with atomic max: the caller zeroes the words first and may spread one row's columns over several calls.  No K split
+// (the epilogue that sees whole sums must be the GEMM's own).  Decoder: the fn_2 product of one decode step (rnn.py:80) whose arg-max
+// feeds the next step (rnn.py:83-92); decode.hip.
+extern "C" int cst_gemm_bf16_argmax(const void* A, long lda, const void* B, long ldb, float* C, long ldc, int M, int N, int K,
+                                    void* amax_packed, void* stream) {
+    CST_REQUIRE(C && amax_packed && (((uintptr_t)amax_packed) & 7) == 0, "cst_gemm_bf16_argmax: null / misaligned output");
+    return bgemm_entry(A, lda, B, ldb, C, ldc, nullptr, 0, M, N, K, nullptr, nullptr, 0, nullptr, 0, 0, 1.f, 1.f, 0,
+                       0.f, 0, 0, nullptr, 64, 1, nullptr, 0, stream, (unsigned long long*)amax_packed);
 }
 
 extern "C" int cst_gemm_bf16_tt(const void* A, long lda, const void* B, long ldb, float* C, long ldc, int M, int N, int K,

@@ -8,10 +8,12 @@ fused LSTM cell, single-query attention, fn_1 (+LeakyReLU), fn_2 straight into t
 gradients are NOT accumulated step by step: per-step activations and gate gradients are kept and
 each weight gets one large wgrad GEMM after the loop.
 """
+import os
+
 import torch
 
 from . import ops
-from ._lib import call
+from ._lib import call, call_plain
 from .ops import (NO_DROP, STREAM_G_EMB_IN, STREAM_G_FFN, STREAM_G_XT, act_bwd, argmax_rows, axpby, cast_bf16, colsum,
                   dgrad, dropout2d, embed_gather, embed_scatter_add, gemm, gemm_bf16, linear_fwd, softmax_tau,
                   softmax_tau_bwd, weight_bf16, wgrad)
@@ -228,7 +230,41 @@ class GeneratorFn(torch.autograd.Function):
         # shared soft-embedding product over all steps (ops.SharedSoftEmbedFn)
         Vp = (V + 63) // 64 * 64
         outb = _i16(dev, B, T * Vp) if (soft and use_b and V % 4 == 0 and V <= 16384) else None
-        for s in range(T):
+        # Fast decode loop (csrc/decode.hip): four launches per step, none a split-K reduce -- cst_dec_gates (token choice + embedding +
+        # gates + cell), cst_dot_attn_fwd, cst_gemm_bf16_skinny (fn_1), cst_gemm_bf16_argmax (fn_2 + the row arg-max the next step feeds
+        # back).  The soft decode's softmax runs ONCE after the loop over all T steps (the recurrence only needs the arg-max).
+        fast = (use_b and E == 128 and Hd % 16 == 0 and (B * T) % 64 == 0 and W_ % 64 == 0 and W_ <= 1280 and Hd % 32 == 0
+                and V % 4 == 0 and V <= 16384 and call_plain("cst_dec_gates_lds_bytes", E, Hd) <= 160 * 1024 and os.environ.get("CST_DECODE_SLOW") != "1")
+        if fast:
+            NG = call_plain("cst_argmax_groups")
+            amax = ops.zeros(T, NG, B, device=dev, dtype=torch.int64)      # packed (logit, first index) words: NG per row and step
+            for s in range(T):
+                c_in = c0 if s == 0 else cdec[s - 1]
+                i_s = if2[:, s * W_:(s + 1) * W_]
+                idb_s = ifdb[:, s * W_:(s + 1) * W_]
+                hb_next = XHb[s + 1][:, E:] if s + 1 < T else None
+                teacher = x_c[:, s - 1] if (s > 0 and not soft and x_c is not None) else None
+                xd = drop.at(STREAM_G_XT + s - 1) if s > 0 else NO_DROP
+                call("cst_dec_gates", XHb[s], XHb[s].stride(0), wcat_b, wcat_b.stride(0),
+                     amax[s - 1] if s > 0 else None, teacher, T if teacher is not None else 0,
+                     coins[s - 1:s] if teacher is not None else None, E_tok, E_tok.stride(0), V, *xd.args(),
+                     XHb[s] if s > 0 else None, XHb[s].stride(0), bdec, c_in, c_in.stride(0),
+                     gdec[s], gdec[s].stride(0), cdec[s], cdec[s].stride(0), i_s[:, :Hd], T * W_, hb_next, _st(hb_next), B, E, Hd)
+                if Hd == 512 and Lp <= 64:
+                    call("cst_dec_attn", i_s[:, :Hd], T * W_, memory, i_s[:, Hd:], T * W_, patt[s], B, Lp, Hd,
+                         idb_s, T * W_, *drop.at(STREAM_G_FFN + s).args())
+                else:
+                    call("cst_dot_attn_fwd", i_s[:, :Hd], T * W_, memory, i_s[:, Hd:], T * W_, patt[s], B, Lp, Hd,
+                         None, 0, idb_s, T * W_, *drop.at(STREAM_G_FFN + s).args())
+                r1b_s = r1b[:, s * Hd:(s + 1) * Hd]
+                call("cst_gemm_bf16_skinny", idb_s, T * W_, fn1_b, fn1_b.stride(0), r12[:, s * Hd:(s + 1) * Hd], T * Hd, r1b_s, T * Hd,
+                     B, Hd, W_, P["fn_1.bias"], 2)
+                call("cst_gemm_bf16_argmax", r1b_s, T * Hd, fn2_b, fn2_b.stride(0), out2[:, s * V:(s + 1) * V], T * V, B, V, Hd, amax[s])
+            call("cst_unpack_argmax", amax, ids_fb, B, T)
+            if soft:
+                o2 = out.view(B * T, V)
+                softmax_tau(o2, inv_tau, o2, None, gather=None, p_b=outb.view(B * T, Vp) if outb is not None else None)
+        for s in (() if fast else range(T)):
             c_in = c0 if s == 0 else cdec[s - 1]
             h_next = XH[s + 1][:, E:] if s + 1 < T else None
             i_s = if2[:, s * W_:(s + 1) * W_]

@@ -321,6 +321,50 @@ int cst_gemm_bf16_lstm_attn(const void* A, long lda, const void* B, long ldb, in
                             float* dropped, long lddrop, void* dropped_bf16, long lddropb,
                             float drop_p, uint32_t drop_seed, uint32_t drop_stream, const void* drop_seed_dev,
                             int splitk, float* workspace, long workspace_floats, void* stream);
+/* ---- decoder step in four launches (csrc/decode.hip; rnn.py:72-97) --------------------------------------------------
+ * cst_dec_gates: one decode step's LSTM cell, input side included (rnn.py:74, :88-96).
+ *   A [B, E + Hd] bf16 = [x_t | h_{t-1}].  With amax_prev != NULL the x columns are not read: x_t = dropout(table[token]) is
+ *   built in the kernel, token = the previous step's arg-max (packed words amax_prev[g][b], see cst_gemm_bf16_argmax) or, when
+ *   ids_teacher != NULL and (coin_dev == NULL or *coin_dev == 0), the teacher token ids_teacher[b * ldids] (scheduled sampling,
+ *   rnn.py:91-94: the coin is a device word so a captured graph stays static); dropout (p, seed, stream) over the (B, E) index
+ *   space (rnn.py:96); its bf16 copy goes to x_bf16_out (operand of the weight gradient; may be A's own x columns).
+ *   W [4 Hd, E + Hd] bf16 = [W_ih | W_hh], bias [4 Hd] = b_ih + b_hh; gates (i, f, g, o ACTIVATED, what the backward pass reads),
+ *   c_out, h_out fp32; h_bf16_next (may be NULL) = the h columns of the next step's A.  Whole K in LDS (cst_dec_gates_lds_bytes),
+ *   32 rows x 16 hidden units per workgroup, no K split, no reduce launch.  Needs Hd % 16 == 0, E == 128. */
+long cst_dec_gates_lds_bytes(int E, int Hd);
+int cst_dec_gates(const void* A, long lda, const void* W, long ldw,
+                  const void* amax_prev, const int64_t* ids_teacher, long ldids, const int* coin_dev,
+                  const float* table, long ldtab, int V,
+                  float drop_p, uint32_t drop_seed, uint32_t drop_stream, const void* drop_seed_dev,
+                  void* x_bf16_out, long ldxb, const float* bias, const float* c_prev, long ldcp,
+                  float* gates, long ldg, float* c_out, long ldc, float* h_out, long ldh, void* h_bf16_next, long ldhb,
+                  int B, int E, int Hd, void* stream);
+/* cst_dot_attn_fwd for the decode loop's shapes (D == 512, L <= 64): out = softmax(q mem^T / sqrt(D)) mem per batch row (rnn.py:46-50,
+ * :76), p = the attention weights (kept for the backward pass), dropped_bf16 (may be NULL) = bf16(dropout([q | out])) over the (B, 2D)
+ * index space = the A operand of fn_1 (rnn.py:79).  The row's encoder states go straight to registers in one burst. */
+int cst_dec_attn(const float* q, long ldq, const float* mem, float* out, long ldo, float* p, int B, int L, int D,
+                 void* dropped_bf16, long lddropb,
+                 float drop_p, uint32_t drop_seed, uint32_t drop_stream, const void* drop_seed_dev, void* stream);
+/* C / Cb [M, N] = act(A[M, K] . B[N, K]^T + bias), bf16 operands with K contiguous, act 0 none / 1 relu / 2 LeakyReLU(0.1): the
+ * M = batch products of a decode step that are too small to split (fn_1, rnn.py:79-80): whole K in LDS (K <= 1280), 32 x 32
+ * tiles, one launch.  N a multiple of 32, K of 64. */
+int cst_gemm_bf16_skinny(const void* A, long lda, const void* B, long ldb, float* C, long ldc, void* Cb, long ldcb,
+                         int M, int N, int K, const float* bias, int act, void* stream);
+/* C[M, N] = A . B^T as cst_gemm_bf16 without epilogue operands, plus the arg-max of every row.  amax_packed: G = cst_argmax_groups()
+ * words of 8 bytes per row, group-major [G][M], zeroed by the caller; word (group of a 128-column tile = tile index mod G, row m)
+ * receives max over the tile's columns of ((order-preserving bits of C[m, n]) << 32 | (0xFFFFFFFF - n)) by 64-bit atomic max -- the
+ * largest value and, among equals, the FIRST column, in any arrival order (torch.argmax, rnn.py:53, :92); the max over a row's G words
+ * is the row's arg-max.  (G words per row, not one: one word would put every atomic of eight rows on a single 64-byte line.)
+ * fn_2 of a decode step (rnn.py:80): the next step's cst_dec_gates reads the words, the loop needs no softmax / arg-max launch. */
+int cst_argmax_groups(void);
+int cst_gemm_bf16_argmax(const void* A, long lda, const void* B, long ldb, float* C, long ldc, int M, int N, int K,
+                         void* amax_packed, void* stream);
+/* ids[s][i] = column index held by the packed arg-max words of row i of product s: packed = `steps` blocks [G][n]
+ * (rnn.py:88-92: the ids fed back; main_optimize.py:104 sample_p.argmax) */
+int cst_unpack_argmax(const void* packed, int64_t* ids, long n, int steps, void* stream);
+/* 1 when the library was built with -DCST_BENCH_VARIANTS (bench-only GEMM variants and timing ablations), else 0 */
+int cst_bench_variants(void);
+
 int cst_gemm_bf16_lstm_bwd(const void* A, long lda, const void* B, long ldb, int M, int H, int K,
                            const float* gates, long ldg, const float* c_prev, long ldcp, const float* c_new, long ldcn,
                            const float* dh_extra, long lddh, const float* dc_in, long lddc,

@@ -1033,3 +1033,135 @@ def test_lstm_seq_bwd_equals_per_step_path(ops):
     assert torch.equal(f_dgb.view(torch.bfloat16), f_dge.to(torch.bfloat16))         # the optional bf16 twin of dgates
     close(f_dge, r_dge, 5e-3, 5e-3)                  # bf16 dgates feedback: rounding-level differences compound over the steps
     close(f_dh0, r_dh0, 5e-3, 5e-3)
+
+
+# ------------------------------------------------------------------------------------------ decoder step kernels (csrc/decode.hip)
+def _bf(t):
+    return t.to(torch.bfloat16).float()
+
+
+@pytest.mark.parametrize("B,Hd,mode", [(16, 64, "teacher"), (40, 512, "feedback"), (256, 512, "teacher"), (256, 512, "first")])
+def test_dec_gates(ops, B, Hd, mode):
+    """rnn.py:74, :88-96: token choice (arg-max word of the previous step / teacher token by the coin), embedding + dropout, gate
+    product over [x_t | h_{t-1}], LSTM cell -- against the same arithmetic in fp32 torch on bf16-rounded operands."""
+    from consistent__style_transfer_amd._lib import call, call_plain
+    E, V = 128, 300
+    K = E + Hd
+    W, bias = rnd(4 * Hd, K, seed=1, scale=0.05), rnd(4 * Hd, seed=2, scale=0.1)
+    table = rnd(V, E, seed=3)
+    hprev, cprev = rnd(B, Hd, seed=4, scale=0.5), rnd(B, Hd, seed=5, scale=0.5)
+    x0 = rnd(B, E, seed=6)
+    g = torch.Generator().manual_seed(7)
+    ids_arg = torch.randint(0, V, (B,), generator=g)
+    ids_t = torch.randint(0, V, (B, 5), generator=g)
+    ids_arg[0] = V + 3                                               # out-of-range id -> zero embedding (as cst_embed_gather does)
+    for coin in ((0, 1) if mode == "teacher" else (1,)):
+        A = torch.zeros(B, K)
+        A[:, :E] = x0
+        A[:, E:] = hprev
+        Ab, _ = ops.cast_bf16(dev(A), want_t=False)
+        Wb, _ = ops.cast_bf16(dev(W), want_t=False)
+        # the row's arg-max word sits in ONE of the NG group slots (a different one per row), the others hold smaller / empty words
+        NG = call_plain("cst_argmax_groups")
+        packed = torch.zeros(NG, B, dtype=torch.int64)
+        packed[torch.arange(B) % NG, torch.arange(B)] = (torch.full((B,), 1 << 40, dtype=torch.int64)) | (0xFFFFFFFF - ids_arg)
+        packed[(torch.arange(B) + 1) % NG, torch.arange(B)] = (torch.full((B,), 1 << 39, dtype=torch.int64)) | (0xFFFFFFFF - 1)
+        packed = packed.cuda()
+        d = ops.Drop(0.1, 5, 203)
+        gates, c_out, h_out = (torch.full((B, n), float("nan"), device="cuda") for n in (4 * Hd, Hd, Hd))
+        hb = torch.zeros(B, Hd, device="cuda", dtype=torch.int16)
+        xb = torch.zeros(B, E, device="cuda", dtype=torch.int16)
+        first = mode == "first"
+        call("cst_dec_gates", Ab, Ab.stride(0), Wb, Wb.stride(0), None if first else packed,
+             dev(ids_t)[:, 2] if mode == "teacher" else None, 5 if mode == "teacher" else 0,
+             torch.tensor([coin], dtype=torch.int32, device="cuda") if mode == "teacher" else None,
+             dev(table), E, V, *d.args(), None if first else xb, E, dev(bias), dev(cprev), Hd,
+             gates, 4 * Hd, c_out, Hd, h_out, Hd, hb, Hd, B, E, Hd)
+        if first:
+            x = _bf(x0)
+        else:
+            tok = ids_arg.clone() if (mode == "feedback" or coin) else ids_t[:, 2].clone()
+            okm = (tok >= 0) & (tok < V)
+            emb = table[tok.clamp(0, V - 1)] * okm[:, None].float()
+            mask = torch.from_numpy(orng.dropout_mask(5, 203, (B, E), 0.1))
+            x = _bf(emb * mask)
+            assert torch.equal(xb.view(torch.bfloat16).float().cpu(), x)
+        pre = torch.cat([x, _bf(hprev)], 1) @ _bf(W).t() + bias
+        i, f, gg, o = (pre[:, q * Hd:(q + 1) * Hd] for q in range(4))
+        i, f, gg, o = torch.sigmoid(i), torch.sigmoid(f), torch.tanh(gg), torch.sigmoid(o)
+        c = f * cprev + i * gg
+        h = o * torch.tanh(c)
+        close(gates, torch.cat([i, f, gg, o], 1), 2e-3, 2e-3, f"gates {mode} coin={coin}")
+        close(c_out, c, 2e-3, 2e-3)
+        close(h_out, h, 2e-3, 2e-3)
+        assert torch.equal(hb.view(torch.bfloat16).float().cpu(), _bf(h_out.cpu()))
+
+
+@pytest.mark.parametrize("shape", [(256, 512, 1024), (16, 64, 128), (40, 1024, 512), (256, 512, 640), (100, 96, 1280)])
+@pytest.mark.parametrize("act", [0, 2])
+def test_gemm_bf16_skinny(ops, shape, act):
+    from consistent__style_transfer_amd._lib import call
+    M, N, K = shape
+    A, Bm, bias = rnd(M, K, seed=1), rnd(N, K, seed=2), rnd(N, seed=3)
+    Ab, _ = ops.cast_bf16(dev(A), want_t=False)
+    Bb, _ = ops.cast_bf16(dev(Bm), want_t=False)
+    C = torch.full((M, N), float("nan"), device="cuda")
+    Cb = torch.zeros(M, N, device="cuda", dtype=torch.int16)
+    call("cst_gemm_bf16_skinny", Ab, Ab.stride(0), Bb, Bb.stride(0), C, N, Cb, N, M, N, K, dev(bias), act)
+    ref = _bf(A) @ _bf(Bm).t() + bias
+    if act == 2:
+        ref = torch.where(ref > 0, ref, 0.1 * ref)
+    close(C, ref, 2e-3, 2e-3 * math.sqrt(K), f"{shape}")
+    assert torch.equal(Cb.view(torch.bfloat16).float().cpu(), _bf(C.cpu()))
+
+
+@pytest.mark.parametrize("shape", [(256, 10000, 512), (16, 208, 512), (70, 1000, 64), (256, 384, 128)])
+def test_gemm_bf16_argmax(ops, shape):
+    """fn_2 of a decode step with the row arg-max folded into packed words by atomic max: the product equals cst_gemm_bf16, the ids
+    equal torch.argmax of THAT product -- the first index among equal maxima (duplicated weight rows force exact ties)."""
+    from consistent__style_transfer_amd._lib import call, call_plain
+    M, N, K = shape
+    A, Bm = rnd(M, K, seed=1), rnd(N, K, seed=2)
+    Bm[N // 2 + 5] = Bm[7]                                  # columns 7 and N/2 + 5 tie exactly in every row
+    Bm[N - 1] = Bm[3]
+    A[:, :] = A.abs()                                       # and make those columns likely maxima of some rows
+    Bm[7] = Bm[7].abs() * 3
+    Bm[N // 2 + 5] = Bm[7]
+    Ab, _ = ops.cast_bf16(dev(A), want_t=False)
+    Bb, _ = ops.cast_bf16(dev(Bm), want_t=False)
+    C = torch.full((M, N), float("nan"), device="cuda")
+    NG = call_plain("cst_argmax_groups")
+    packed = torch.zeros(NG, M, device="cuda", dtype=torch.int64)
+    call("cst_gemm_bf16_argmax", Ab, Ab.stride(0), Bb, Bb.stride(0), C, N, M, N, K, packed)
+    C2 = torch.empty(M, N, device="cuda")
+    ops.gemm_bf16(Ab, Bb, M, N, C=C2, tile=64, splitk=1)
+    assert torch.equal(C, C2)
+    ids = torch.empty(M, device="cuda", dtype=torch.int64)
+    call("cst_unpack_argmax", packed, ids, M, 1)
+    ref = C.cpu().argmax(-1)                                 # torch returns the first maximal index
+    assert torch.equal(ids.cpu(), ref)
+    assert int((ref == 7).sum()) > 0                         # the tie really decides rows
+    # a second call on the same words with the same data changes nothing (max is idempotent) ...
+    before = packed.clone()
+    call("cst_gemm_bf16_argmax", Ab, Ab.stride(0), Bb, Bb.stride(0), C, N, M, N, K, packed)
+    assert torch.equal(packed, before)
+
+
+@pytest.mark.parametrize("B,L", [(16, 8), (256, 18), (40, 39), (8, 64)])
+def test_dec_attn(ops, B, L):
+    """rnn.py:46-50, :76, :79 for the decode loop's shapes: attention output, weights and the dropped bf16 FFN input."""
+    from consistent__style_transfer_amd._lib import call
+    D = 512
+    q, mem = rnd(B, D, seed=1), rnd(B, L, D, seed=2)
+    out = torch.full((B, D), float("nan"), device="cuda")
+    p = torch.full((B, L), float("nan"), device="cuda")
+    db = torch.zeros(B, 2 * D, device="cuda", dtype=torch.int16)
+    d = ops.Drop(0.1, 9, 104)
+    call("cst_dec_attn", dev(q), D, dev(mem), out, D, p, B, L, D, db, 2 * D, *d.args())
+    a = torch.softmax(torch.einsum("bd,bld->bl", q, mem) / math.sqrt(D), -1)
+    ref = torch.einsum("bl,bld->bd", a, mem)
+    close(p, a, 2e-4, 1e-6)
+    close(out, ref, 2e-4, 1e-5)
+    mask = torch.from_numpy(orng.dropout_mask(9, 104, (B, 2 * D), 0.1))
+    want = _bf(torch.cat([q, out.cpu()], 1) * mask)
+    assert torch.equal(db.view(torch.bfloat16).float().cpu(), want)
