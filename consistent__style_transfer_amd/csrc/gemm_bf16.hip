@@ -898,6 +898,7 @@ __global__ __launch_bounds__(256 * WR, 2) void cst_gemm_bf16_big_kernel(BGemmArg
     const int src_slot = (lane & 3) ^ gsw;
     const bf16_t* abase = g.A + (long)(m0 + (lane >> 2)) * g.lda + (src_slot << 3);
     const bf16_t* bbase = g.B + (long)(n0 + (lane >> 2)) * g.ldb + (src_slot << 3);
+    const int nk = g.K / GB_K;
     auto issue_a = [&](int t) {
         if (abl & 1) return;
         char* st = smem + (t % NST) * STAGE;
@@ -918,7 +919,6 @@ __global__ __launch_bounds__(256 * WR, 2) void cst_gemm_bf16_big_kernel(BGemmArg
             __builtin_amdgcn_global_load_lds((gbl_ptr_t)(bbase + (long)r0 * g.ldb + k), (lds_ptr_t)(st + r0 * GB_ROW), 16, 0, 0);
         }
     };
-    const int nk = g.K / GB_K;
 
     f32x4_t acc[8][4];
 #pragma unroll
