@@ -141,6 +141,9 @@ def _cgroup_cpu_quota():
     return None
 
 
+CORE_INFO = {}          # what physical_cores() found: host cores, affinity, cgroup quota, the CST_CPU_THREADS cap, threads used
+
+
 def physical_cores():
     """Host cores this job may actually use: distinct (physical id, core id) pairs of /proc/cpuinfo (SMT siblings counted
     once), capped by the CPU affinity mask, by the cgroup CPU quota and by CST_CPU_THREADS (default 16: the CPU share of a
@@ -159,14 +162,21 @@ def physical_cores():
     except OSError:
         pass
     n = len(seen) or (os.cpu_count() or 1)
+    CORE_INFO["physical_cores_of_host"] = n
     try:
-        n = min(n, len(os.sched_getaffinity(0)))
+        aff = len(os.sched_getaffinity(0))
+        CORE_INFO["affinity_cpus"] = aff
+        n = min(n, aff)
     except (AttributeError, OSError):
         pass
     q = _cgroup_cpu_quota()
+    CORE_INFO["cgroup_cpu_quota"] = q
     if q:
         n = min(n, q)
-    n = min(n, int(os.environ.get("CST_CPU_THREADS", "16")))
+    cap = int(os.environ.get("CST_CPU_THREADS", "16"))
+    CORE_INFO["thread_cap"] = cap
+    n = min(n, cap)
+    CORE_INFO["threads_used"] = max(1, n)
     return max(1, n)
 
 
@@ -235,12 +245,51 @@ def cpu_baseline(w, workload):
     w0 = WORKLOADS["yelp_2l_d256_b32"]
     c0 = _cpu_stage_times(w0, w0["B"], cores)
     tot0 = sum(v["ms_per_step"] for v in c0.values()) * 1e-3
-    return {"value": Bc / tot, "unit": "sentences/s", "cores": cores, "kind": "port",
-            "sample": f"oracle (plain torch fp32, torch.set_num_threads({cores}) = physical cores) on {workload} at batch {Bc}: "
+    return {"value": Bc / tot, "unit": "sentences/s", "cores": cores, "kind": "port", "core_accounting": dict(CORE_INFO),
+            "sample": f"oracle (plain torch fp32, torch.set_num_threads({cores}): min of the host's physical cores, the affinity mask, the cgroup CPU "
+                      f"quota and the CST_CPU_THREADS cap -- see core_accounting) on {workload} at batch {Bc}: "
                       f"3 warm-up + {min(v['timed_steps'] for v in head.values())} timed steps per stage (pretrain, warmup, optimize G+D)",
             "per_stage": {k: {**v, "sentences_per_s": Bc / (v["ms_per_step"] * 1e-3)} for k, v in head.items()},
             "configs0": {"workload": "yelp_2l_d256_b32", "batch": w0["B"], "value": w0["B"] / tot0, "unit": "sentences/s",
                          "per_stage": {k: {**v, "sentences_per_s": w0["B"] / (v["ms_per_step"] * 1e-3)} for k, v in c0.items()}}}
+
+
+def host_path(w, pretrain_sentences_per_s):
+    """the pretrain stage's host side.  collate_pretrain needs one Word Mover's Distance per sentence
+    (src/loader.py:60 -> src/wmd.py:31-45); libcst_host.so solves a whole batch per call (csrc/host_wmd.cpp).  Measured here on
+    Yelp-shaped synthetic pairs (two independently noised copies of a batch, 100-dimensional unit word vectors for every id):
+    labels / s on one core and on all cores of this box, next to what the GPU's pretrain step consumes."""
+    import numpy as np
+    from consistent__style_transfer_amd import synthetic as syn
+    from consistent__style_transfer_amd.wmd import WMDdistance, WordVectors
+    B, L, V = w["B"], w["L"], w["V"]
+    rs = np.random.RandomState(0)
+    wv = WordVectors([str(i) for i in range(V)], rs.randn(V, 100))
+
+    class Tok:
+        def ids_to_tokens(self, ids):
+            return [str(i) for i in ids]
+
+        def __len__(self):
+            return V
+
+    wm, tok = WMDdistance(wv), Tok()
+    bp = syn.pretrain_batch(B, L, V, 5)
+    strip = lambda t: [[int(v) for v in row if v != 0] for row in t.tolist()]
+    n1, n2 = strip(bp[1]), strip(bp[2])
+    cores = physical_cores()
+    out = {}
+    for name, nt in (("one_core", 1), ("box", cores)):
+        wm.cal_wmd_label(n1, n2, tok, nthreads=nt)
+        t0, n = time.time(), 0
+        while time.time() - t0 < 1.5:
+            wm.cal_wmd_label(n1, n2, tok, nthreads=nt)
+            n += B
+        out[name] = n / (time.time() - t0)
+    return {"labels_per_s_per_core": out["one_core"], "labels_per_s_box": out["box"], "threads": cores,
+            "pretrain_consumes_sentences_per_s": pretrain_sentences_per_s,
+            "cores_needed_at_this_rate": pretrain_sentences_per_s / out["one_core"] if pretrain_sentences_per_s else None,
+            "note": "exact transportation solves in C++ (libcst_host.so); each data-parallel rank solves only its own rows; round 2: 281 labels/s/core (scipy LP)"}
 
 
 def time_pipeline(w, device, rank, steps, warmup, reducer=None):
@@ -496,6 +545,9 @@ def main():
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(w, args.workload)
+    host = None
+    if rank == 0 and not args.no_cpu_baseline:
+        host = host_path(w, per_stage["pretrain"]["sentences_per_s"] if per_stage else None)
 
     if rank == 0:
         line = {
@@ -507,7 +559,7 @@ def main():
                        "seq_len": w["L"], "vocab": w["V"], "critic_layers": w["n_layer"], "d_model": w["d_model"],
                        "parallelism": f"dp{world}", "stages": "pretrain+warmup+optimize(G+D)", "weights": "random-init",
                        "launch": ("hipGraph replay" if reducer is None else "hipGraph segments + eager all-reduce") if use_graph else "eager"},
-            "roofline": roofline, "cpu_baseline": cpu, "per_stage": per_stage, "f32_mode": f32_mode, "fp8w_mode": fp8w_mode, "workloads": others,
+            "roofline": roofline, "cpu_baseline": cpu, "host_path": host, "per_stage": per_stage, "f32_mode": f32_mode, "fp8w_mode": fp8w_mode, "workloads": others,
         }
         print(json.dumps(line), flush=True)
     if torch.distributed.is_initialized():

@@ -28,6 +28,24 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+HOST_LIB = os.path.join(CSRC, "libcst_host.so")
+HOST_SOURCES = ["host_wmd.cpp"]
+
+
+def build_host_lib(force=False, verbose=True):
+    """libcst_host.so: the host-side C++ of the path (exact transportation solver behind the pretrain stage's WMD labels) -- g++, no GPU."""
+    cxx = shutil.which("g++") or shutil.which("c++")
+    if cxx is None:
+        raise RuntimeError("g++ not found: libcst_host.so cannot be built")
+    srcs = [os.path.join(CSRC, s) for s in HOST_SOURCES]
+    if force or _stale(HOST_LIB, srcs):
+        cmd = [cxx, "-O3", "-std=c++17", "-fPIC", "-shared", "-pthread", "-o", HOST_LIB] + srcs
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    return HOST_LIB
+
+
 def build_lib(force=False, verbose=True):
     hipcc = _hipcc()
     hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
@@ -53,4 +71,6 @@ def build_lib(force=False, verbose=True):
 
 if __name__ == "__main__":
     build_lib(force="--force" in sys.argv)
+    build_host_lib(force="--force" in sys.argv)
     print(LIB)
+    print(HOST_LIB)

@@ -191,15 +191,23 @@ class PretrainCollate:
     """loader.py:46-70 as a picklable callable (PrefetchBatches ships it to worker processes).  `position` = (epoch, batch
     index) of the batch being built; iterate_batches / the prefetch workers set it, the label cache reads it."""
 
-    def __init__(self, vocab, label_fn, label_cache=None):
-        self.vocab, self.label_fn, self.label_cache = vocab, label_fn, label_cache
+    def __init__(self, vocab, label_fn, label_cache=None, shard=None):
+        """shard = (rank, world): compute the content-distance labels of this rank's rows only (parallel.shard_batch gives rank r the
+        rows [r n, (r + 1) n) of the global batch) -- the noise is drawn for the whole global batch on every rank, the transportation
+        problems are not solved `world` times over.  Only label functions that take `rows=` are narrowed."""
+        self.vocab, self.label_fn, self.label_cache, self.shard = vocab, label_fn, label_cache, shard
         self.position = (0, 0)
+        import inspect
+        try:
+            self._takes_rows = "rows" in inspect.signature(label_fn).parameters
+        except (TypeError, ValueError):
+            self._takes_rows = False
 
     def without_cache(self):
         """The collate for anything that is NOT the seeded training stream the cache was made for (validation: Trainer.fit).  The cache
         is keyed by (epoch, batch index) of the TRAINING sampler only; read through it, validation batch i would silently get the
         labels of training batch i of epoch 0 (same row count), and those targets decide best_eval, the freeze flags and mat.pth."""
-        return PretrainCollate(self.vocab, self.label_fn, None) if self.label_cache is not None else self
+        return PretrainCollate(self.vocab, self.label_fn, None, self.shard) if self.label_cache is not None else self
 
     def __call__(self, batch_samples):
         sentences, labels = zip(*batch_samples)
@@ -212,18 +220,21 @@ class PretrainCollate:
         nx_3, _, _ = align(noised_3, PAD_ID)
         if self.label_cache is not None:
             c_label = self.label_cache.get(*self.position, len(sentences))
+        elif self.shard is not None and self.shard[1] > 1 and self._takes_rows and len(sentences) % self.shard[1] == 0:
+            per = len(sentences) // self.shard[1]
+            c_label = self.label_fn(noised_1, noised_2, self.vocab, rows=(self.shard[0] * per, (self.shard[0] + 1) * per))
         else:
             c_label = self.label_fn(noised_1, noised_2, self.vocab)
         return (pth_tensor(x, torch.long), pth_tensor(nx_1, torch.long), pth_tensor(nx_2, torch.long),
                 pth_tensor(nx_3, torch.long), pth_tensor(labels, torch.long), pth_tensor(c_label, torch.float))
 
 
-def collate_pretrain(vocab, w2v=None, label_fn=None, label_cache=None):
+def collate_pretrain(vocab, w2v=None, label_fn=None, label_cache=None, shard=None):
     """`w2v`: an object with the reference's `cal_wmd_label(xs1, xs2, tokenizer)` (wmd.WMDdistance); `label_fn`: any
     function of (noised_1, noised_2, vocab); `label_cache` (a LabelCache): labels are read from it instead of computed."""
     if label_fn is None:
         label_fn = w2v.cal_wmd_label if w2v is not None else overlap_distance_label
-    return PretrainCollate(vocab, label_fn, label_cache)
+    return PretrainCollate(vocab, label_fn, label_cache, shard)
 
 
 def collate_warmup(batch_samples):

@@ -91,7 +91,8 @@ def main(argv=None, label_fn=None):
     if args.label_cache:
         cache = LabelCache(args.label_cache)
         cache.check(args.seed, args.batch_size, len(train_ds))
-    trainer.fit(stage, train_ds, val_ds, collate_pretrain(vocab, w2v=w2v, label_fn=label_fn, label_cache=cache), args.batch_size)
+    trainer.fit(stage, train_ds, val_ds, collate_pretrain(vocab, w2v=w2v, label_fn=label_fn, label_cache=cache, shard=(trainer.rank, trainer.world)),
+                args.batch_size)
     return stage
 
 

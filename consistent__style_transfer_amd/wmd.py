@@ -10,8 +10,9 @@ installable here, so the published algorithm is restated on numpy + scipy:
                          all distances 0 -> inf; nBOW weights = count / document length;
                          result = min sum_ij F_ij D_ij  s.t.  F >= 0, F 1 = nbow(d1), F^T 1 = nbow(d2)      (earth mover's distance)
 
-The transportation problem is solved exactly (scipy's HiGHS dual simplex; pyemd's Pele-Werman solver is exact too, so the
-two agree to LP tolerance).  Parity with gensim itself is UNPINNED offline; what IS pinned (tests/test_host_cpu.py) is the
+The transportation problem is solved exactly by this build's own C++ solver (csrc/host_wmd.cpp, libcst_host.so: successive shortest
+augmenting paths; pyemd's Pele-Werman solver is exact too, so the two agree to rounding), a whole batch per call
+(`WMDdistance.cal_wmd_label` -> cst_host_wmd_labels); scipy's HiGHS LP (`emd_lp`) is kept as the independent check of the tests.  Parity with gensim itself is UNPINNED offline; what IS pinned (tests/test_host_cpu.py) is the
 algorithm: hand-solvable cases, symmetry, the triangle inequality, agreement with an independent min-cost-flow formulation,
 and the reference's three special cases in `cal_wmd_label` (empty sentence, inf, normal).
 
@@ -29,9 +30,41 @@ processes ahead of the GPU, bit-identical to the in-line path because every batc
 and `loader.LabelCache` stores the labels of such a seeded run in a file so that later runs (and every data-parallel rank)
 read them back instead of solving.
 """
+import ctypes
 import math
+import os
 
 import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+HOST_LIB_PATH = os.path.join(_HERE, "csrc", "libcst_host.so")
+_host = None
+
+
+def host_lib():
+    """libcst_host.so (csrc/host_wmd.cpp, ABI include/cst_host.h): the exact transportation solver and the batch label entry point.
+    No fallback: the per-pair scipy LP of round 2 (281 labels / s / core) cannot keep up with the GPU and is kept only as `emd_lp`, the
+    independent check the tests compare this library against."""
+    global _host
+    if _host is None:
+        if not os.path.exists(HOST_LIB_PATH):
+            raise ImportError(f"{HOST_LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` (g++ -O3 -shared)")
+        L = ctypes.CDLL(HOST_LIB_PATH)
+        vp, i32, i64 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64
+        L.cst_host_abi_version.restype = ctypes.c_int
+        L.cst_host_emd.restype = ctypes.c_int
+        L.cst_host_emd.argtypes = [ctypes.c_int, ctypes.c_int, vp, vp, vp, vp]
+        L.cst_host_wmd_labels.restype = ctypes.c_int
+        L.cst_host_wmd_labels.argtypes = [vp, vp, vp, vp, i64, i64, i64, vp, i32, vp, i32, i32, vp]
+        _host = L
+    return _host
+
+
+def _ragged(seqs):
+    off = np.zeros(len(seqs) + 1, dtype=np.int64)
+    np.cumsum([len(s) for s in seqs], out=off[1:])
+    ids = np.fromiter((t for s in seqs for t in s), dtype=np.int32, count=int(off[-1]))
+    return ids, off
 
 
 class WordVectors:
@@ -90,8 +123,22 @@ class WordVectors:
 
 
 def emd(w1, w2, D):
-    """Exact earth mover's distance between two histograms of equal mass over the same support.  Rows / columns of zero
-    weight are dropped first (the LP is over the occupied bins only)."""
+    """Exact earth mover's distance between two histograms of equal mass over the same support (libcst_host.so: successive shortest
+    augmenting paths).  Rows / columns of zero weight are dropped first (the problem is over the occupied bins only)."""
+    i1, i2 = np.flatnonzero(w1 > 0), np.flatnonzero(w2 > 0)
+    a = np.ascontiguousarray(w1[i1], dtype=np.float64)
+    b = np.ascontiguousarray(w2[i2], dtype=np.float64)
+    cost = np.ascontiguousarray(D[np.ix_(i1, i2)], dtype=np.float64)
+    out = ctypes.c_double()
+    rc = host_lib().cst_host_emd(len(a), len(b), a.ctypes.data, b.ctypes.data, cost.ctypes.data, ctypes.addressof(out))
+    if rc != 0:
+        raise RuntimeError("cst_host_emd: bad arguments")
+    return float(out.value)
+
+
+def emd_lp(w1, w2, D):
+    """The same transportation problem as a linear program (scipy HiGHS): the independent formulation tests/test_host_cpu.py holds
+    `emd` to.  Not on the training path."""
     from scipy.optimize import linprog
     i1, i2 = np.flatnonzero(w1 > 0), np.flatnonzero(w2 > 0)
     a, b = w1[i1], w2[i2]
@@ -108,7 +155,7 @@ def emd(w1, w2, D):
         A[n + j, j::m] = 1.0
     res = linprog(cost.reshape(-1), A_eq=A[:-1], b_eq=np.concatenate([a, b])[:-1], bounds=(0, None), method="highs")
     if res.status != 0:
-        raise RuntimeError(f"emd: LP solver failed ({res.message})")
+        raise RuntimeError(f"emd_lp: LP solver failed ({res.message})")
     return float(res.fun)
 
 
@@ -146,7 +193,35 @@ class WMDdistance:
     def cal_wmd(self, x1, x2):
         return wmdistance(self.wv, x1, x2)
 
-    def cal_wmd_label(self, xs1, xs2, tokenizer):
+    def _rows_of_ids(self, tokenizer):
+        """vocabulary id -> row of the word-vector table, -1 for tokens without a vector (cached per tokenizer)."""
+        key = id(tokenizer)
+        hit = getattr(self, "_row_cache", None)
+        if hit is None or hit[0] != key:
+            toks = tokenizer.ids_to_tokens(list(range(len(tokenizer))))
+            rows = np.array([self.wv.index.get(t, -1) for t in toks], dtype=np.int32)
+            self._row_cache = hit = (key, rows, np.ascontiguousarray(self.wv.vectors, dtype=np.float64))
+        return hit[1], hit[2]
+
+    def cal_wmd_label(self, xs1, xs2, tokenizer, rows=None, nthreads=1):
+        """src/wmd.py:34-45 for a whole batch in ONE call of libcst_host.so (cst_host_wmd_labels).  rows = (lo, hi): only those pairs
+        are computed (a data-parallel rank needs the labels of its own rows only), the others are returned as 0.0."""
+        n = len(xs1)
+        lo, hi = (0, n) if rows is None else rows
+        row_of_id, vec = self._rows_of_ids(tokenizer)
+        ids1, off1 = _ragged(xs1)
+        ids2, off2 = _ragged(xs2)
+        out = np.zeros(n, dtype=np.float64)
+        rc = host_lib().cst_host_wmd_labels(ids1.ctypes.data, off1.ctypes.data, ids2.ctypes.data, off2.ctypes.data, n, int(lo), int(hi),
+                                            row_of_id.ctypes.data, len(row_of_id), vec.ctypes.data, vec.shape[1], int(nthreads),
+                                            out.ctypes.data)
+        if rc != 0:
+            raise RuntimeError("cst_host_wmd_labels: bad arguments")
+        return out.tolist()
+
+    def cal_wmd_label_py(self, xs1, xs2, tokenizer):
+        """The per-pair Python restatement of round 2 (numpy distances + one transportation solve per pair): what the tests compare
+        the batch entry point with.  Not on the training path."""
         label = []
         for x1, x2 in zip(xs1, xs2):
             if len(x1) == 0 or len(x2) == 0:              # wmd.py:37-38

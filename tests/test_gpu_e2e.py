@@ -51,7 +51,25 @@ def test_three_stages_cli(tmp_path, graph):
         common += ["--token_cache", "--prefetch_workers", "2"]      # binary token cache + batches built ahead in workers
     _small_constants()
     try:
-        pre = main_pretrain.main(common + ["--ver", "0"])
+        if graph:
+            # word vectors in this build's container format next to the vocabulary: main_pretrain then takes the REAL label path
+            # (wmd.WMDdistance -> libcst_host.so cst_host_wmd_labels) instead of the overlap stand-in (round-2 verdict, f1)
+            from consistent__style_transfer_amd import wmd as _wmd
+            from consistent__style_transfer_amd.vocab import BPETokenizer
+            vocab = BPETokenizer.load(str(dump / "yelp-vocab.json"), str(dump / "yelp-merges.txt"))
+            _wmd.WMDdistance.train([str(data / "style.train.0"), str(data / "style.train.1")], vocab, dim=8).save(str(dump / "yelp-w2v.npz"))
+            calls = []
+            orig = _wmd.WMDdistance.cal_wmd_label
+
+            def spy(self, xs1, xs2, tok, rows=None, nthreads=1):
+                out = orig(self, xs1, xs2, tok, rows=rows, nthreads=nthreads)
+                calls.append((len(xs1), float(max(out)), float(min(out))))
+                return out
+            _wmd.WMDdistance.cal_wmd_label = spy
+        pre = main_pretrain.main(common + ["--ver", "0"] + (["--prefetch_workers", "0"] if graph else []))
+        if graph:
+            _wmd.WMDdistance.cal_wmd_label = orig
+            assert len(calls) >= 6 and all(n == 32 for n, _, _ in calls[:3]) and max(hi for _, hi, _ in calls) > 0.05, calls[:4]
         for name in ("cls", "mat", "dn"):
             assert os.path.exists(dump / "pretrain" / f"{name}.pth")
         assert all(torch.isfinite(p).all() for p in pre.parameters())
