@@ -388,6 +388,193 @@ extern "C" int cst_gemm_bf16_skinny(const void* A, long lda, const void* B, long
 }
 
 // =============================================================================================
+// cst_dec_fn2: the vocabulary projection of one decode step, logits[M, V] = r1[M, 512] . W2[V, 512]^T (rnn.py:80), plus the packed
+// arg-max words of every row (see cst_gemm_bf16_argmax).
+//
+// The general NT kernel runs this 2.6 GFLOP product in 13-16 us: K = 512 is eight K-tiles fetched one tile ahead of 0.1 us of MFMA, so
+// every tile costs an L2 round trip, and 316 small tiles each re-read their rows of r1.  Here r1 is STATIONARY: a workgroup loads its
+// 64 rows once (64 KB), the four MFMA waves keep them as fragments in registers for the whole launch, and the workgroup walks a
+// contiguous range of vocabulary columns in 32-column sub-tiles (32 KB of W2 each) through a ring of four LDS buffers -- two of them the
+// space r1 occupied before it moved to registers.  Roles are split as in a loader / consumer GEMM because gfx950 counts loads and
+// stores in ONE in-order counter: waves 4-7 only issue LDS-DMA and count vmcnt (loads only, three sub-tiles in flight), waves 0-3 only
+// read fragments, issue MFMAs and store C (stores only, never waited for).  One barrier per sub-tile:
+//   barrier(j) = "sub-tile j has landed" (the loaders waited for it) + "the MFMA waves are done with sub-tile j - 1" (they arrive after it)
+//   loaders after barrier(j): DMA sub-tile j + 3 into buffer (j + 3) % 4 = the buffer sub-tile j - 1 left
+// The arg-max of a row is kept per lane across the sub-tiles, reduced over the 16 lanes of a DPP row at the end and folded into the
+// row's packed words with ONE atomic per row and workgroup.
+// =============================================================================================
+typedef __attribute__((ext_vector_type(2))) unsigned u32x2_t;
+__device__ __forceinline__ u32x4_t dk_lds_read128(unsigned addr) {
+    u32x4_t v;
+    asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr) : "memory");
+    return v;
+}
+template <int CTRL>
+__device__ __forceinline__ int dk_dpp_i(int v, int old) { return __builtin_amdgcn_update_dpp(old, v, CTRL, 0xf, 0xf, false); }
+__device__ __forceinline__ int dk_row16_min_i(int v) {
+    v = min(v, dk_dpp_i<0xB1>(v, v));
+    v = min(v, dk_dpp_i<0x4E>(v, v));
+    v = min(v, dk_dpp_i<0x141>(v, v));
+    v = min(v, dk_dpp_i<0x140>(v, v));
+    return v;
+}
+__device__ __forceinline__ unsigned long long dk_pack_max(float v, int idx) {
+    unsigned u = __float_as_uint(v);
+    u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+    return ((unsigned long long)u << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)idx);
+}
+
+struct Fn2Args {
+    const bf16_t* A; long lda;        // [M, 512] bf16
+    const bf16_t* W; long ldw;        // [V, 512] bf16
+    float* C; long ldc;               // [M, V] fp32
+    unsigned long long* amax;         // [DK_AMAX_GROUPS][M] packed words (zeroed by the caller) or null
+    int M, V, nsub;                   // nsub = 32-column sub-tiles per workgroup
+};
+
+constexpr int FN2_KT = 8;             // K = 512
+constexpr int FN2_SUB = 32 * FN2_KT * 128;      // bytes of one W2 sub-tile image: 32 KB
+constexpr int FN2_DMA = 8;            // DMA pieces per loader wave and sub-tile
+
+__global__ __launch_bounds__(512) void dec_fn2_kernel(Fn2Args a) {
+    extern __shared__ __attribute__((aligned(16))) char dk_smem[];
+    // buffers 2, 3 = the A region (free once the fragments are in registers), buffers 0, 1 behind it
+    char* Areg = dk_smem;                                   // [8][64][128 B] = 64 KB
+    auto buf = [&](int j) -> char* { const int b = j & 3; return dk_smem + (b < 2 ? 2 * FN2_SUB + b * FN2_SUB : (b - 2) * FN2_SUB); };
+    // The workgroups that share a slice of W2 (same column range, different row tile) should share an XCD's L2: the dispatcher deals
+    // consecutive workgroup ids round-robin over the 8 XCDs, so id = 8 k + x puts (row tile k % mt, slice x + 8 (k / mt)) on XCD group x.
+    // (gridDim.y is a multiple of 8; slices past the last sub-tile exit at once.)  Speed only -- any placement computes the same thing.
+    const int mt = gridDim.x;
+    const int id = blockIdx.x + mt * blockIdx.y, xg = id & 7, kq = id >> 3;
+    const int mtile = kq % mt, slice = xg + 8 * (kq / mt);
+    const int m0 = mtile * 64;
+    const int sub0 = slice * a.nsub;                        // first sub-tile of this workgroup
+    const int nsub_tot = (a.V + 31) >> 5;
+    const int nsub = min(a.nsub, nsub_tot - sub0);
+    if (nsub <= 0) return;                                  // the whole workgroup, before any barrier
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (wave >= 4) {
+        // ------------------------------------------------------------------------------------------ loaders
+        const int lw = wave - 4;
+        auto issue_sub = [&](int j) {
+            const int n0 = (sub0 + j) * 32;
+            dk_issue_panel<32, 4>(buf(j), 0, FN2_KT, lw, lane, [&](int r) { return a.W + (long)min(n0 + r, a.V - 1) * a.ldw; });
+        };
+        dk_issue_panel<64, 4>(Areg, 0, FN2_KT, lw, lane, [&](int r) { return a.A + (long)min(m0 + r, a.M - 1) * a.lda; });
+        issue_sub(0);
+        if (nsub > 1) issue_sub(1);
+        // only r1 has to be there for A1: the (one or two) sub-tiles requested behind it stay in flight
+        if (nsub > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * FN2_DMA) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(FN2_DMA) : "memory");
+        __builtin_amdgcn_s_barrier();                       // A1: the r1 rows are in LDS
+        __builtin_amdgcn_s_barrier();                       // A2: the MFMA waves hold r1 in registers -> buffers 2, 3 are free
+        if (nsub > 2) issue_sub(2);
+        for (int j = 0; j < nsub; ++j) {
+            // sub-tile j must have landed; younger DMA of this wave: sub-tiles j + 1, j + 2 where they exist (all issued by now)
+            const int younger = min(nsub - 1, j + 2) - j;
+            if (younger >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * FN2_DMA) : "memory");
+            else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(FN2_DMA) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();                   // barrier(j)
+            if (j + 3 < nsub) issue_sub(j + 3);   // into the buffer sub-tile j - 1 left (j = 0: buffer 3, free since A2)
+        }
+        return;
+    }
+    // ---------------------------------------------------------------------------------------------- MFMA waves
+    const int lr = lane & 15, lq = lane >> 4;
+    const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)dk_smem;
+    __builtin_amdgcn_s_barrier();                           // A1
+    u32x4_t af[2 * FN2_KT];
+#pragma unroll
+    for (int ks = 0; ks < 2 * FN2_KT; ++ks)
+        af[ks] = dk_lds_read128(lds_base + (ks >> 1) * 64 * 128 + dk_off(16 * wave + lr, (ks & 1) * 4 + lq));
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();                           // A2
+    float bestv[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    int besti[4] = {0x7fffffff, 0x7fffffff, 0x7fffffff, 0x7fffffff};
+    for (int j = 0; j < nsub; ++j) {
+        __builtin_amdgcn_s_barrier();                       // barrier(j): sub-tile j has landed
+        const unsigned bb = lds_base + (unsigned)(buf(j) - dk_smem);
+        f32x4_t acc0 = (f32x4_t){0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
+        u32x4_t bq[2][8];
+        // group g = K steps 4g .. 4g + 3: 8 reads (4 K steps x 2 column tiles); the next group's reads fly under this group's MFMAs
+        auto rd = [&](int ks, int ct) -> u32x4_t {          // fragment of K step ks (K-tile ks / 2, half ks % 2), column tile ct
+            const unsigned base = bb + (unsigned)((ks >> 1) * 32 * 128);
+            return dk_lds_read128(base + dk_off(16 * ct + lr, (ks & 1) * 4 + lq));
+        };
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { bq[0][2 * q] = rd(q, 0); bq[0][2 * q + 1] = rd(q, 1); }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            if (g < 3) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { bq[(g + 1) & 1][2 * q] = rd(4 * (g + 1) + q, 0); bq[(g + 1) & 1][2 * q + 1] = rd(4 * (g + 1) + q, 1); }
+                asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");          // this group's 8 reads are back, the next group's 8 may fly
+            } else {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const bf16x8_t av = __builtin_bit_cast(bf16x8_t, af[4 * g + q]);
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, __builtin_bit_cast(bf16x8_t, bq[g & 1][2 * q]), acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, __builtin_bit_cast(bf16x8_t, bq[g & 1][2 * q + 1]), acc1, 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // C rows 16 wave + 4 lq + r, columns n0 + lr and n0 + 16 + lr
+        const int n0 = (sub0 + j) * 32;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const long m = m0 + 16 * wave + 4 * lq + r;
+            if (m < a.M) {
+                if (n0 + lr < a.V) a.C[m * a.ldc + n0 + lr] = acc0[r];
+                if (n0 + 16 + lr < a.V) a.C[m * a.ldc + n0 + 16 + lr] = acc1[r];
+            }
+            if (n0 + lr < a.V && acc0[r] > bestv[r]) { bestv[r] = acc0[r]; besti[r] = n0 + lr; }
+            if (n0 + 16 + lr < a.V && acc1[r] > bestv[r]) { bestv[r] = acc1[r]; besti[r] = n0 + 16 + lr; }
+        }
+    }
+    if (a.amax) {
+        // the columns a lane saw were ascending, so its strict > kept the FIRST maximal column; now the 16 lanes of a DPP row
+        const int grp = slice & (DK_AMAX_GROUPS - 1);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float rm = row16_max(bestv[r]);
+            const int ri = dk_row16_min_i(bestv[r] == rm ? besti[r] : 0x7fffffff);
+            const long m = m0 + 16 * wave + 4 * lq + r;
+            if (lr == 0 && m < a.M) atomicMax(a.amax + (long)grp * a.M + m, dk_pack_max(rm, ri));
+        }
+    }
+}
+
+extern "C" int cst_dec_fn2(const void* A, long lda, const void* W, long ldw, float* C, long ldc, int M, int V, int K,
+                           void* amax_packed, void* stream) {
+    CST_REQUIRE(A && W && C && M > 0 && V > 0, "cst_dec_fn2: bad arguments");
+    CST_REQUIRE(K == 64 * FN2_KT, "cst_dec_fn2: K=%d (this kernel is built for K = %d)", K, 64 * FN2_KT);
+    CST_REQUIRE(lda >= K && ldw >= K && lda % 8 == 0 && ldw % 8 == 0 && ((((uintptr_t)A) | ((uintptr_t)W)) & 15) == 0 && ldc >= V,
+                "cst_dec_fn2: operands must be 16-byte aligned with leading dimensions >= K, multiples of 8; ldc >= V");
+    CST_REQUIRE(!amax_packed || (((uintptr_t)amax_packed) & 7) == 0, "cst_dec_fn2: arg-max words must be 8-byte aligned");
+    Fn2Args a;
+    a.A = (const bf16_t*)A; a.lda = lda; a.W = (const bf16_t*)W; a.ldw = ldw; a.C = C; a.ldc = ldc;
+    a.amax = (unsigned long long*)amax_packed; a.M = M; a.V = V;
+    const int mt = (M + 63) / 64, nsub_tot = (V + 31) / 32;
+    int slices = 256 / mt; if (slices < 1) slices = 1; if (slices > nsub_tot) slices = nsub_tot;
+    a.nsub = (nsub_tot + slices - 1) / slices;
+    slices = ((nsub_tot + a.nsub - 1) / a.nsub + 7) / 8 * 8;        // a multiple of 8 (XCD grouping in the kernel); surplus slices exit at once
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void*)dec_fn2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(dec_fn2_kernel, dim3(mt, slices), dim3(512), (size_t)4 * FN2_SUB, (hipStream_t)stream, a);
+    CST_LAUNCH_CHECK("cst_dec_fn2");
+    return CST_OK;
+}
+
+// =============================================================================================
 // packed arg-max words -> token ids
 // =============================================================================================
 __global__ void unpack_argmax_kernel(const unsigned long long* __restrict__ packed, int64_t* __restrict__ ids, long n) {

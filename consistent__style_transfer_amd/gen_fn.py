@@ -259,7 +259,10 @@ class GeneratorFn(torch.autograd.Function):
                 r1b_s = r1b[:, s * Hd:(s + 1) * Hd]
                 call("cst_gemm_bf16_skinny", idb_s, T * W_, fn1_b, fn1_b.stride(0), r12[:, s * Hd:(s + 1) * Hd], T * Hd, r1b_s, T * Hd,
                      B, Hd, W_, P["fn_1.bias"], 2)
-                call("cst_gemm_bf16_argmax", r1b_s, T * Hd, fn2_b, fn2_b.stride(0), out2[:, s * V:(s + 1) * V], T * V, B, V, Hd, amax[s])
+                if Hd == 512 and os.environ.get("CST_FN2_GENERIC") != "1":
+                    call("cst_dec_fn2", r1b_s, T * Hd, fn2_b, fn2_b.stride(0), out2[:, s * V:(s + 1) * V], T * V, B, V, Hd, amax[s])
+                else:
+                    call("cst_gemm_bf16_argmax", r1b_s, T * Hd, fn2_b, fn2_b.stride(0), out2[:, s * V:(s + 1) * V], T * V, B, V, Hd, amax[s])
             call("cst_unpack_argmax", amax, ids_fb, B, T)
             if soft:
                 o2 = out.view(B * T, V)

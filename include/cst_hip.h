@@ -359,6 +359,11 @@ int cst_gemm_bf16_skinny(const void* A, long lda, const void* B, long ldb, float
 int cst_argmax_groups(void);
 int cst_gemm_bf16_argmax(const void* A, long lda, const void* B, long ldb, float* C, long ldc, int M, int N, int K,
                          void* amax_packed, void* stream);
+/* The same product and arg-max words for K == 512 (the decoder's fn_2: logits = r1 W2^T, rnn.py:80) with the r1 rows STATIONARY: a
+ * workgroup keeps its 64 rows of A as MFMA fragments in registers and streams a contiguous range of B's rows (vocabulary columns)
+ * through a four-buffer LDS ring fed by dedicated loader waves; one arg-max atomic per row and workgroup.  C [M, V] fp32 (ldc >= V). */
+int cst_dec_fn2(const void* A, long lda, const void* W, long ldw, float* C, long ldc, int M, int V, int K,
+                void* amax_packed, void* stream);
 /* ids[s][i] = column index held by the packed arg-max words of row i of product s: packed = `steps` blocks [G][n]
  * (rnn.py:88-92: the ids fed back; main_optimize.py:104 sample_p.argmax) */
 int cst_unpack_argmax(const void* packed, int64_t* ids, long n, int steps, void* stream);

@@ -1169,3 +1169,38 @@ def test_dec_attn(ops, B, L):
     mask = torch.from_numpy(orng.dropout_mask(9, 104, (B, 2 * D), 0.1))
     want = _bf(torch.cat([q, out.cpu()], 1) * mask)
     assert torch.equal(db.view(torch.bfloat16).float().cpu(), want)
+
+
+@pytest.mark.parametrize("shape", [(256, 10000), (16, 208), (70, 1000), (256, 33), (300, 4097), (64, 32)])
+def test_dec_fn2(ops, shape):
+    """cst_dec_fn2 (A-stationary fn_2, K = 512): product against the bf16-rounded reference, arg-max ids == torch.argmax of the
+    kernel's own product with duplicated weight rows forcing exact ties, repeated launches bit-identical (no split-K, no float atomics)."""
+    from consistent__style_transfer_amd._lib import call, call_plain
+    M, N = shape
+    K = 512
+    A, Bm = rnd(M, K, seed=1).abs(), rnd(N, K, seed=2)
+    if N > 40:
+        Bm[7] = Bm[7].abs() * 3
+        Bm[N // 2 + 5] = Bm[7]                              # columns 7 and N/2 + 5 tie exactly in every row
+        Bm[N - 1] = Bm[3]
+    Ab, _ = ops.cast_bf16(dev(A), want_t=False)
+    Bb, _ = ops.cast_bf16(dev(Bm), want_t=False)
+    NG = call_plain("cst_argmax_groups")
+    ldc = N + 8
+    Cbuf = torch.full((M, ldc), float("nan"), device="cuda")
+    packed = torch.zeros(NG, M, device="cuda", dtype=torch.int64)
+    call("cst_dec_fn2", Ab, Ab.stride(0), Bb, Bb.stride(0), Cbuf, ldc, M, N, K, packed)
+    C = Cbuf[:, :N]
+    assert torch.isnan(Cbuf[:, N:]).all()                    # nothing written past the row
+    ref = _bf(A) @ _bf(Bm).t()
+    close(C, ref, 2e-3, 2e-3 * math.sqrt(K), f"{shape}")
+    ids = torch.empty(M, device="cuda", dtype=torch.int64)
+    call("cst_unpack_argmax", packed, ids, M, 1)
+    want = C.cpu().argmax(-1)
+    assert torch.equal(ids.cpu(), want)
+    if N > 40:
+        assert int((want == 7).sum()) > 0
+    C2 = torch.full((M, ldc), float("nan"), device="cuda")
+    p2 = torch.zeros(NG, M, device="cuda", dtype=torch.int64)
+    call("cst_dec_fn2", Ab, Ab.stride(0), Bb, Bb.stride(0), C2, ldc, M, N, K, p2)
+    assert torch.equal(C2[:, :N], C) and torch.equal(p2.max(0).values, packed.max(0).values)
