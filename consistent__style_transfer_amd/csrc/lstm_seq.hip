@@ -57,6 +57,10 @@ struct LstmSeqArgs {
 // is one the step does not wait for.  4 waves x 4 tiles x 8 KiB = 128 KiB next to the 8 KiB h tile.
 constexpr int SQ_NL = 4;
 constexpr int SQ_FWD_LDS = 16 * SQ_HS * 2 + 4 * SQ_NL * SQ_KK * 1024;
+// ... and the FIRST SQ_NR tiles stay in REGISTERS for the whole launch: the kernel runs one wave per SIMD (512 VGPRs a lane), of which the
+// step itself needs ~380.  SQ_NR x 8 x 16 B per lane = another SQ_NR x 8 KiB per wave that is never streamed again (2 tiles: 506 registers, no
+// spill; 3 spill 10, 4 spill 24): with 4 + 2 of the 16 tiles on chip the per-step W_hh stream out of L2 is 320 instead of 384 KB per workgroup.
+constexpr int SQ_NR = 2;
 
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void lstm_seq_fwd_kernel(LstmSeqArgs a) {
     constexpr int H = SQ_H;
@@ -94,6 +98,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     for (int i = 0; i < SQ_NL * SQ_KK; ++i)
         *reinterpret_cast<u32x4_t*>(wl + i * 1024) = *reinterpret_cast<const u32x4_t*>(wfrag + ((long)(16 - SQ_NL) * SQ_KK + i) * 64 * 8);
 
+    u32x4_t wreg[SQ_NR][SQ_KK];
+#pragma unroll
+    for (int ti = 0; ti < SQ_NR; ++ti)
+#pragma unroll
+        for (int kk = 0; kk < SQ_KK; ++kk) wreg[ti][kk] = *reinterpret_cast<const u32x4_t*>(wfrag + ((long)ti * SQ_KK + kk) * 64 * 8);
+
     for (int n = 0; n < L; ++n) {
         const int t = D.reverse ? L - 1 - n : n;
         f32x4_t acc[4][SQ_J];
@@ -104,6 +114,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         // W_hh fragments, three tiles in flight
         u32x4_t bb[3][SQ_KK];
         auto load_b = [&](int ti, u32x4_t (&dst)[SQ_KK]) {
+            if (ti < SQ_NR) return;                       // register-resident tile: used in place below
             if (ti >= 16 - SQ_NL) {                       // resident tile (ti is a compile-time constant once the loop is unrolled)
                 const char* ws = wl + (ti - (16 - SQ_NL)) * SQ_KK * 1024;
 #pragma unroll
@@ -129,7 +140,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             f32x4_t s = acc[ti / SQ_J][ti % SQ_J];
 #pragma unroll
             for (int kk = 0; kk < SQ_KK; ++kk)
-                s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, af[kk]), __builtin_bit_cast(bf16x8_t, bb[ti % 3][kk]), s, 0, 0, 0);
+                s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, af[kk]),
+                                                            __builtin_bit_cast(bf16x8_t, ti < SQ_NR ? wreg[ti < SQ_NR ? ti : 0][kk] : bb[ti % 3][kk]), s, 0, 0, 0);
             acc[ti / SQ_J][ti % SQ_J] = s;
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -230,6 +242,7 @@ struct LstmSeqBwdArgs {
 // resident W_hh^T fragments: the last SQ_NLB of a wave's 32 k steps (4 KiB each): 4 waves x 7 x 4 KiB = 112 KiB next to the 32 KiB dgates tile
 constexpr int SQ_NLB = 7;
 constexpr int SQ_BWD_LDS = 16 * SQ_GS * 2 + 4 * SQ_NLB * SQ_J * 1024;
+constexpr int SQ_NRB = 16;             // ... and the FIRST SQ_NRB k steps stay in registers (one wave per SIMD: 512 VGPRs a lane): 9 of 32 k steps streamed per step instead of 25 (504 registers, no spill)
 
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void lstm_seq_bwd_kernel(LstmSeqBwdArgs a) {
     constexpr int H = SQ_H;
@@ -254,6 +267,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
     for (int i = 0; i < SQ_NLB * SQ_J; ++i)
         *reinterpret_cast<u32x4_t*>(wl + i * 1024) = *reinterpret_cast<const u32x4_t*>(wfrag + ((long)(SQ_KB - SQ_NLB) * SQ_J + i) * 64 * 8);
+
+    u32x4_t wreg[SQ_NRB][SQ_J];
+#pragma unroll
+    for (int kk = 0; kk < SQ_NRB; ++kk)
+#pragma unroll
+        for (int j = 0; j < SQ_J; ++j) wreg[kk][j] = *reinterpret_cast<const u32x4_t*>(wfrag + ((long)kk * SQ_J + j) * 64 * 8);
 
     for (int n = L - 1; n >= 0; --n) {
         const int t = D.reverse ? L - 1 - n : n;
@@ -295,6 +314,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         for (int j = 0; j < SQ_J; ++j) acc[j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
         u32x4_t bb[3][SQ_J];
         auto load_b = [&](int kk, u32x4_t (&dst)[SQ_J]) {
+            if (kk < SQ_NRB) return;                      // register-resident k step: used in place below
             if (kk >= SQ_KB - SQ_NLB) {                   // resident k step
                 const char* ws = wl + (kk - (SQ_KB - SQ_NLB)) * SQ_J * 1024;
 #pragma unroll
@@ -314,7 +334,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int j = 0; j < SQ_J; ++j)
-                acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, af), __builtin_bit_cast(bf16x8_t, bb[kk % 3][j]), acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, af),
+                                                                 __builtin_bit_cast(bf16x8_t, kk < SQ_NRB ? wreg[kk < SQ_NRB ? kk : 0][j] : bb[kk % 3][j]), acc[j], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
 #pragma unroll

@@ -197,10 +197,11 @@ EXACT_SMALL_FLOP = float(os.environ.get("CST_EXACT_SMALL_MFLOP", "8")) * 1e6
 
 
 def gemm(A, a_kmajor, B, b_kmajor, C, M, N, K, bias=None, addend=None, aux=None, act=0, gate_scale=1.0,
-         accumulate=False, alpha=1.0, drop=NO_DROP, tile=0, splitk=0):
+         accumulate=False, alpha=1.0, drop=NO_DROP, tile=0, splitk=0, exact=None):
     """C[M,N] = epi(alpha * op(A) op(B)); A, B, C, addend, aux are row-major 2-D views."""
     ws = _workspace(C.device)
-    exact = _STATE["f32"] or 2.0 * M * N * K <= EXACT_SMALL_FLOP
+    if exact is None:
+        exact = _STATE["f32"] or 2.0 * M * N * K <= EXACT_SMALL_FLOP
     call("cst_gemm", _f32(A), _ld(A), int(a_kmajor), _f32(B), _ld(B), int(b_kmajor), _f32(C), _ld(C), M, N, K,
          bias, addend, _ld(addend) if addend is not None else 0, aux, _ld(aux) if aux is not None else 0,
          act, float(gate_scale), int(accumulate), float(alpha), int(exact),
