@@ -32,9 +32,11 @@ WORKLOADS = {
     "book_6l_d512_b512": dict(n_layer=6, d_model=512, n_head=8, B=512, L=30, V=10000),
     # BASELINE.json configs[0]-shaped small case
     "yelp_2l_d256_b32": dict(n_layer=2, d_model=256, n_head=8, B=32, L=16, V=10000),
+    # the WHOLE global batch of configs[3] on one GPU: the strong-scaling denominator of north_star's ">= 6x at 8 GPUs on batch 2048"
+    "yelp_6l_d768_b2048": dict(n_layer=6, d_model=768, n_head=8, B=2048, L=18, V=10000),
 }
 HEADLINE = "yelp_6l_d768_b256"   # the per-GPU shard of BASELINE configs[3] (global batch 2048 at 8 GPUs): what the 1 -> 8 curve runs
-OTHER_WORKLOADS = ("yelp_4l_d512_b256", "book_6l_d512_b512", "yelp_6l_d512_b256")      # configs[1], configs[2], the reference's own sizes
+OTHER_WORKLOADS = ("yelp_4l_d512_b256", "book_6l_d512_b512", "yelp_6l_d512_b256", "yelp_6l_d768_b2048")      # configs[1], configs[2], the reference's own sizes, configs[3]'s global batch on one GPU
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_PEAK_TFLOPS = 2500.0        # dense bf16 MFMA peak (not the 2:1 sparse figure)
 
@@ -342,6 +344,20 @@ def main():
     stages_ = build_stages(w, device)
     batches = make_batches(w, rank, device)
     reducer = GradReducer(world) if world > 1 else None
+    rccl = None
+    if world > 1:
+        # self-check of the first real multi-GPU run: every rank reports where it sits and what it talks through; rank 0 keeps the table
+        import socket
+        me = {"rank": rank, "local_rank": local, "device": str(device), "gpu": torch.cuda.get_device_name(device), "host": socket.gethostname(),
+              "backend": torch.distributed.get_backend(), "rccl_version": ".".join(str(v) for v in torch.cuda.nccl.version()) if torch.distributed.get_backend() == "nccl" else None}
+        table = [None] * world
+        torch.distributed.all_gather_object(table, me)
+        probe = torch.ones(1, device=device if me["backend"] == "nccl" else "cpu")
+        torch.distributed.all_reduce(probe)                          # SUM of ones = the number of ranks the collective really reached
+        rccl = {"ranks_seen": int(probe.item()), "world": world, "backend": me["backend"], "rccl_version": me["rccl_version"],
+                "devices": sorted({(t["host"], t["device"]) for t in table}).__len__(), "table": table}
+        print(f"[bench] rank {rank}/{world}: {me['gpu']} {me['device']} on {me['host']}, backend {me['backend']} (RCCL {me['rccl_version']}), "
+              f"all_reduce reached {rccl['ranks_seen']} ranks", file=sys.stderr, flush=True)
     if world == 1 and os.environ.get("CST_RCCL_REHEARSAL"):
         # one-rank RCCL group on the one GPU: the N > 1 launch structure (hipGraph segments, bucketed backward, async all_reduce(AVG) on
         # RCCL's stream) with every collective really issued -- what it costs next to the single-graph step, minus the wire time
@@ -536,10 +552,14 @@ def main():
             if name == args.workload:
                 continue
             wo = WORKLOADS[name]
-            mso, so, bo_, po = time_pipeline(wo, device, rank, 5, 2)
-            others[name] = {"ms_per_step": mso, "value": wo["B"] / (mso * 1e-3), "unit": "sentences/s", "steps": 5, "warmup": 2,
-                            "per_gpu_batch": wo["B"], "seq_len": wo["L"], "critic_layers": wo["n_layer"], "d_model": wo["d_model"]}
-            del so, bo_, po
+            nst, nwu = (3, 1) if wo["B"] >= 2048 else (5, 2)
+            try:
+                mso, so, bo_, po = time_pipeline(wo, device, rank, nst, nwu)
+                others[name] = {"ms_per_step": mso, "value": wo["B"] / (mso * 1e-3), "unit": "sentences/s", "steps": nst, "warmup": nwu,
+                                "per_gpu_batch": wo["B"], "seq_len": wo["L"], "critic_layers": wo["n_layer"], "d_model": wo["d_model"]}
+                del so, bo_, po
+            except Exception as e:                                   # noqa: BLE001 -- a side workload must not cost the headline line
+                others[name] = {"error": f"{type(e).__name__}: {e}"[:300]}
             torch.cuda.empty_cache()
 
     cpu = None
@@ -558,7 +578,8 @@ def main():
             "config": {"workload": args.workload, "per_gpu_batch": w["B"], "global_batch": w["B"] * world,
                        "seq_len": w["L"], "vocab": w["V"], "critic_layers": w["n_layer"], "d_model": w["d_model"],
                        "parallelism": f"dp{world}", "stages": "pretrain+warmup+optimize(G+D)", "weights": "random-init",
-                       "launch": ("hipGraph replay" if reducer is None else "hipGraph segments + eager all-reduce") if use_graph else "eager"},
+                       "launch": ("hipGraph replay" if reducer is None else "hipGraph segments + eager all-reduce") if use_graph else "eager",
+                       "rccl": rccl},
             "roofline": roofline, "cpu_baseline": cpu, "host_path": host, "per_stage": per_stage, "f32_mode": f32_mode, "fp8w_mode": fp8w_mode, "workloads": others,
         }
         print(json.dumps(line), flush=True)
