@@ -392,14 +392,15 @@ extern "C" int cst_gemm_bf16_skinny(const void* A, long lda, const void* B, long
 // arg-max words of every row (see cst_gemm_bf16_argmax).
 //
 // The general NT kernel runs this 2.6 GFLOP product in 13-16 us: K = 512 is eight K-tiles fetched one tile ahead of 0.1 us of MFMA, so
-// every tile costs an L2 round trip, and 316 small tiles each re-read their rows of r1.  Here r1 is STATIONARY: a workgroup loads its
-// 64 rows once (64 KB), the four MFMA waves keep them as fragments in registers for the whole launch, and the workgroup walks a
-// contiguous range of vocabulary columns in 32-column sub-tiles (32 KB of W2 each) through a ring of four LDS buffers -- two of them the
-// space r1 occupied before it moved to registers.  Roles are split as in a loader / consumer GEMM because gfx950 counts loads and
-// stores in ONE in-order counter: waves 4-7 only issue LDS-DMA and count vmcnt (loads only, three sub-tiles in flight), waves 0-3 only
-// read fragments, issue MFMAs and store C (stores only, never waited for).  One barrier per sub-tile:
+// every tile costs an L2 round trip, and 316 small tiles each re-read their rows of r1.  Here r1 is STATIONARY: each of the four MFMA
+// waves of a workgroup loads its 16 rows once, straight from global memory into MFMA A fragments (64 registers a lane, kept for the
+// whole launch), and the workgroup walks a contiguous range of vocabulary columns in 32-column sub-tiles (32 KB of W2 each) through a
+// ring of five LDS buffers -- all 160 KB, requested at once at the start, so the first five sub-tiles (the whole range at V = 10 000) cost
+// ONE exposed round trip.  Roles are split as in a loader / consumer GEMM because gfx950 counts loads and stores in ONE in-order
+// counter: waves 4-7 only issue LDS-DMA and count vmcnt (loads only), waves 0-3 only read fragments, issue MFMAs and store C (stores
+// only, never waited for).  One barrier per sub-tile:
 //   barrier(j) = "sub-tile j has landed" (the loaders waited for it) + "the MFMA waves are done with sub-tile j - 1" (they arrive after it)
-//   loaders after barrier(j): DMA sub-tile j + 3 into buffer (j + 3) % 4 = the buffer sub-tile j - 1 left
+//   loaders after barrier(j), j >= 1: DMA sub-tile j + 4 into buffer (j + 4) % 5 = the buffer sub-tile j - 1 left
 // The arg-max of a row is kept per lane across the sub-tiles, reduced over the 16 lanes of a DPP row at the end and folded into the
 // row's packed words with ONE atomic per row and workgroup.
 // =============================================================================================
@@ -430,17 +431,17 @@ struct Fn2Args {
     float* C; long ldc;               // [M, V] fp32
     unsigned long long* amax;         // [DK_AMAX_GROUPS][M] packed words (zeroed by the caller) or null
     int M, V, nsub;                   // nsub = 32-column sub-tiles per workgroup
+    int abl;
 };
 
 constexpr int FN2_KT = 8;             // K = 512
 constexpr int FN2_SUB = 32 * FN2_KT * 128;      // bytes of one W2 sub-tile image: 32 KB
 constexpr int FN2_DMA = 8;            // DMA pieces per loader wave and sub-tile
+constexpr int FN2_NB = 5;             // ring buffers: 5 x 32 KB = all 160 KB of LDS
 
 __global__ __launch_bounds__(512) void dec_fn2_kernel(Fn2Args a) {
     extern __shared__ __attribute__((aligned(16))) char dk_smem[];
-    // buffers 2, 3 = the A region (free once the fragments are in registers), buffers 0, 1 behind it
-    char* Areg = dk_smem;                                   // [8][64][128 B] = 64 KB
-    auto buf = [&](int j) -> char* { const int b = j & 3; return dk_smem + (b < 2 ? 2 * FN2_SUB + b * FN2_SUB : (b - 2) * FN2_SUB); };
+    auto buf = [&](int j) -> char* { return dk_smem + (j % FN2_NB) * FN2_SUB; };
     // The workgroups that share a slice of W2 (same column range, different row tile) should share an XCD's L2: the dispatcher deals
     // consecutive workgroup ids round-robin over the 8 XCDs, so id = 8 k + x puts (row tile k % mt, slice x + 8 (k / mt)) on XCD group x.
     // (gridDim.y is a multiple of 8; slices past the last sub-tile exit at once.)  Speed only -- any placement computes the same thing.
@@ -461,37 +462,31 @@ __global__ __launch_bounds__(512) void dec_fn2_kernel(Fn2Args a) {
             const int n0 = (sub0 + j) * 32;
             dk_issue_panel<32, 4>(buf(j), 0, FN2_KT, lw, lane, [&](int r) { return a.W + (long)min(n0 + r, a.V - 1) * a.ldw; });
         };
-        dk_issue_panel<64, 4>(Areg, 0, FN2_KT, lw, lane, [&](int r) { return a.A + (long)min(m0 + r, a.M - 1) * a.lda; });
-        issue_sub(0);
-        if (nsub > 1) issue_sub(1);
-        // only r1 has to be there for A1: the (one or two) sub-tiles requested behind it stay in flight
-        if (nsub > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * FN2_DMA) : "memory");
-        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(FN2_DMA) : "memory");
-        __builtin_amdgcn_s_barrier();                       // A1: the r1 rows are in LDS
-        __builtin_amdgcn_s_barrier();                       // A2: the MFMA waves hold r1 in registers -> buffers 2, 3 are free
-        if (nsub > 2) issue_sub(2);
+        if (!(a.abl & 8)) for (int j = 0; j < min(nsub, FN2_NB); ++j) issue_sub(j);          // the whole ring at once: up to 160 KB in flight per CU
         for (int j = 0; j < nsub; ++j) {
-            // sub-tile j must have landed; younger DMA of this wave: sub-tiles j + 1, j + 2 where they exist (all issued by now)
-            const int younger = min(nsub - 1, j + 2) - j;
-            if (younger >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * FN2_DMA) : "memory");
+            // sub-tile j must have landed; younger DMA of this wave: everything issued after it
+            const int issued_hi = min(nsub - 1, max(FN2_NB - 1, j + FN2_NB - 2));
+            const int younger = issued_hi - j;
+            if (younger >= 4) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * FN2_DMA) : "memory");
+            else if (younger == 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * FN2_DMA) : "memory");
+            else if (younger == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * FN2_DMA) : "memory");
             else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(FN2_DMA) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();                   // barrier(j)
-            if (j + 3 < nsub) issue_sub(j + 3);   // into the buffer sub-tile j - 1 left (j = 0: buffer 3, free since A2)
+            __builtin_amdgcn_s_barrier();                   // barrier(j): sub-tile j is in LDS; the MFMA waves are done with sub-tile j - 1
+            if (j >= 1 && j + FN2_NB - 1 < nsub) issue_sub(j + FN2_NB - 1);     // into the buffer sub-tile j - 1 left
         }
         return;
     }
     // ---------------------------------------------------------------------------------------------- MFMA waves
     const int lr = lane & 15, lq = lane >> 4;
     const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)dk_smem;
-    __builtin_amdgcn_s_barrier();                           // A1
+    // this wave's 16 rows of r1 as MFMA A fragments, straight from global memory (read once per workgroup: no LDS round trip)
     u32x4_t af[2 * FN2_KT];
+    {
+        const bf16_t* arow = a.A + (long)min(m0 + 16 * wave + lr, a.M - 1) * a.lda + lq * 8;
 #pragma unroll
-    for (int ks = 0; ks < 2 * FN2_KT; ++ks)
-        af[ks] = dk_lds_read128(lds_base + (ks >> 1) * 64 * 128 + dk_off(16 * wave + lr, (ks & 1) * 4 + lq));
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_barrier();                           // A2
+        for (int ks = 0; ks < 2 * FN2_KT; ++ks) af[ks] = *reinterpret_cast<const u32x4_t*>(arow + ks * 32);
+    }
     float bestv[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
     int besti[4] = {0x7fffffff, 0x7fffffff, 0x7fffffff, 0x7fffffff};
     for (int j = 0; j < nsub; ++j) {
@@ -518,6 +513,7 @@ __global__ __launch_bounds__(512) void dec_fn2_kernel(Fn2Args a) {
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
+                if (a.abl & 4) break;
                 const bf16x8_t av = __builtin_bit_cast(bf16x8_t, af[4 * g + q]);
                 acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, __builtin_bit_cast(bf16x8_t, bq[g & 1][2 * q]), acc0, 0, 0, 0);
                 acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, __builtin_bit_cast(bf16x8_t, bq[g & 1][2 * q + 1]), acc1, 0, 0, 0);
@@ -529,7 +525,7 @@ __global__ __launch_bounds__(512) void dec_fn2_kernel(Fn2Args a) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const long m = m0 + 16 * wave + 4 * lq + r;
-            if (m < a.M) {
+            if (m < a.M && !(a.abl & 1)) {
                 if (n0 + lr < a.V) a.C[m * a.ldc + n0 + lr] = acc0[r];
                 if (n0 + 16 + lr < a.V) a.C[m * a.ldc + n0 + 16 + lr] = acc1[r];
             }
@@ -537,7 +533,7 @@ __global__ __launch_bounds__(512) void dec_fn2_kernel(Fn2Args a) {
             if (n0 + 16 + lr < a.V && acc1[r] > bestv[r]) { bestv[r] = acc1[r]; besti[r] = n0 + 16 + lr; }
         }
     }
-    if (a.amax) {
+    if (a.amax && !(a.abl & 2)) {
         // the columns a lane saw were ascending, so its strict > kept the FIRST maximal column; now the 16 lanes of a DPP row
         const int grp = slice & (DK_AMAX_GROUPS - 1);
 #pragma unroll
@@ -560,6 +556,7 @@ extern "C" int cst_dec_fn2(const void* A, long lda, const void* W, long ldw, flo
     Fn2Args a;
     a.A = (const bf16_t*)A; a.lda = lda; a.W = (const bf16_t*)W; a.ldw = ldw; a.C = C; a.ldc = ldc;
     a.amax = (unsigned long long*)amax_packed; a.M = M; a.V = V;
+    a.abl = getenv("CST_FN2_ABL") ? atoi(getenv("CST_FN2_ABL")) : 0;
     const int mt = (M + 63) / 64, nsub_tot = (V + 31) / 32;
     int slices = 256 / mt; if (slices < 1) slices = 1; if (slices > nsub_tot) slices = nsub_tot;
     a.nsub = (nsub_tot + slices - 1) / slices;
@@ -569,7 +566,7 @@ extern "C" int cst_dec_fn2(const void* A, long lda, const void* W, long ldw, flo
         (void)hipFuncSetAttribute((const void*)dec_fn2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_done = true;
     }
-    hipLaunchKernelGGL(dec_fn2_kernel, dim3(mt, slices), dim3(512), (size_t)4 * FN2_SUB, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(dec_fn2_kernel, dim3(mt, slices), dim3(512), (size_t)FN2_NB * FN2_SUB, (hipStream_t)stream, a);
     CST_LAUNCH_CHECK("cst_dec_fn2");
     return CST_OK;
 }

@@ -1312,7 +1312,10 @@ static void bgemm_plan(int M, int N, int K, int tile, int splitk, bool has_ws, l
     if (tile == 128) use_big = 1;
     else if (tile == 64) use_big = 0;
     else {
-        use_big = (mid < 256 && K >= 2048);
+        // long-K products with few output tiles (the vocabulary-side dgrads, K = 10 048: 4608 x 512 and 4608 x 1024): one or two 64 x 128
+        // workgroups per CU walking 157 K-tiles one tile ahead are latency-bound; 128 x 128 tiles (+ the split below when they are fewer
+        // than 192) measured 92 -> 58 us and 146 -> 115 us (tools/splitk_probe.py)
+        use_big = (mid < 256 && K >= 2048) || (K >= 4096 && big <= 512);
         if (!use_big && splitk <= 1 && mid >= 256 && big >= 256) {
             const double e64 = (double)mid / (double)(cst_div_up(mid, 768) * 768);
             const double e128 = (double)big / (double)(cst_div_up(big, 512) * 512);
