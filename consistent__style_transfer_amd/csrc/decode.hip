@@ -431,7 +431,6 @@ struct Fn2Args {
     float* C; long ldc;               // [M, V] fp32
     unsigned long long* amax;         // [DK_AMAX_GROUPS][M] packed words (zeroed by the caller) or null
     int M, V, nsub;                   // nsub = 32-column sub-tiles per workgroup
-    int abl;
 };
 
 constexpr int FN2_KT = 8;             // K = 512
@@ -462,7 +461,7 @@ __global__ __launch_bounds__(512) void dec_fn2_kernel(Fn2Args a) {
             const int n0 = (sub0 + j) * 32;
             dk_issue_panel<32, 4>(buf(j), 0, FN2_KT, lw, lane, [&](int r) { return a.W + (long)min(n0 + r, a.V - 1) * a.ldw; });
         };
-        if (!(a.abl & 8)) for (int j = 0; j < min(nsub, FN2_NB); ++j) issue_sub(j);          // the whole ring at once: up to 160 KB in flight per CU
+        for (int j = 0; j < min(nsub, FN2_NB); ++j) issue_sub(j);          // the whole ring at once: up to 160 KB in flight per CU
         for (int j = 0; j < nsub; ++j) {
             // sub-tile j must have landed; younger DMA of this wave: everything issued after it
             const int issued_hi = min(nsub - 1, max(FN2_NB - 1, j + FN2_NB - 2));
@@ -513,7 +512,6 @@ __global__ __launch_bounds__(512) void dec_fn2_kernel(Fn2Args a) {
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                if (a.abl & 4) break;
                 const bf16x8_t av = __builtin_bit_cast(bf16x8_t, af[4 * g + q]);
                 acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, __builtin_bit_cast(bf16x8_t, bq[g & 1][2 * q]), acc0, 0, 0, 0);
                 acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, __builtin_bit_cast(bf16x8_t, bq[g & 1][2 * q + 1]), acc1, 0, 0, 0);
@@ -525,7 +523,7 @@ __global__ __launch_bounds__(512) void dec_fn2_kernel(Fn2Args a) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const long m = m0 + 16 * wave + 4 * lq + r;
-            if (m < a.M && !(a.abl & 1)) {
+            if (m < a.M) {
                 if (n0 + lr < a.V) a.C[m * a.ldc + n0 + lr] = acc0[r];
                 if (n0 + 16 + lr < a.V) a.C[m * a.ldc + n0 + 16 + lr] = acc1[r];
             }
@@ -533,7 +531,7 @@ __global__ __launch_bounds__(512) void dec_fn2_kernel(Fn2Args a) {
             if (n0 + 16 + lr < a.V && acc1[r] > bestv[r]) { bestv[r] = acc1[r]; besti[r] = n0 + 16 + lr; }
         }
     }
-    if (a.amax && !(a.abl & 2)) {
+    if (a.amax) {
         // the columns a lane saw were ascending, so its strict > kept the FIRST maximal column; now the 16 lanes of a DPP row
         const int grp = slice & (DK_AMAX_GROUPS - 1);
 #pragma unroll
@@ -556,7 +554,6 @@ extern "C" int cst_dec_fn2(const void* A, long lda, const void* W, long ldw, flo
     Fn2Args a;
     a.A = (const bf16_t*)A; a.lda = lda; a.W = (const bf16_t*)W; a.ldw = ldw; a.C = C; a.ldc = ldc;
     a.amax = (unsigned long long*)amax_packed; a.M = M; a.V = V;
-    a.abl = getenv("CST_FN2_ABL") ? atoi(getenv("CST_FN2_ABL")) : 0;
     const int mt = (M + 63) / 64, nsub_tot = (V + 31) / 32;
     int slices = 256 / mt; if (slices < 1) slices = 1; if (slices > nsub_tot) slices = nsub_tot;
     a.nsub = (nsub_tot + slices - 1) / slices;

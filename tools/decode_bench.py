@@ -58,19 +58,6 @@ def k_step():
     k_gates(); k_attn(); k_fn1(); k_fn2()
 
 
-if os.environ.get("CST_FN2_ABL"):
-    for abl in (0, 1, 2, 3, 4, 7, 8, 15):
-        os.environ["CST_FN2_ABL"] = str(abl)
-        for _ in range(3):
-            k_fn2()
-        torch.cuda.synchronize()
-        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        a.record()
-        for _ in range(200):
-            k_fn2()
-        b.record(); torch.cuda.synchronize()
-        print(f"fn2 abl={abl:2d} (1 no stores, 2 no atomics, 4 no mfma, 8 no dma): {a.elapsed_time(b) * 1000 / 200:7.2f} us (eager back-to-back)", flush=True)
-    sys.exit(0)
 for name, fn, per in (("one-block fill", k_fill, 1), ("dec_gates", k_gates, 1), ("dec_attn", k_attn, 1), ("skinny fn_1", k_fn1, 1), ("dec_fn2", k_fn2, 1),
                       ("fn_2 generic + argmax", k_fn2_generic, 1), ("whole step (4 launches)", k_step, 4)):
     for _ in range(3):
