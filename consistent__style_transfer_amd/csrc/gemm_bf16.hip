@@ -1317,9 +1317,11 @@ static void bgemm_plan(int M, int N, int K, int tile, int splitk, bool has_ws, l
         // than 192) measured 92 -> 58 us and 146 -> 115 us (tools/splitk_probe.py)
         use_big = (mid < 256 && K >= 2048) || (K >= 4096 && big <= 512);
         if (!use_big && splitk <= 1 && mid >= 256 && big >= 256) {
-            const double e64 = (double)mid / (double)(cst_div_up(mid, 768) * 768);
+            // round 3 (tools/gemm_bench.py enc, tools/blas_reference.py): once both tilings fill the chip the 128 x 128 / 8-wave form is the
+            // faster one (9216 x 2304 x 768: 47.8 against 52.4 us, 4608 x 10000 x 768: 96 against 107, 9216 x 1536 x 512: 25.7 against 27.4)
+            // EXCEPT when its last round is nearly empty -- 576 tiles on 512 slots (4608 x 2048 x 768 / x 512): 27.9 against 25.9
             const double e128 = (double)big / (double)(cst_div_up(big, 512) * 512);
-            if (e128 > e64 + 0.15) use_big = 1;
+            if (e128 >= 0.6) use_big = 1;
         }
     }
     const long tiles = use_big ? big : mid;
