@@ -565,7 +565,7 @@ __global__ void adam_clipped_kernel(float* __restrict__ p, const float* __restri
     const float step_size = lr / bc1, rbc2 = 1.f / sqrtf(bc2);
     const float norm = sqrtf(*sumsq);
     const float coef = max_norm / (norm + 1e-6f);
-    const bool scale = coef < 1.f;
+    const bool scale = !(coef >= 1.f);         // as clip_scale_kernel: a NaN norm gives a NaN coefficient that IS applied (torch.nn.utils.clip_grad_norm_ does the same)
     EW_LOOP(i, n) {
         const float g0 = g[i];
         const float gi = scale ? g0 * coef : g0;

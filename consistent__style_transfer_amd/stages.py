@@ -72,6 +72,16 @@ def bucketed_backward(loss, stack, group, head_params, embed_params, reducer, la
     taps = stack.taps
     n = len(stack.layers)
     assert taps is not None and len(taps) == n + 1, "EncoderStack.taps was not recorded for this forward pass"
+    # the buckets are picked by convention (head, layers, everything named *embedding*): make sure they are a partition of the group --
+    # a parameter outside them would get neither a gradient nor an all-reduce on this path only (checked once per group)
+    if not getattr(group, "_buckets_checked", False):
+        covered = [id(p) for p in head_params] + [id(p) for l in stack.layers for p in l.parameters()] + [id(p) for p in embed_params]
+        assert len(covered) == len(set(covered)) and set(covered) == {id(p) for p in group.params}, \
+            f"bucketed_backward({tag}): head + layers + embeddings do not partition the optimizer group"
+        spans = sorted([group.span(head_params)] + [group.span(list(l.parameters())) for l in stack.layers] + [group.span(embed_params)])
+        assert spans[0][0] == 0 and spans[-1][1] == group.total and all(a[1] == b[0] for a, b in zip(spans, spans[1:])), \
+            f"bucketed_backward({tag}): the bucket spans do not tile the flat gradient buffer"
+        group._buckets_checked = True
     group.direct = True
     try:
         grads = torch.autograd.grad(loss, [taps[n]] + head_params)
