@@ -321,6 +321,7 @@ struct SkinnyArgs {
     const bf16_t* A; long lda; const bf16_t* B; long ldb;
     float* C; long ldc; bf16_t* Cb; long ldcb;
     const float* bias; int act;               // 0 none, 1 relu, 2 LeakyReLU(0.1)
+    CstDrop drop;                             // dropout over the (M, N) index space, applied last
     int M, N, K;
 };
 
@@ -354,6 +355,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_skinny_kernel(SkinnyArgs a) {
     const f32x4_t hi = *reinterpret_cast<const f32x4_t*>(ex + ((wave & 3) * 64 + lane) * 4);
     const int n = n0 + 16 * wn + lr;
     const float bv = a.bias ? a.bias[n] : 0.f;
+    const uint32_t dseed = a.drop.p > 0.f ? cst_drop_seed(a.drop) : 0u;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const long m = m0 + 16 * wm + 4 * lq + r;
@@ -361,13 +363,15 @@ __global__ __launch_bounds__(512) void gemm_bf16_skinny_kernel(SkinnyArgs a) {
         float v = (acc[0][r] + hi[r]) + bv;
         if (a.act == 1) v = v > 0.f ? v : 0.f;
         else if (a.act == 2) v = v > 0.f ? v : 0.1f * v;
+        if (a.drop.p > 0.f) v *= cst_drop_mask(a.drop, dseed, (uint32_t)(m * a.N + n));
         if (a.C) a.C[m * a.ldc + n] = v;
         if (a.Cb) a.Cb[m * a.ldcb + n] = dk_f2bf(v);
     }
 }
 
 extern "C" int cst_gemm_bf16_skinny(const void* A, long lda, const void* B, long ldb, float* C, long ldc, void* Cb, long ldcb,
-                                    int M, int N, int K, const float* bias, int act, void* stream) {
+                                    int M, int N, int K, const float* bias, int act,
+                                    float drop_p, uint32_t drop_seed, uint32_t drop_stream, const void* drop_seed_dev, void* stream) {
     CST_REQUIRE(A && B && (C || Cb), "cst_gemm_bf16_skinny: null operand");
     CST_REQUIRE(M > 0 && N > 0 && K > 0 && N % 32 == 0 && K % 64 == 0, "cst_gemm_bf16_skinny: N=%d must be a multiple of 32, K=%d of 64 (M=%d)", N, K, M);
     CST_REQUIRE((long)(K / 64) * 64 * 128 <= 160 * 1024, "cst_gemm_bf16_skinny: K=%d does not fit the LDS whole (max 1280)", K);
@@ -377,6 +381,7 @@ extern "C" int cst_gemm_bf16_skinny(const void* A, long lda, const void* B, long
     SkinnyArgs a;
     a.A = (const bf16_t*)A; a.lda = lda; a.B = (const bf16_t*)B; a.ldb = ldb; a.C = C; a.ldc = ldc; a.Cb = (bf16_t*)Cb; a.ldcb = ldcb;
     a.bias = bias; a.act = act; a.M = M; a.N = N; a.K = K;
+    a.drop = cst_make_drop(drop_p, drop_seed, drop_stream, drop_seed_dev, (long)M * N);
     static bool attr_done = false;
     if (!attr_done) {
         (void)hipFuncSetAttribute((const void*)gemm_bf16_skinny_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);

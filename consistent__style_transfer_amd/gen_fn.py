@@ -258,7 +258,7 @@ class GeneratorFn(torch.autograd.Function):
                          None, 0, idb_s, T * W_, *drop.at(STREAM_G_FFN + s).args())
                 r1b_s = r1b[:, s * Hd:(s + 1) * Hd]
                 call("cst_gemm_bf16_skinny", idb_s, T * W_, fn1_b, fn1_b.stride(0), r12[:, s * Hd:(s + 1) * Hd], T * Hd, r1b_s, T * Hd,
-                     B, Hd, W_, P["fn_1.bias"], 2)
+                     B, Hd, W_, P["fn_1.bias"], 2, *NO_DROP.args())
                 if Hd == 512 and os.environ.get("CST_FN2_GENERIC") != "1":
                     call("cst_dec_fn2", r1b_s, T * Hd, fn2_b, fn2_b.stride(0), out2[:, s * V:(s + 1) * V], T * V, B, V, Hd, amax[s])
                 else:
@@ -417,7 +417,10 @@ class GeneratorFn(torch.autograd.Function):
                 if use_b:
                     dp1b = dp1b_all[:, s * Hd:(s + 1) * Hd]
                     gemm_bf16(dlb, fn2_t, B, Hd, C=dp1s, Cb=dp1b, aux=r1b[:, s * Hd:(s + 1) * Hd], act=4)   # through LeakyReLU
-                    gemm_bf16(dp1b, fn1_t, B, W_, C=diffn, drop=fd)                                          # through dropout(i_ffn)
+                    if Hd % 64 == 0 and Hd <= 1280 and W_ % 32 == 0:                                         # whole-K product, no split, no reduce launch
+                        call("cst_gemm_bf16_skinny", dp1b, T * Hd, fn1_t, fn1_t.stride(0), diffn, T * W_, None, 0, B, W_, Hd, None, 0, *fd.args())
+                    else:
+                        gemm_bf16(dp1b, fn1_t, B, W_, C=diffn, drop=fd)                                      # through dropout(i_ffn)
                 else:
                     dgrad(dl, P["fn_2.weight"], out=dp1s, aux=r1s, act=4)                   # through LeakyReLU
                     dgrad(dp1s, P["fn_1.weight"], out=diffn, drop=fd)                         # through dropout(i_ffn)

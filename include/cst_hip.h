@@ -347,9 +347,10 @@ int cst_dec_attn(const float* q, long ldq, const float* mem, float* out, long ld
                  float drop_p, uint32_t drop_seed, uint32_t drop_stream, const void* drop_seed_dev, void* stream);
 /* C / Cb [M, N] = act(A[M, K] . B[N, K]^T + bias), bf16 operands with K contiguous, act 0 none / 1 relu / 2 LeakyReLU(0.1): the
  * M = batch products of a decode step that are too small to split (fn_1, rnn.py:79-80): whole K in LDS (K <= 1280), 32 x 32
- * tiles, one launch.  N a multiple of 32, K of 64. */
+ * tiles, one launch; dropout over the (M, N) index space last (the dgrad through dropout(i_ffn), rnn.py:79).  N a multiple of 32, K of 64. */
 int cst_gemm_bf16_skinny(const void* A, long lda, const void* B, long ldb, float* C, long ldc, void* Cb, long ldcb,
-                         int M, int N, int K, const float* bias, int act, void* stream);
+                         int M, int N, int K, const float* bias, int act,
+                         float drop_p, uint32_t drop_seed, uint32_t drop_stream, const void* drop_seed_dev, void* stream);
 /* C[M, N] = A . B^T as cst_gemm_bf16 without epilogue operands, plus the arg-max of every row.  amax_packed: G = cst_argmax_groups()
  * words of 8 bytes per row, group-major [G][M], zeroed by the caller; word (group of a 128-column tile = tile index mod G, row m)
  * receives max over the tile's columns of ((order-preserving bits of C[m, n]) << 32 | (0xFFFFFFFF - n)) by 64-bit atomic max -- the

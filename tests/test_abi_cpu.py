@@ -123,6 +123,6 @@ def test_decode_entry_points_validate_their_limits():
     assert L.fn["cst_argmax_groups"]() in (16, 32, 64)
     assert L.fn["cst_dec_gates"](P, 640, P, 640, None, None, 0, None, None, 0, 0, 0.0, 0, 0, None, None, 0, P, P, 512,
                                  P, 2048, P, 512, P, 512, None, 0, 256, 64, 512, None) == 1 and "E == 128" in L.last_error()
-    assert L.fn["cst_gemm_bf16_skinny"](P, 2048, P, 2048, P, 512, None, 0, 256, 512, 2048, None, 0, None) == 1 and "whole" in L.last_error()
+    assert L.fn["cst_gemm_bf16_skinny"](P, 2048, P, 2048, P, 512, None, 0, 256, 512, 2048, None, 0, 0.0, 0, 0, None, None) == 1 and "whole" in L.last_error()
     assert L.fn["cst_dec_fn2"](P, 640, P, 640, P, 10000, 256, 10000, 640, None, None) == 1 and "K = 512" in L.last_error()
     assert L.fn["cst_dec_attn"](P, 1024, P, P, 1024, P, 4, 18, 256, None, 0, 0.0, 0, 0, None, None) == 1 and "D == 512" in L.last_error()

@@ -1111,10 +1111,11 @@ def test_gemm_bf16_skinny(ops, shape, act):
     Bb, _ = ops.cast_bf16(dev(Bm), want_t=False)
     C = torch.full((M, N), float("nan"), device="cuda")
     Cb = torch.zeros(M, N, device="cuda", dtype=torch.int16)
-    call("cst_gemm_bf16_skinny", Ab, Ab.stride(0), Bb, Bb.stride(0), C, N, Cb, N, M, N, K, dev(bias), act)
+    d = ops.Drop(0.2, 4, 77) if act == 2 else ops.NO_DROP
+    call("cst_gemm_bf16_skinny", Ab, Ab.stride(0), Bb, Bb.stride(0), C, N, Cb, N, M, N, K, dev(bias), act, *d.args())
     ref = _bf(A) @ _bf(Bm).t() + bias
     if act == 2:
-        ref = torch.where(ref > 0, ref, 0.1 * ref)
+        ref = torch.where(ref > 0, ref, 0.1 * ref) * torch.from_numpy(orng.dropout_mask(4, 77, (M, N), 0.2))
     close(C, ref, 2e-3, 2e-3 * math.sqrt(K), f"{shape}")
     assert torch.equal(Cb.view(torch.bfloat16).float().cpu(), _bf(C.cpu()))
 

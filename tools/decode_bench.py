@@ -43,7 +43,7 @@ def k_attn():
 
 
 def k_fn1():
-    call("cst_gemm_bf16_skinny", idb, W_, fn1_b, fn1_b.stride(0), r1, Hd, r1b, Hd, B, Hd, W_, bias[:Hd], 2)
+    call("cst_gemm_bf16_skinny", idb, W_, fn1_b, fn1_b.stride(0), r1, Hd, r1b, Hd, B, Hd, W_, bias[:Hd], 2, *ops.NO_DROP.args())
 
 
 def k_fn2():
