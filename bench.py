@@ -454,7 +454,7 @@ def main():
         # HBM traffic per launch cannot be measured inside this process (PMC counters need rocprofv3 around it): it is
         # read from the committed summary of the same workload (tools/profile_pmc.sh) and the JSON line says so
         pmc, traffic_source = {}, None
-        for cand in ("round2_pmc_traffic.json", "round1_pmc_traffic.json"):
+        for cand in ("round3_pmc_traffic.json", "round2_pmc_traffic.json", "round1_pmc_traffic.json"):
             pmc_path = os.path.join(REPO, "profiles", cand)
             if os.path.exists(pmc_path):
                 blob = json.load(open(pmc_path))
