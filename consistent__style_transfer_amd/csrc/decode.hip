@@ -597,3 +597,175 @@ extern "C" int cst_unpack_argmax(const void* packed, int64_t* ids, long n, int s
     CST_LAUNCH_CHECK("cst_unpack_argmax");
     return CST_OK;
 }
+
+// =============================================================================================
+// cst_dec_attn_cell_bwd: one step of the soft decode's backward behind the fn_1 dgrad -- the single-query attention backward
+// (rnn.py:46-50) and the LSTM cell backward (rnn.py:75) of one batch row in one workgroup.
+//
+//   g = d[h_s | a_s] (the dropped FFN-input gradient);  dp_j = g_a . mem_j;  ds_j = p_j (dp_j - sum_i p_i dp_i) / sqrt(D);
+//   d h_s = g_h + sum_j ds_j mem_j + dh2 (the recurrent gradient from step s + 1)  ->  dgates_s, dc_{s-1}.
+//
+// Thread t owns dimensions 2t, 2t + 1 as in dec_attn_kernel: the row's encoder states go straight into registers, are used for the
+// L' dot products and for the weighted sum, and the cell backward of the thread's two hidden units follows in the same registers.
+// d memory is NOT touched here: the step stores its L' values ds_j, and cst_dec_attn_dmem adds every step's p_j g_a + ds_j h_s in
+// one launch after the loop -- the per-step read-modify-write of the (L', D) gradient tile (2/3 of the old kernel's traffic) is gone.
+// =============================================================================================
+struct AttnCellBwdArgs {
+    const float* g; long ldg; const float* mem; const float* p; float* ds_out;
+    const float* gates; long ldgt; const float* c_prev; long ldcp; const float* c_new; long ldcn;
+    const float* dh2; long lddh2; const float* dc; long lddc;
+    float* dgates; long lddg; float* dc_prev; long lddcp; bf16_t* dgb; long lddgb;
+    int L; float scale;
+};
+
+template <int LMAX>
+__global__ __launch_bounds__(256) void dec_attn_cell_bwd_kernel(AttnCellBwdArgs a) {
+    constexpr int D = 512;
+    __shared__ float red[4][LMAX];
+    __shared__ float ps[LMAX];
+    const int b = blockIdx.x, t = threadIdx.x, lane = t & 63, w = t >> 6, L = a.L;
+    const float* gb = a.g + (long)b * a.ldg;
+    const float2 gh = *reinterpret_cast<const float2*>(gb + 2 * t);
+    const float2 ga = *reinterpret_cast<const float2*>(gb + D + 2 * t);
+    const float pv = a.p[(long)b * L + min(t, L - 1)];
+    // the cell's operands travel with the memory tile: one round trip for everything the row needs
+    const float* gt = a.gates + (long)b * a.ldgt + 2 * t;
+    const float2 gi = *reinterpret_cast<const float2*>(gt), gf = *reinterpret_cast<const float2*>(gt + D);
+    const float2 gg = *reinterpret_cast<const float2*>(gt + 2 * D), go = *reinterpret_cast<const float2*>(gt + 3 * D);
+    const float2 cp = *reinterpret_cast<const float2*>(a.c_prev + (long)b * a.ldcp + 2 * t);
+    const float2 cn = *reinterpret_cast<const float2*>(a.c_new + (long)b * a.ldcn + 2 * t);
+    const float2 d2 = a.dh2 ? *reinterpret_cast<const float2*>(a.dh2 + (long)b * a.lddh2 + 2 * t) : make_float2(0.f, 0.f);
+    const float2 dcv = a.dc ? *reinterpret_cast<const float2*>(a.dc + (long)b * a.lddc + 2 * t) : make_float2(0.f, 0.f);
+    const float* mb = a.mem + (long)b * L * D + 2 * t;
+    float2 m[LMAX];
+#pragma unroll
+    for (int j = 0; j < LMAX; ++j) m[j] = j < L ? *reinterpret_cast<const float2*>(mb + (long)j * D) : make_float2(0.f, 0.f);
+    if (t < L) ps[t] = pv;
+#pragma unroll
+    for (int j = 0; j < LMAX; ++j) {
+        if (j < L) {                                       // wave-uniform
+            const float s = wave_sum(ga.x * m[j].x + ga.y * m[j].y);
+            if (lane == 0) red[w][j] = s;
+        }
+    }
+    __syncthreads();
+    float dsj[LMAX], delta = 0.f;
+#pragma unroll
+    for (int j = 0; j < LMAX; ++j) {
+        dsj[j] = j < L ? (red[0][j] + red[1][j]) + (red[2][j] + red[3][j]) : 0.f;
+        delta += j < L ? ps[j] * dsj[j] : 0.f;
+    }
+    float2 dq = make_float2(0.f, 0.f);
+#pragma unroll
+    for (int j = 0; j < LMAX; ++j) {
+        const float d = j < L ? ps[j] * (dsj[j] - delta) * a.scale : 0.f;
+        dq.x += d * m[j].x; dq.y += d * m[j].y;
+        if (t == j && j < L) a.ds_out[(long)b * L + j] = d;
+    }
+    const float dh[2] = {gh.x + dq.x + d2.x, gh.y + dq.y + d2.y};
+    const float iv[2] = {gi.x, gi.y}, fv[2] = {gf.x, gf.y}, gv[2] = {gg.x, gg.y}, ov[2] = {go.x, go.y};
+    const float cpv[2] = {cp.x, cp.y}, cnv[2] = {cn.x, cn.y}, dci[2] = {dcv.x, dcv.y};
+    float g0[2], g1[2], g2[2], g3[2], dcp[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {                          // as lstm_cell_bwd_kernel (pointwise.hip)
+        const float tc = tanhf(cnv[u]);
+        const float dct = dci[u] + dh[u] * ov[u] * (1.f - tc * tc);
+        g0[u] = dct * gv[u] * iv[u] * (1.f - iv[u]);
+        g1[u] = dct * cpv[u] * fv[u] * (1.f - fv[u]);
+        g2[u] = dct * iv[u] * (1.f - gv[u] * gv[u]);
+        g3[u] = dh[u] * tc * ov[u] * (1.f - ov[u]);
+        dcp[u] = dct * fv[u];
+    }
+    float* dg = a.dgates + (long)b * a.lddg + 2 * t;
+    *reinterpret_cast<float2*>(dg) = make_float2(g0[0], g0[1]);
+    *reinterpret_cast<float2*>(dg + D) = make_float2(g1[0], g1[1]);
+    *reinterpret_cast<float2*>(dg + 2 * D) = make_float2(g2[0], g2[1]);
+    *reinterpret_cast<float2*>(dg + 3 * D) = make_float2(g3[0], g3[1]);
+    if (a.dgb) {
+        unsigned* q = reinterpret_cast<unsigned*>(a.dgb + (long)b * a.lddgb);
+        q[t] = dk_pack2(g0[0], g0[1]); q[D / 2 + t] = dk_pack2(g1[0], g1[1]);
+        q[D + t] = dk_pack2(g2[0], g2[1]); q[3 * D / 2 + t] = dk_pack2(g3[0], g3[1]);
+    }
+    *reinterpret_cast<float2*>(a.dc_prev + (long)b * a.lddcp + 2 * t) = make_float2(dcp[0], dcp[1]);
+}
+
+extern "C" int cst_dec_attn_cell_bwd(const float* g, long ldg, const float* mem, const float* p, float* ds_out, int B, int L, int D,
+                                     const float* gates, long ldgt, const float* c_prev, long ldcp, const float* c_new, long ldcn,
+                                     const float* dh2, long lddh2, const float* dc, long lddc,
+                                     float* dgates, long lddg, float* dc_prev, long lddcp, void* dgates_bf16, long lddgb, void* stream) {
+    CST_REQUIRE(g && mem && p && ds_out && gates && c_prev && c_new && dgates && dc_prev && B > 0, "cst_dec_attn_cell_bwd: null pointer");
+    CST_REQUIRE(D == 512 && L > 0 && L <= 64, "cst_dec_attn_cell_bwd: needs D == 512 and L <= 64 (D=%d, L=%d)", D, L);
+    CST_REQUIRE(ldg >= 2 * D && ldgt >= 4 * D && lddg >= 4 * D && (!dgates_bf16 || lddgb >= 4 * D), "cst_dec_attn_cell_bwd: leading dimension too small");
+    const long lds_or = ldg | ldgt | ldcp | ldcn | lddg | lddcp | (dh2 ? lddh2 : 0) | (dc ? lddc : 0) | (dgates_bf16 ? lddgb : 0);
+    const uintptr_t ptr_or = (uintptr_t)g | (uintptr_t)mem | (uintptr_t)gates | (uintptr_t)c_prev | (uintptr_t)c_new | (uintptr_t)dh2 | (uintptr_t)dc |
+                             (uintptr_t)dgates | (uintptr_t)dc_prev;
+    CST_REQUIRE(lds_or % 2 == 0 && (ptr_or & 7) == 0 && (((uintptr_t)dgates_bf16) & 3) == 0, "cst_dec_attn_cell_bwd: rows must be 8-byte aligned");
+    AttnCellBwdArgs a{g, ldg, mem, p, ds_out, gates, ldgt, c_prev, ldcp, c_new, ldcn, dh2, lddh2, dc, lddc, dgates, lddg, dc_prev, lddcp,
+                      (bf16_t*)dgates_bf16, lddgb, L, 1.0f / sqrtf((float)D)};
+    hipStream_t st = (hipStream_t)stream;
+    if (L <= 24) hipLaunchKernelGGL(dec_attn_cell_bwd_kernel<24>, dim3(B), dim3(256), 0, st, a);
+    else if (L <= 40) hipLaunchKernelGGL(dec_attn_cell_bwd_kernel<40>, dim3(B), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(dec_attn_cell_bwd_kernel<64>, dim3(B), dim3(256), 0, st, a);
+    CST_LAUNCH_CHECK("cst_dec_attn_cell_bwd");
+    return CST_OK;
+}
+
+// d memory of all T steps of the soft decode in one launch: dmem[b, j, :] += sum_s p[s, b, j] g_a[b, s, :] + ds[s, b, j] h[b, s, :]
+// (the two outer products cst_dot_attn_bwd adds per step).  One workgroup per batch row, thread t owns dimensions 2t, 2t + 1.
+template <int LMAX>
+__global__ __launch_bounds__(256) void dec_attn_dmem_kernel(const float* __restrict__ ga, long ldga, long ga_step, const float* __restrict__ h, long ldh, long h_step,
+                                                            const float* __restrict__ p, const float* __restrict__ ds, float* __restrict__ dmem,
+                                                            int B, int T, int L) {
+    constexpr int D = 512;
+    extern __shared__ float pd[];                          // [T][2][L]
+    const int b = blockIdx.x, t = threadIdx.x;
+    for (int e = t; e < T * L; e += 256) {
+        const int s = e / L, j = e % L;
+        pd[(s * 2) * L + j] = p[((long)s * B + b) * L + j];
+        pd[(s * 2 + 1) * L + j] = ds[((long)s * B + b) * L + j];
+    }
+    __syncthreads();
+    float2 acc[LMAX];
+#pragma unroll
+    for (int j = 0; j < LMAX; ++j) acc[j] = make_float2(0.f, 0.f);
+    const float* gr = ga + (long)b * ldga + 2 * t;
+    const float* hr = h + (long)b * ldh + 2 * t;
+    float2 gv = *reinterpret_cast<const float2*>(gr), hv = *reinterpret_cast<const float2*>(hr);
+    for (int s = 0; s < T; ++s) {
+        const int sn = min(s + 1, T - 1);
+        const float2 gn = *reinterpret_cast<const float2*>(gr + sn * ga_step), hn = *reinterpret_cast<const float2*>(hr + sn * h_step);
+        const float* pr = pd + (s * 2) * L;
+#pragma unroll
+        for (int j = 0; j < LMAX; ++j) {
+            if (j < L) {
+                const float pj = pr[j], dj = pr[L + j];
+                acc[j].x += pj * gv.x + dj * hv.x; acc[j].y += pj * gv.y + dj * hv.y;
+            }
+        }
+        gv = gn; hv = hn;
+    }
+    float* o = dmem + (long)b * L * D + 2 * t;
+#pragma unroll
+    for (int j = 0; j < LMAX; ++j) {
+        if (j < L) {
+            float2 v = *reinterpret_cast<float2*>(o + (long)j * D);
+            v.x += acc[j].x; v.y += acc[j].y;
+            *reinterpret_cast<float2*>(o + (long)j * D) = v;
+        }
+    }
+}
+
+// ga: g_a of step s, row b at ga[b * ldga + s * ga_step + 0..D); h likewise; p, ds: [T][B][L]; dmem [B][L][D] accumulated into
+extern "C" int cst_dec_attn_dmem(const float* ga, long ldga, long ga_step, const float* h, long ldh, long h_step,
+                                 const float* p, const float* ds, float* dmem, int B, int T, int L, int D, void* stream) {
+    CST_REQUIRE(ga && h && p && ds && dmem && B > 0 && T > 0, "cst_dec_attn_dmem: null pointer");
+    CST_REQUIRE(D == 512 && L > 0 && L <= 64 && (size_t)T * 2 * L * sizeof(float) <= 64 * 1024, "cst_dec_attn_dmem: needs D == 512, L <= 64 (D=%d, L=%d, T=%d)", D, L, T);
+    CST_REQUIRE((ldga | ga_step | ldh | h_step) % 2 == 0 && ((((uintptr_t)ga) | ((uintptr_t)h) | ((uintptr_t)dmem)) & 7) == 0, "cst_dec_attn_dmem: rows must be 8-byte aligned");
+    hipStream_t st = (hipStream_t)stream;
+    const size_t lds = (size_t)T * 2 * L * sizeof(float);
+    if (L <= 24) hipLaunchKernelGGL(dec_attn_dmem_kernel<24>, dim3(B), dim3(256), lds, st, ga, ldga, ga_step, h, ldh, h_step, p, ds, dmem, B, T, L);
+    else if (L <= 40) hipLaunchKernelGGL(dec_attn_dmem_kernel<40>, dim3(B), dim3(256), lds, st, ga, ldga, ga_step, h, ldh, h_step, p, ds, dmem, B, T, L);
+    else hipLaunchKernelGGL(dec_attn_dmem_kernel<64>, dim3(B), dim3(256), lds, st, ga, ldga, ga_step, h, ldh, h_step, p, ds, dmem, B, T, L);
+    CST_LAUNCH_CHECK("cst_dec_attn_dmem");
+    return CST_OK;
+}

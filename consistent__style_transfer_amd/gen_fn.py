@@ -79,15 +79,21 @@ def _cell_bwd(gates, c_prev, c_new, dh, dh2, dc, dgates, dc_prev, B, H, dgb=None
 def _lstm_frag_order(wb, H):
     """bf16 W_hh [4H, H] (K contiguous) -> the MFMA-fragment order cst_lstm_seq_fwd streams:
     [wave][gate][tile][k step][lane = 16 lq + lr][8], element = W_hh[q*H + 64w + 16j + lr][32kk + 8lq + e]."""
-    v = wb[:, :H].reshape(4, 4, H // 64, 16, H // 32, 4, 8)           # (q, w, j, lr, kk, lq, e)
-    return v.permute(1, 0, 2, 4, 5, 3, 6).contiguous()               # (w, q, j, kk, lq, lr, e)
+    hit = getattr(wb, "_cst_frag", None)          # the bf16 copy lives as long as its optimizer version (ops.weight_bf16): so does its re-ordering
+    if hit is None:
+        v = wb[:, :H].reshape(4, 4, H // 64, 16, H // 32, 4, 8)       # (q, w, j, lr, kk, lq, e)
+        hit = wb._cst_frag = v.permute(1, 0, 2, 4, 5, 3, 6).contiguous()   # (w, q, j, kk, lq, lr, e)
+    return hit
 
 
 def _lstm_frag_order_t(wt, H):
     """bf16 W_hh^T [H, 4H] (K = 4H contiguous) -> the fragment order cst_lstm_seq_bwd streams:
     [wave][k step][tile][lane = 16 lq + lr][8], element = W_hh^T[64w + 16j + lr][32kk + 8lq + e]."""
-    v = wt[:, :4 * H].reshape(4, H // 64, 16, 4 * H // 32, 4, 8)      # (w, j, lr, kk, lq, e)
-    return v.permute(0, 3, 1, 4, 2, 5).contiguous()                  # (w, kk, j, lq, lr, e)
+    hit = getattr(wt, "_cst_frag", None)
+    if hit is None:
+        v = wt[:, :4 * H].reshape(4, H // 64, 16, 4 * H // 32, 4, 8)  # (w, j, lr, kk, lq, e)
+        hit = wt._cst_frag = v.permute(0, 3, 1, 4, 2, 5).contiguous()      # (w, kk, j, lq, lr, e)
+    return hit
 
 
 def _bf16_ok(*dims):
@@ -393,6 +399,9 @@ class GeneratorFn(torch.autograd.Function):
                     _gemm_cell_bwd([dict(Ab=dgdb_all[s + 1], Bb=wcat_t, gates=gdec[s], c_prev=c_prev, c_new=cdec[s], dh_extra=diffn[:, :Hd],
                                          dc_in=dc, dgates=dgd[s], dc_prev=dc, dgb=dgdb_all[s], n_extra=E, extra_out=dXH_all[s + 1][:, :E])], B, Hd)
             gemm_bf16(dgdb_all[0], wcat_t, B, E + Hd, C=dXH_all[0])
+        # soft decode: attention backward + cell backward of a step in one launch, the steps' d memory in one launch after the loop
+        attn_cell = (not steps_fused) and Hd == 512 and Lp <= 64
+        ds_all = _new(dev, T, B, Lp) if attn_cell else None
         for s in (() if steps_fused else range(T - 1, -1, -1)):
             dl = dout2[:, s * V:(s + 1) * V]
             dXH = dXH_all[s + 1] if s + 1 < T else None        # written by step s+1's dgrad below
@@ -426,16 +435,24 @@ class GeneratorFn(torch.autograd.Function):
                     dgrad(dp1s, P["fn_1.weight"], out=diffn, drop=fd)                         # through dropout(i_ffn)
             elif fd.p > 0:
                 dropout2d(diffn, fd, out=diffn)
-            call("cst_dot_attn_bwd", diffn[:, Hd:], T * W_, if2[:, s * W_:s * W_ + Hd], T * W_, memory, patt[s],
-                 diffn[:, :Hd], T * W_, 1, dmem, B, Lp, Hd)
             c_prev = c0 if s == 0 else cdec[s - 1]
             last = s == T - 1
-            _cell_bwd(gdec[s], c_prev, cdec[s], diffn[:, :Hd], None if last else dXH[:, E:], None if last else dc,
-                      dgd[s], dc, B, Hd, dgb=dgdb_all[s] if use_b else None)
+            dh2 = None if last else dXH[:, E:]
+            dgb = dgdb_all[s] if use_b else None
+            if attn_cell:
+                call("cst_dec_attn_cell_bwd", diffn, T * W_, memory, patt[s], ds_all[s], B, Lp, Hd, gdec[s], gdec[s].stride(0),
+                     c_prev, c_prev.stride(0), cdec[s], cdec[s].stride(0), dh2, _st(dh2), None if last else dc, Hd,
+                     dgd[s], dgd[s].stride(0), dc, Hd, dgb, _st(dgb))
+            else:
+                call("cst_dot_attn_bwd", diffn[:, Hd:], T * W_, if2[:, s * W_:s * W_ + Hd], T * W_, memory, patt[s],
+                     diffn[:, :Hd], T * W_, 1, dmem, B, Lp, Hd)
+                _cell_bwd(gdec[s], c_prev, cdec[s], diffn[:, :Hd], dh2, None if last else dc, dgd[s], dc, B, Hd, dgb=dgb)
             if use_b:
                 gemm_bf16(dgdb_all[s], wcat_t, B, E + Hd, C=dXH_all[s])
             else:
                 dgrad(dgd[s], wcat, out=dXH_all[s])
+        if attn_cell:
+            call("cst_dec_attn_dmem", df2[:, Hd:], T * W_, W_, if2, T * W_, W_, patt, ds_all, dmem, B, T, Lp, Hd)
         # embedding gradients of the tokens fed to steps 1..T-1, all steps in one scatter
         if T > 1:
             S_ = T - 1

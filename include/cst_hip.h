@@ -286,6 +286,17 @@ int cst_lstm_seq_bwd(const void* wt0, const void* wt1, const float* gates0, cons
                      float* dgates0, float* dgates1, void* dgates0_bf16, void* dgates1_bf16,
                      float* dh0, long lddh0, int B, int L, int H, void* stream);
 
+/* Soft decode backward, one step behind the fn_1 dgrad (rnn.py:46-50 attention, :75 LSTM cell): single-query attention backward and cell
+ * backward of every batch row in one launch (D == 512, L <= 64).  g = d[h | a] of the (dropped) FFN input, row b at g + b * ldg; writes the
+ * step's ds [B][L], dgates (fp32 + optional bf16) and dc_prev (may alias dc).  d memory is left to cst_dec_attn_dmem. */
+int cst_dec_attn_cell_bwd(const float* g, long ldg, const float* mem, const float* p, float* ds_out, int B, int L, int D,
+                          const float* gates, long ldgt, const float* c_prev, long ldcp, const float* c_new, long ldcn,
+                          const float* dh2, long lddh2, const float* dc, long lddc,
+                          float* dgates, long lddg, float* dc_prev, long lddcp, void* dgates_bf16, long lddgb, void* stream);
+/* dmem[b, j, :] += sum_s p[s, b, j] ga[b, s] + ds[s, b, j] h[b, s]: the d memory of all T steps after the loop (p, ds: [T][B][L]). */
+int cst_dec_attn_dmem(const float* ga, long ldga, long ga_step, const float* h, long ldh, long h_step,
+                      const float* p, const float* ds, float* dmem, int B, int T, int L, int D, void* stream);
+
 /* One recurrent step of nn.LSTM (rnn.py:25-33, called at rnn.py:57 and :75) in two launches, for one problem
  * or for two independent problems of one shape (the *2 / *_p2 arguments; A2 == NULL: single) -- the two
  * directions of the bidirectional encoder share every dimension and leading dimension.

@@ -1205,3 +1205,58 @@ def test_dec_fn2(ops, shape):
     p2 = torch.zeros(NG, M, device="cuda", dtype=torch.int64)
     call("cst_dec_fn2", Ab, Ab.stride(0), Bb, Bb.stride(0), C2, ldc, M, N, K, p2)
     assert torch.equal(C2[:, :N], C) and torch.equal(p2.max(0).values, packed.max(0).values)
+
+
+@pytest.mark.parametrize("B,L,T", [(256, 18, 3), (16, 40, 2), (5, 64, 2), (33, 7, 4)])
+def test_dec_attn_cell_bwd(ops, B, L, T):
+    """cst_dec_attn_cell_bwd + cst_dec_attn_dmem against a torch autograd restatement of rnn.py:46-50 (single-query attention) and the
+    LSTM cell (rnn.py:75), T chained steps sharing dc and the memory gradient."""
+    from consistent__style_transfer_amd._lib import call
+    D, W_ = 512, 1024
+    mem = rnd(B, L, D, seed=1)
+    hs, g = rnd(B, T, D, seed=2), rnd(B, T, W_, seed=3)                       # h_s; d[h_s | a_s]
+    gates_pre, c_prev = rnd(T, B, 4 * D, seed=4), rnd(T, B, D, seed=5)
+    dh2, dc0 = rnd(T, B, D, seed=6), rnd(B, D, seed=7)
+    # forward restatement with autograd
+    memr = mem.clone().requires_grad_(True)
+    dmem_ref = torch.zeros_like(mem)
+    want_dg, want_ds, dc = [], [], dc0.clone()
+    act, cnew, patt = [], [], []
+    for s in range(T):
+        gp = gates_pre[s]
+        i, f, gg, o = torch.sigmoid(gp[:, :D]), torch.sigmoid(gp[:, D:2 * D]), torch.tanh(gp[:, 2 * D:3 * D]), torch.sigmoid(gp[:, 3 * D:])
+        act.append(torch.cat([i, f, gg, o], 1))
+        cnew.append(f * c_prev[s] + i * gg)
+        patt.append(torch.softmax(torch.einsum("bd,bld->bl", hs[:, s], mem) / math.sqrt(D), -1))
+    for s in range(T - 1, -1, -1):
+        h = hs[:, s].clone().requires_grad_(True)
+        a = torch.einsum("bl,bld->bd", torch.softmax(torch.einsum("bd,bld->bl", h, memr) / math.sqrt(D), -1), memr)
+        gq, gm = torch.autograd.grad((a * g[:, s, D:]).sum(), [h, memr])
+        dmem_ref += gm
+        dh = g[:, s, :D] + gq + dh2[s]
+        gp = gates_pre[s].clone().requires_grad_(True)
+        cp = c_prev[s].clone().requires_grad_(True)
+        i, f, gg, o = torch.sigmoid(gp[:, :D]), torch.sigmoid(gp[:, D:2 * D]), torch.tanh(gp[:, 2 * D:3 * D]), torch.sigmoid(gp[:, 3 * D:])
+        c = f * cp + i * gg
+        hh = o * torch.tanh(c)
+        dgp, dcp = torch.autograd.grad((hh * dh).sum() + (c * dc).sum(), [gp, cp])
+        want_dg.append(dgp)
+        dc = dcp
+    want_dg = want_dg[::-1]
+    # device
+    gd, memd, hsd = dev(g.reshape(B, T * W_)), dev(mem), dev(hs.reshape(B, T * D))
+    pd, actd, cpd, cnd, dh2d = dev(torch.stack(patt)), dev(torch.stack(act)), dev(c_prev), dev(torch.stack(cnew)), dev(dh2)
+    dcd = dev(dc0)
+    ds_all = torch.full((T, B, L), float("nan"), device="cuda")
+    dgd = torch.full((T, B, 4 * D), float("nan"), device="cuda")
+    dgb = torch.zeros(T, B, 4 * D, device="cuda", dtype=torch.int16)
+    for s in range(T - 1, -1, -1):
+        call("cst_dec_attn_cell_bwd", gd[:, s * W_:], T * W_, memd, pd[s], ds_all[s], B, L, D, actd[s], 4 * D, cpd[s], D, cnd[s], D,
+             dh2d[s], D, dcd, D, dgd[s], 4 * D, dcd, D, dgb[s], 4 * D)
+    dmem = torch.zeros(B, L, D, device="cuda")
+    call("cst_dec_attn_dmem", gd[:, D:], T * W_, W_, hsd, T * D, D, pd, ds_all, dmem, B, T, L, D)
+    for s in range(T):
+        close(dgd[s], want_dg[s], 2e-4, 2e-5, f"dgates step {s}")
+    assert torch.equal(dgb.view(torch.bfloat16).float().cpu(), _bf(dgd.cpu()))
+    close(dcd, dc, 2e-4, 2e-5, "dc")
+    close(dmem, dmem_ref, 2e-4, 2e-5, "dmem")
