@@ -769,3 +769,137 @@ extern "C" int cst_dec_attn_dmem(const float* ga, long ldga, long ga_step, const
     CST_LAUNCH_CHECK("cst_dec_attn_dmem");
     return CST_OK;
 }
+
+// =============================================================================================
+// cst_dec_dxe: the straight-through gradient of the soft decode (rnn.py:84-85), one step: C[M, V] += dropout(g)[M, 128] . E[V, 128]^T
+//
+// 0.66 GFLOP against a read-modify-write of the step's (M, V) gradient block: an HBM-bound accumulate with a product inside.
+// The 16 batch rows of a wave are the MFMA's B operand (dropout applied and rounded to bf16 on the way into registers, kept for the
+// whole launch; the workgroups of slice 0 also write the dropped fp32 rows -- the operand of the embedding scatter after the loop), each
+// wave walks the 32-column chunks of the workgroup's vocabulary slice with the table rows as the A operand (LDS, see the kernel).  MFMA row i of
+// tile f is vocabulary column v0 + 8 (i / 4) + 4 f + i % 4, so a lane's eight accumulators are eight CONSECUTIVE columns of one batch
+// row: the tile of C is read into the accumulators and written back as whole 128-byte lines per four lanes.
+// =============================================================================================
+struct DxeArgs {
+    const float* g; long ldg; float* gx; long ldgx; const bf16_t* E; long lde; float* C; long ldc;
+    int M, V, cps, rb, ns; CstDrop drop;
+};
+
+// 64 batch rows per workgroup: wave w owns rows 16w .. 16w + 15 and all four waves walk the SAME 32-column chunks of the workgroup's
+// vocabulary slice.  The slice's table rows (cps x 32 rows x 256 B) are requested whole by LDS-DMA at the start (two K-tile images,
+// the swizzle of dk_off) next to the first two C tiles, and the dropout masks are computed while they travel.
+__global__ __launch_bounds__(256) void dec_dxe_kernel(DxeArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char dk_smem[];
+    const int lane = threadIdx.x & 63, lr = lane & 15, lq = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    // workgroup id -> (row block, vocabulary slice), XCD-aware: consecutive ids go round-robin over the 8 XCDs, so XCD x takes the x-th
+    // eighth of the slice-major order and its L2 fetches one eighth of the table instead of all of it
+    const int per = (a.rb * a.ns + 7) >> 3;
+    const int logical = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
+    if (logical >= a.rb * a.ns) return;
+    const int slice = logical / a.rb, rblk = logical - slice * a.rb;
+    const int b0 = rblk * 64 + 16 * wave;
+    const bool row_ok = b0 + lr < a.M;
+    const long brow = min(b0 + lr, a.M - 1);
+    const int nchunks = (a.V + 31) >> 5;
+    const int c_lo = slice * a.cps, c_hi = min(c_lo + a.cps, nchunks);
+    const int rows = (c_hi - c_lo) * 32, v_lo = c_lo * 32;
+    {   // table rows -> LDS: one wave instruction = 8 rows x 128 B of one K-tile
+        const int lrow = lane >> 3, lps = lane & 7;
+        const int npieces = 2 * (rows >> 3);
+        for (int pc = wave; pc < npieces; pc += 4) {
+            const int kt = pc & 1, rc = pc >> 1;
+            const int r = rc * 8 + lrow;
+            const bf16_t* src = a.E + (long)min(v_lo + r, a.V - 1) * a.lde + kt * 64 + ((lps ^ (r & 7)) << 3);
+            __builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)(dk_smem + kt * rows * 128 + rc * 1024), 16, 0, 0);
+        }
+    }
+    float* crow = a.C + brow * a.ldc;
+    f32x4_t acc[2][2];                                     // [chunk parity][f]
+    auto load_c = [&](int c, f32x4_t (&dst)[2]) {
+#pragma unroll
+        for (int f = 0; f < 2; ++f) {
+            const int v = c * 32 + 8 * lq + 4 * f;
+            dst[f] = (row_ok && v < a.V) ? *reinterpret_cast<const f32x4_t*>(crow + v) : (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    load_c(c_lo, acc[0]);
+    if (c_lo + 1 < c_hi) load_c(c_lo + 1, acc[1]);
+    const uint32_t dseed = a.drop.p > 0.f ? cst_drop_seed(a.drop) : 0u;
+    const bool write_gx = a.gx && slice == 0 && row_ok;
+    bf16x8_t gb[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+        const int k0 = 32 * kk + 8 * lq;
+        const float4* src = reinterpret_cast<const float4*>(a.g + brow * a.ldg + k0);
+        float4 x = src[0], y = src[1];
+        if (a.drop.p > 0.f) {
+            const uint32_t i0 = (uint32_t)(brow * 128 + k0);
+            x.x *= cst_drop_mask(a.drop, dseed, i0); x.y *= cst_drop_mask(a.drop, dseed, i0 + 1);
+            x.z *= cst_drop_mask(a.drop, dseed, i0 + 2); x.w *= cst_drop_mask(a.drop, dseed, i0 + 3);
+            y.x *= cst_drop_mask(a.drop, dseed, i0 + 4); y.y *= cst_drop_mask(a.drop, dseed, i0 + 5);
+            y.z *= cst_drop_mask(a.drop, dseed, i0 + 6); y.w *= cst_drop_mask(a.drop, dseed, i0 + 7);
+        }
+        if (write_gx) {
+            float4* o = reinterpret_cast<float4*>(a.gx + brow * a.ldgx + k0);
+            o[0] = x; o[1] = y;
+        }
+        u32x4_t pk;
+        pk.x = dk_pack2(x.x, x.y); pk.y = dk_pack2(x.z, x.w); pk.z = dk_pack2(y.x, y.y); pk.w = dk_pack2(y.z, y.w);
+        gb[kk] = __builtin_bit_cast(bf16x8_t, pk);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the table rows (and the first C tiles) have landed
+    __syncthreads();
+    auto do_chunk = [&](int c, f32x4_t (&cur)[2]) {
+        f32x4_t t[2] = {cur[0], cur[1]};
+        if (c + 2 < c_hi) load_c(c + 2, cur);              // two C tiles ahead: the wait for it leaves this chunk's and the next one's stores in flight
+#pragma unroll
+        for (int f = 0; f < 2; ++f) {
+            const int r = (c - c_lo) * 32 + 8 * (lr >> 2) + 4 * f + (lr & 3);    // MFMA row lr of tile f
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                const u32x4_t e = *reinterpret_cast<const u32x4_t*>(dk_smem + (kk >> 1) * rows * 128 + dk_off(r, (kk & 1) * 4 + lq));
+                t[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, e), gb[kk], t[f], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int f = 0; f < 2; ++f) {
+            const int v = c * 32 + 8 * lq + 4 * f;
+            if (row_ok && v < a.V) *reinterpret_cast<f32x4_t*>(crow + v) = t[f];
+        }
+    };
+    for (int c = c_lo; c < c_hi; c += 2) {
+        do_chunk(c, acc[0]);
+        if (c + 1 < c_hi) do_chunk(c + 1, acc[1]);
+    }
+}
+
+// g [M, 128] fp32 (row stride ldg); gx_out (optional) receives dropout(g); E_bf16 [V, lde >= 128]; C [M, V] (row stride ldc) accumulated into.
+// Dropout over the (M, 128) index space, as cst_dropout on the same matrix.  V and ldc multiples of 4.
+extern "C" int cst_dec_dxe(const float* g, long ldg, float* gx_out, long ldgx, const void* E_bf16, long lde, float* C, long ldc,
+                           int M, int V, int K, float drop_p, uint32_t drop_seed, uint32_t drop_stream, const void* drop_seed_dev, void* stream) {
+    CST_REQUIRE(g && E_bf16 && C && M > 0 && V > 0, "cst_dec_dxe: null pointer");
+    CST_REQUIRE(K == 128 && V % 4 == 0 && ldc % 4 == 0 && ldc >= V && ldg % 4 == 0 && ldg >= K && lde % 8 == 0 && lde >= K && (!gx_out || (ldgx % 4 == 0 && ldgx >= K)),
+                "cst_dec_dxe: needs K == 128, V and the leading dimensions multiples of 4 (K=%d, V=%d)", K, V);
+    CST_REQUIRE(((((uintptr_t)g) | ((uintptr_t)gx_out) | ((uintptr_t)E_bf16) | ((uintptr_t)C)) & 15) == 0, "cst_dec_dxe: operands must be 16-byte aligned");
+    DxeArgs a;
+    a.g = g; a.ldg = ldg; a.gx = gx_out; a.ldgx = ldgx; a.E = (const bf16_t*)E_bf16; a.lde = lde; a.C = C; a.ldc = ldc; a.M = M; a.V = V;
+    a.drop = cst_make_drop(drop_p, drop_seed, drop_stream, drop_seed_dev, (long)M * K);
+    const int rb = (M + 63) / 64, nchunks = (V + 31) / 32;
+    // ~one workgroup per CU: the per-workgroup prologue (g rows, masks) is a third of the launch (8.7 us at 256 / 512 workgroups, 9.8 at 768)
+    int ns = (256 + rb - 1) / rb;
+    if (ns > (nchunks + 1) / 2) ns = (nchunks + 1) / 2;     // two chunks per workgroup or more
+    ns = ns < 1 ? 1 : ns;
+    a.cps = (nchunks + ns - 1) / ns;
+    if (a.cps > 16) a.cps = 16;                             // 16 chunks = 128 KB of table rows in LDS
+    ns = (nchunks + a.cps - 1) / a.cps;
+    a.rb = rb; a.ns = ns;
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void*)dec_dxe_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(dec_dxe_kernel, dim3((rb * ns + 7) / 8 * 8), dim3(256), (size_t)a.cps * 32 * 256, (hipStream_t)stream, a);
+    CST_LAUNCH_CHECK("cst_dec_dxe");
+    return CST_OK;
+}

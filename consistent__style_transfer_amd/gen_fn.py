@@ -380,6 +380,7 @@ class GeneratorFn(torch.autograd.Function):
                 dgrad(dout.view(B * T, V), P["fn_2.weight"], out=dpre1.view(B * T, Hd), aux=r1.view(B * T, Hd), act=4)
                 dgrad(dpre1.view(B * T, Hd), P["fn_1.weight"], out=diffn_all.view(B * T, W_))
         dXH_all = _new(dev, T, B, E + Hd)              # step s writes [d x_s | d h_{s-1}] into slice s
+        etok_b = weight_bf16(E_tok)[0] if (soft and use_b) else None
         dxe_all = _new(dev, max(T - 1, 1), B, E) if (soft and drop.p > 0) else None
         dc = _new(dev, B, Hd)
         # Teacher-forced / free-running decodes on the bf16 path: every step's FFN gradient is already in
@@ -409,12 +410,17 @@ class GeneratorFn(torch.autograd.Function):
                 # gradient of the embedding that fed step s+1 (dropout STREAM_G_XT+s was applied to it);
                 # straight-through: d p_s += dx @ E^T (rnn.py:84-85).  The scatter into dE waits for the end of the loop.
                 xd = drop.at(STREAM_G_XT + s)
-                if xd.p > 0:
-                    g_x = dxe_all[s]
-                    dropout2d(dXH[:, :E], xd, out=g_x)
+                if use_b and E == 128 and V % 4 == 0:
+                    # dropout on the operand load, bf16 product, accumulate: one launch (the dropped rows go to dxe_all for the scatter)
+                    g_x = dxe_all[s] if xd.p > 0 else None
+                    call("cst_dec_dxe", dXH, E + Hd, g_x, E, etok_b, etok_b.stride(0), dl, T * V, B, V, E, *xd.args())
                 else:
-                    g_x = dXH[:, :E]
-                gemm(g_x, True, E_tok, True, dl, B, V, E, accumulate=True)
+                    if xd.p > 0:
+                        g_x = dxe_all[s]
+                        dropout2d(dXH[:, :E], xd, out=g_x)
+                    else:
+                        g_x = dXH[:, :E]
+                    gemm(g_x, True, E_tok, True, dl, B, V, E, accumulate=True)
             if soft:
                 dlb = dlb_all[:, s * Vp:(s + 1) * Vp] if use_b else None
                 softmax_tau_bwd(out2[:, s * V:(s + 1) * V], dl, inv_tau, dl, dx_b=dlb)

@@ -293,6 +293,10 @@ int cst_dec_attn_cell_bwd(const float* g, long ldg, const float* mem, const floa
                           const float* gates, long ldgt, const float* c_prev, long ldcp, const float* c_new, long ldcn,
                           const float* dh2, long lddh2, const float* dc, long lddc,
                           float* dgates, long lddg, float* dc_prev, long lddcp, void* dgates_bf16, long lddgb, void* stream);
+/* Straight-through gradient of the soft decode (rnn.py:84-85), one step: C[M, V] += dropout(g)[M, 128] . E_bf16[V, 128]^T; gx_out (optional)
+ * receives dropout(g) in fp32 (the embedding scatter's operand).  Dropout over the (M, 128) index space, as cst_dropout.  K == 128. */
+int cst_dec_dxe(const float* g, long ldg, float* gx_out, long ldgx, const void* E_bf16, long lde, float* C, long ldc,
+                int M, int V, int K, float drop_p, uint32_t drop_seed, uint32_t drop_stream, const void* drop_seed_dev, void* stream);
 /* dmem[b, j, :] += sum_s p[s, b, j] ga[b, s] + ds[s, b, j] h[b, s]: the d memory of all T steps after the loop (p, ds: [T][B][L]). */
 int cst_dec_attn_dmem(const float* ga, long ldga, long ga_step, const float* h, long ldh, long h_step,
                       const float* p, const float* ds, float* dmem, int B, int T, int L, int D, void* stream);

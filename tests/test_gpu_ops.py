@@ -1260,3 +1260,24 @@ def test_dec_attn_cell_bwd(ops, B, L, T):
     assert torch.equal(dgb.view(torch.bfloat16).float().cpu(), _bf(dgd.cpu()))
     close(dcd, dc, 2e-4, 2e-5, "dc")
     close(dmem, dmem_ref, 2e-4, 2e-5, "dmem")
+
+
+@pytest.mark.parametrize("M,V,p", [(256, 10000, 0.1), (16, 208, 0.1), (37, 1000, 0.0), (5, 36, 0.25)])
+def test_dec_dxe(ops, M, V, p):
+    """cst_dec_dxe: C += dropout(g) E^T on bf16-rounded operands (rnn.py:84-85's straight-through gradient), the dropped rows written once,
+    nothing written outside the (M, V) block of a wider buffer."""
+    from consistent__style_transfer_amd._lib import call
+    K, ldg, ldc = 128, 640, 3 * V
+    g, E, C0 = rnd(M, ldg, seed=1), rnd(V, K, seed=2), rnd(M, ldc, seed=3)
+    Eb, _ = ops.cast_bf16(dev(E), want_t=False)
+    gd, C = dev(g), dev(C0)
+    gx = torch.full((M, K), float("nan"), device="cuda")
+    d = ops.Drop(p, 5, 321) if p > 0 else ops.NO_DROP
+    call("cst_dec_dxe", gd, ldg, gx if p > 0 else None, K, Eb, Eb.stride(0), C[:, V:], ldc, M, V, K, *d.args())
+    mask = torch.from_numpy(orng.dropout_mask(5, 321, (M, K), p)) if p > 0 else torch.ones(M, K)
+    want_gx = g[:, :K] * mask
+    if p > 0:
+        assert torch.equal(gx.cpu(), want_gx)
+    ref = C0[:, V:2 * V] + _bf(want_gx) @ _bf(E).t()
+    close(C[:, V:2 * V], ref, 2e-3, 2e-3 * math.sqrt(K), f"{M}x{V}")
+    assert torch.equal(C[:, :V].cpu(), C0[:, :V]) and torch.equal(C[:, 2 * V:].cpu(), C0[:, 2 * V:])
