@@ -29,6 +29,7 @@ def _stale(target, deps):
 
 
 HOST_LIB = os.path.join(CSRC, "libcst_host.so")
+BENCH_SOURCES = ["gemm_rs.hip"]          # only with CST_BENCH_VARIANTS=1: measured experiments that the step never dispatches (tools/gemm_rs_bench.py)
 HOST_SOURCES = ["host_wmd.cpp"]
 
 
@@ -50,13 +51,14 @@ def build_lib(force=False, verbose=True):
     hipcc = _hipcc()
     hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
     objs = []
-    for s in SOURCES:
+    bench = os.environ.get("CST_BENCH_VARIANTS") == "1"
+    for s in SOURCES + (BENCH_SOURCES if bench else []):
         src = os.path.join(CSRC, s)
         obj = os.path.join(CSRC, s.replace(".hip", ".o"))
         objs.append(obj)
         if force or _stale(obj, [src] + hdrs):
             cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-fPIC", "-std=c++17", "-c", src, "-o", obj]
-            if os.environ.get("CST_BENCH_VARIANTS") == "1":          # bench-only GEMM variants + timing ablations (gemm_bf16.hip)
+            if bench:                                                # bench-only GEMM variants + timing ablations (gemm_bf16.hip)
                 cmd.insert(-4, "-DCST_BENCH_VARIANTS")
             if verbose:
                 print(" ".join(cmd), flush=True)
