@@ -36,9 +36,10 @@ class Fork:
     either way, 40.6 ms with forked streams in eager mode) -- so the step stays serial unless
     CST_FORK=1."""
 
-    def __init__(self, n):
+    def __init__(self, n, stage=""):
         import os
-        self.enabled = torch.cuda.is_available() and os.environ.get("CST_FORK", "0") == "1"
+        want = os.environ.get("CST_FORK", "0")                 # "1": every stage, or a stage name ("pretrain" / "optimize")
+        self.enabled = torch.cuda.is_available() and (want == "1" or (stage and want == stage))
         self.streams = [torch.cuda.Stream() for _ in range(n - 1)] if self.enabled else []
 
     def run(self, fns):
@@ -159,7 +160,7 @@ class PretrainStage(nn.Module):
             return ops.token_ce(self.classifier(x, seed=seed), label) if self.flags["cls"] else None
 
         if not hasattr(self, "_fork"):
-            self._fork = Fork(3)
+            self._fork = Fork(3, "pretrain")
         dn, c, s = self._fork.run([f_dn, f_mat, f_cls])          # three independent critics, three streams
         return s, c, dn
 
@@ -317,7 +318,7 @@ class OptimizeStage(nn.Module):
             return ops.bce_logits_loss(self.disc(sample_p), 1.0)
 
         if not hasattr(self, "_fork"):
-            self._fork = Fork(4)
+            self._fork = Fork(4, "optimize")
         # the three critics embed the same sample_p: one shared product (and one shared d sample_p) instead of three
         with ops.shared_soft_embed(sample_p, [(self.matcher.token_embedding.weight, False), (self.classifier.embedding.weight, False),
                                               (self.disc.embeddings.weight, True)]):
