@@ -664,7 +664,18 @@ extern "C" int cst_mha_bwd(const float* qkv, const float* dout, const float* lse
 // ---------------------------------------------------------------------------------------------
 __host__ __device__ inline size_t mha_bwd_hb_lds_bytes(int S, int hd) {
     const size_t SP = (size_t)((S + 15) / 16) * 16;
-    return 4 * SP * (hd + 8) * 2 + 64 + sizeof(float) * (2 * SP * (SP + 4) + SP * 4 + SP);
+    return 4 * SP * (hd + 8) * 2 + 64 + 2 * SP * (SP + 4) * 2 + sizeof(float) * (SP * 4 + SP);
+}
+
+typedef __attribute__((ext_vector_type(4))) short mha_s16x4_t;
+// ds_read_b64_tr_b16: the 16 lanes of a group read a 4-row x 16-column block of bf16 (lane 4q + p supplies the address of row q, columns
+// 4p .. 4p + 3) and each lane receives COLUMN (lane % 16) of it, rows 0 .. 3 -- the MFMA operand of a product whose contraction index
+// is the image's row index, without a transposed copy.  EXEC must be all ones (cdna_hip_programming.md T10).
+__device__ __forceinline__ mha_s16x4_t mha_tr_read(const unsigned short* p) {
+    mha_s16x4_t v;
+    const unsigned addr = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const unsigned short*)p;
+    asm volatile("ds_read_b64_tr_b16 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(addr) : "memory");
+    return v;
 }
 
 template <int HD, int ST>
@@ -675,14 +686,14 @@ __global__ __launch_bounds__(MHA_NW * 64) void mha_bwd_hb_kernel(const unsigned 
     static_assert(HD % 32 == 0, "bf16 MFMA k-steps of 32");
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     constexpr int HD4 = HD / 4, HDB = HD + 8, NT = HD / 16;
-    constexpr int SP = ST * 16, SS = SP + 4, KSEG = SP / 4;
+    constexpr int SP = ST * 16, SS = SP + 4;
     unsigned short* Qs = reinterpret_cast<unsigned short*>(smem_raw);      // [SP][HDB]
     unsigned short* Ks = Qs + SP * HDB;
     unsigned short* Vs = Ks + SP * HDB;
     unsigned short* Os = Vs + SP * HDB;                                     // dO
-    float* Pm = reinterpret_cast<float*>(Os + SP * HDB + 32);               // [SP][SS]  Pd[i][j]
-    float* Dm = Pm + SP * SS;                                               // [SP][SS]  dS[i][j]
-    float* part = Dm + SP * SS;                                             // [SP][4]
+    unsigned short* Pm = Os + SP * HDB + 32;                                // [SP][SS]  bf16 Pd[i][j]
+    unsigned short* Dm = Pm + SP * SS;                                      // [SP][SS]  bf16 dS[i][j]
+    float* part = reinterpret_cast<float*>(Dm + SP * SS);                   // [SP][4]
     float* lse_s = part + SP * 4;                                           // [SP]
     const int b = blockIdx.x / H, h = blockIdx.x % H;
     const int d = H * HD;
@@ -757,7 +768,7 @@ __global__ __launch_bounds__(MHA_NW * 64) void mha_bwd_hb_kernel(const unsigned 
                 if (drop.p > 0.f && valid)
                     mask = cst_drop_mask(drop, dseed, (uint32_t)((((long)b * H + h) * S + i) * S + j));
                 const float dp = valid ? accD[r] * mask : 0.f;
-                Pm[i * SS + j] = pv * mask;
+                { __bf16 hb = (__bf16)(pv * mask); Pm[i * SS + j] = __builtin_bit_cast(unsigned short, hb); }
                 float rs = dp * pv;
                 rs = row16_sum(rs);
                 if (lr == 0) part[i * 4 + nt] = rs;
@@ -780,31 +791,39 @@ __global__ __launch_bounds__(MHA_NW * 64) void mha_bwd_hb_kernel(const unsigned 
                 float delta = 0.f;
 #pragma unroll
                 for (int n = 0; n < ST; ++n) delta += part[i * 4 + n];
-                Dm[i * SS + j] = Pf[tt][r] * (Df[tt][r] - delta) * scale;
+                __bf16 hb = (__bf16)(Pf[tt][r] * (Df[tt][r] - delta) * scale);
+                Dm[i * SS + j] = __builtin_bit_cast(unsigned short, hb);
             }
         }
     }
     __syncthreads();
-    // ---- phase C: dQ = dS K, dK = dS^T Q, dV = Pd^T dO on the fp32 matrix pipe, B operand widened from the bf16 image ----
+    // ---- phase C: dQ = dS K, dK = dS^T Q, dV = Pd^T dO on the bf16 matrix pipe (v_mfma_f32_16x16x16_bf16, contraction over the sequence
+    // in steps of 16).  dS and Pd are rounded to bf16 once (phase A / B wrote them that way); every operand whose contraction index is its
+    // image's ROW index -- K, Q, dO always, dS and Pd for the two transposed products -- comes from the hardware transposed read, so no
+    // transposed image exists.  (Round 2 ran these on the fp32 pipe from scalar LDS reads: 12 MFMAs and 24 reads per tile where this is 3 and 6.)
     float* dq = dqkv ? dqkv + (long)b * S * 3 * d + h * HD : nullptr;
     constexpr int PAIR = (NT % 2 == 0) ? 2 : 1, NP = NT / PAIR;
     constexpr int per = ST * NP, nout = 3 * per;
+    const int tq = lr >> 2, tp = lr & 3;                  // this lane's (row, column group) inside a transposed-read block
     for (int u = w; u < nout; u += MHA_NW) {
         const int which = u / per, rem = u - which * per;
         const int mt = rem / NP, n0 = (rem - mt * NP) * PAIR * 16;
-        const float* a = which == 0 ? Dm + (mt * 16 + lr) * SS + lq * KSEG
-                                    : (which == 1 ? Dm : Pm) + (lq * KSEG) * SS + mt * 16 + lr;
-        const int as = which == 0 ? 1 : SS;
-        const unsigned short* bp = (which == 0 ? Ks : (which == 1 ? Qs : Os)) + (lq * KSEG) * HDB + n0 + lr;
+        const unsigned short* aimg = which == 2 ? Pm : Dm;
+        const unsigned short* bimg = which == 0 ? Ks : (which == 1 ? Qs : Os);
         f32x4_t acc[PAIR];
 #pragma unroll
         for (int q = 0; q < PAIR; ++q) acc[q] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int k = 0; k < KSEG; ++k) {
-            const float av = a[k * as];
+        for (int ks = 0; ks < ST; ++ks) {
+            const int k0 = ks * 16 + 4 * lq;              // this 16-lane group's four contraction indices
+            mha_s16x4_t af;
+            if (which == 0) af = *reinterpret_cast<const mha_s16x4_t*>(aimg + (mt * 16 + lr) * SS + k0);      // dS[i][j .. j + 3]: a row read
+            else af = mha_tr_read(aimg + (k0 + tq) * SS + mt * 16 + 4 * tp);                                    // dS^T / Pd^T
 #pragma unroll
-            for (int q = 0; q < PAIR; ++q)
-                acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, __uint_as_float((uint32_t)bp[k * HDB + q * 16] << 16), acc[q], 0, 0, 0);
+            for (int q = 0; q < PAIR; ++q) {
+                const mha_s16x4_t bf = mha_tr_read(bimg + (k0 + tq) * HDB + n0 + q * 16 + 4 * tp);
+                acc[q] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(af, bf, acc[q], 0, 0, 0);
+            }
         }
 #pragma unroll
         for (int q = 0; q < PAIR; ++q) {

@@ -461,10 +461,14 @@ def test_mha_bf16_io_equals_fp32_io_on_rounded_inputs(ops, B, S, H, hd, p):
     dq2, dqb2, dqb3 = torch.empty_like(dq), torch.zeros_like(dqb), torch.zeros_like(dqb)
     call("cst_mha_bwd_h", qb, wb, lse, dq2, B, S, H, hd, *drop.args(), dqb2, 3 * d)
     call("cst_mha_bwd_h", qb, wb, lse, None, B, S, H, hd, *drop.args(), dqb3, 3 * d)
-    # backward: bf16 LDS images, Q K^T and dO V^T on the bf16 matrix pipe -- exact products, another summation order (a few ulps)
-    close(dq2, dq, 2e-5, 2e-6)
+    # backward: bf16 LDS images, Q K^T and dO V^T on the bf16 matrix pipe (exact products, another summation order); round 3: dS and Pd are
+    # rounded to bf16 for the three output products (dS K, dS^T Q, Pd^T dO on the bf16 pipe), so the gradients carry one bf16 rounding of a
+    # factor: relative L2 error <= 3e-3 per tensor, element-wise within 2^-7 of the row scale (measured 1.6e-3 / well inside)
+    rel = ((dq2 - dq).norm() / dq.norm()).item()
+    assert rel < 3e-3, rel
+    close(dq2, dq, 2.0 ** -6, 2.0 ** -7 * dq.abs().max().item())
     assert torch.equal(dqb3, dqb2)
-    ulp_close(dqb2, dqb)
+    assert torch.equal(dqb2.view(torch.bfloat16).float().cpu(), _bf(dq2.cpu()))         # the bf16 twin is the rounding of the fp32 result
     with pytest.raises(RuntimeError, match="head dims 64 / 96"):
         call("cst_mha_fwd_h", qb, None, lse2, B, S, H * hd // 32, 32, *drop.args(), outb3, d)
 
