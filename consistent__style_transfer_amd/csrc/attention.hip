@@ -671,6 +671,21 @@ typedef __attribute__((ext_vector_type(4))) short mha_s16x4_t;
 // ds_read_b64_tr_b16: the 16 lanes of a group read a 4-row x 16-column block of bf16 (lane 4q + p supplies the address of row q, columns
 // 4p .. 4p + 3) and each lane receives COLUMN (lane % 16) of it, rows 0 .. 3 -- the MFMA operand of a product whose contraction index
 // is the image's row index, without a transposed copy.  EXEC must be all ones (cdna_hip_programming.md T10).
+// two / three transposed reads and ONE wait in one statement (the compiler believes an asm's outputs are valid when the statement ends)
+__device__ __forceinline__ void mha_tr_read3(const unsigned short* p0, const unsigned short* p1, const unsigned short* p2,
+                                             mha_s16x4_t& v0, mha_s16x4_t& v1, mha_s16x4_t& v2) {
+    const unsigned a0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const unsigned short*)p0;
+    const unsigned a1 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const unsigned short*)p1;
+    const unsigned a2 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const unsigned short*)p2;
+    asm volatile("ds_read_b64_tr_b16 %0, %3\n\tds_read_b64_tr_b16 %1, %4\n\tds_read_b64_tr_b16 %2, %5\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(v0), "=&v"(v1), "=&v"(v2) : "v"(a0), "v"(a1), "v"(a2) : "memory");
+}
+__device__ __forceinline__ void mha_tr_read2(const unsigned short* p0, const unsigned short* p1, mha_s16x4_t& v0, mha_s16x4_t& v1) {
+    const unsigned a0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const unsigned short*)p0;
+    const unsigned a1 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const unsigned short*)p1;
+    asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %3\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(v0), "=&v"(v1) : "v"(a0), "v"(a1) : "memory");
+}
 __device__ __forceinline__ mha_s16x4_t mha_tr_read(const unsigned short* p) {
     mha_s16x4_t v;
     const unsigned addr = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const unsigned short*)p;
@@ -816,27 +831,33 @@ __global__ __launch_bounds__(MHA_NW * 64) void mha_bwd_hb_kernel(const unsigned 
 #pragma unroll
         for (int ks = 0; ks < ST; ++ks) {
             const int k0 = ks * 16 + 4 * lq;              // this 16-lane group's four contraction indices
-            mha_s16x4_t af;
-            if (which == 0) af = *reinterpret_cast<const mha_s16x4_t*>(aimg + (mt * 16 + lr) * SS + k0);      // dS[i][j .. j + 3]: a row read
-            else af = mha_tr_read(aimg + (k0 + tq) * SS + mt * 16 + 4 * tp);                                    // dS^T / Pd^T
+            mha_s16x4_t af, bf[PAIR];
+            const unsigned short* bp = bimg + (k0 + tq) * HDB + n0 + 4 * tp;
+            const unsigned short* ap = aimg + (k0 + tq) * SS + mt * 16 + 4 * tp;                               // dS^T / Pd^T
+            if (which == 0) {
+                af = *reinterpret_cast<const mha_s16x4_t*>(aimg + (mt * 16 + lr) * SS + k0);                    // dS[i][j .. j + 3]: a row read
+                if constexpr (PAIR == 2) mha_tr_read2(bp, bp + 16, bf[0], bf[PAIR - 1]);
+                else bf[0] = mha_tr_read(bp);
+            } else {
+                if constexpr (PAIR == 2) mha_tr_read3(ap, bp, bp + 16, af, bf[0], bf[PAIR - 1]);
+                else mha_tr_read2(ap, bp, af, bf[0]);
+            }
+#pragma unroll
+            for (int q = 0; q < PAIR; ++q) acc[q] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(bf[q], af, acc[q], 0, 0, 0);   // operands swapped: the tile comes out transposed
+        }
+        // transposed tile: this lane holds columns n .. n + 3 of output row m -- one 16-byte (fp32) / 8-byte (bf16) store each
+        const int m = mt * 16 + lr;
+        if (m < S) {
 #pragma unroll
             for (int q = 0; q < PAIR; ++q) {
-                const mha_s16x4_t bf = mha_tr_read(bimg + (k0 + tq) * HDB + n0 + q * 16 + 4 * tp);
-                acc[q] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(af, bf, acc[q], 0, 0, 0);
-            }
-        }
-#pragma unroll
-        for (int q = 0; q < PAIR; ++q) {
-            const int n = n0 + q * 16 + lr;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int m = mt * 16 + lq * 4 + r;
-                if (m < S) {
-                    if (dq) dq[(long)m * 3 * d + which * d + n] = acc[q][r];
-                    if (dqkvb) {
-                        __bf16 hh = (__bf16)acc[q][r];
-                        dqkvb[((long)b * S + m) * lddb + which * d + h * HD + n] = __builtin_bit_cast(unsigned short, hh);
-                    }
+                const int n = n0 + q * 16 + 4 * lq;
+                if (dq) *reinterpret_cast<f32x4_t*>(dq + (long)m * 3 * d + which * d + n) = acc[q];
+                if (dqkvb) {
+                    uint2 pk;
+                    { __bf16 h0 = (__bf16)acc[q][0], h1 = (__bf16)acc[q][1], h2 = (__bf16)acc[q][2], h3 = (__bf16)acc[q][3];
+                      pk.x = (uint32_t)__builtin_bit_cast(unsigned short, h0) | ((uint32_t)__builtin_bit_cast(unsigned short, h1) << 16);
+                      pk.y = (uint32_t)__builtin_bit_cast(unsigned short, h2) | ((uint32_t)__builtin_bit_cast(unsigned short, h3) << 16); }
+                    *reinterpret_cast<uint2*>(dqkvb + ((long)b * S + m) * lddb + which * d + h * HD + n) = pk;
                 }
             }
         }
@@ -885,6 +906,8 @@ static int mha_bwd_any(const void* qkv, const void* dout, int io_bf16, const flo
     static const bool hb_off = getenv("CST_MHA_HB_OFF") != nullptr;          // A/B switch: fp32 LDS images for the bf16-I/O backward
     if (io_bf16 && (hd == 64 || hd == 96) && !hb_off) {
         // bf16 LDS images: two workgroups per CU (see mha_bwd_hb_kernel)
+        CST_REQUIRE((((uintptr_t)dqkv) & 15) == 0 && (((uintptr_t)dqkv_bf16) & 7) == 0 && (!dqkv_bf16 || lddb % 4 == 0),
+                    "cst_mha_bwd_h: dqkv must be 16-byte aligned, its bf16 twin 8-byte aligned with a leading dimension that is a multiple of 4");
         const size_t ldsb = mha_bwd_hb_lds_bytes(S, hd);
 #define MHA_HB_LAUNCH(HDV, STV)                                                                                    \
         {                                                                                                          \
