@@ -216,7 +216,33 @@ typedef __attribute__((ext_vector_type(8))) __bf16 mha_bf16x8_t;
 
 __host__ __device__ inline size_t mha_fwd_hb_lds_bytes(int S, int hd) {
     const size_t SP = (size_t)((S + 15) / 16) * 16;
-    return 3 * SP * (hd + 8) * 2 + 64 + sizeof(float) * SP * (SP + 4);
+    return 3 * SP * (hd + 8) * 2 + 64 + (sizeof(float) + 2) * SP * (SP + 4);
+}
+
+typedef __attribute__((ext_vector_type(4))) short mha_s16x4_t;
+// ds_read_b64_tr_b16: the 16 lanes of a group read a 4-row x 16-column block of bf16 (lane 4q + p supplies the address of row q, columns
+// 4p .. 4p + 3) and each lane receives COLUMN (lane % 16) of it, rows 0 .. 3 -- the MFMA operand of a product whose contraction index
+// is the image's row index, without a transposed copy.  EXEC must be all ones (cdna_hip_programming.md T10).
+// two / three transposed reads and ONE wait in one statement (the compiler believes an asm's outputs are valid when the statement ends)
+__device__ __forceinline__ void mha_tr_read3(const unsigned short* p0, const unsigned short* p1, const unsigned short* p2,
+                                             mha_s16x4_t& v0, mha_s16x4_t& v1, mha_s16x4_t& v2) {
+    const unsigned a0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const unsigned short*)p0;
+    const unsigned a1 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const unsigned short*)p1;
+    const unsigned a2 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const unsigned short*)p2;
+    asm volatile("ds_read_b64_tr_b16 %0, %3\n\tds_read_b64_tr_b16 %1, %4\n\tds_read_b64_tr_b16 %2, %5\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(v0), "=&v"(v1), "=&v"(v2) : "v"(a0), "v"(a1), "v"(a2) : "memory");
+}
+__device__ __forceinline__ void mha_tr_read2(const unsigned short* p0, const unsigned short* p1, mha_s16x4_t& v0, mha_s16x4_t& v1) {
+    const unsigned a0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const unsigned short*)p0;
+    const unsigned a1 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const unsigned short*)p1;
+    asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %3\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(v0), "=&v"(v1) : "v"(a0), "v"(a1) : "memory");
+}
+__device__ __forceinline__ mha_s16x4_t mha_tr_read(const unsigned short* p) {
+    mha_s16x4_t v;
+    const unsigned addr = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const unsigned short*)p;
+    asm volatile("ds_read_b64_tr_b16 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(addr) : "memory");
+    return v;
 }
 
 template <int HD, int ST>
@@ -230,7 +256,8 @@ __global__ __launch_bounds__(MHA_NW * 64) void mha_fwd_hb_kernel(const unsigned 
     unsigned short* Qs = reinterpret_cast<unsigned short*>(smem_raw);      // [SP][HDB]
     unsigned short* Ks = Qs + SP * HDB;
     unsigned short* Vs = Ks + SP * HDB;
-    float* Pm = reinterpret_cast<float*>(Vs + SP * HDB + 32);               // [SP][SS]
+    float* Pm = reinterpret_cast<float*>(Vs + SP * HDB + 32);               // [SP][SS]  scores, then Pd
+    unsigned short* Pb = reinterpret_cast<unsigned short*>(Pm + SP * SS);   // [SP][SS]  bf16 Pd: the A operand of Pd V
     const int b = blockIdx.x / H, h = blockIdx.x % H;
     const int d = H * HD;
     const int lane = threadIdx.x & 63;
@@ -309,41 +336,49 @@ __global__ __launch_bounds__(MHA_NW * 64) void mha_fwd_hb_kernel(const unsigned 
                 float pv = sv[n] * inv;
                 if (drop.p > 0.f && j < S)
                     pv *= cst_drop_mask(drop, dseed, (uint32_t)((((long)b * H + h) * S + i) * S + j));
-                Pm[i * SS + j] = pv;
+                __bf16 hb = (__bf16)pv;
+                Pb[i * SS + j] = __builtin_bit_cast(unsigned short, hb);
             }
+        } else {
+#pragma unroll
+            for (int n = 0; n < ST; ++n) Pb[i * SS + lr + 16 * n] = 0;     // rows S .. SP - 1 (i < SP always: 4 rows per wave pass, SP a multiple of 16)
         }
     }
     __syncthreads();
-    // ---- phase C: O = Pd V on the fp32 matrix pipe, V widened from the bf16 image --------------
+    // ---- phase C: O = Pd V on the bf16 matrix pipe: Pd rounded to bf16 (phase B), V read with ds_read_b64_tr_b16 (its contraction index
+    // is its image's row index), tiles computed transposed so that a lane stores four consecutive columns (as mha_bwd_hb_kernel, round 3)
     float* ob = out ? out + (long)b * S * d + h * HD : nullptr;
     constexpr int PAIR = (NT % 2 == 0) ? 2 : 1, NP = NT / PAIR;
     constexpr int nout = ST * NP;
+    const int tq = lr >> 2, tp = lr & 3;
     for (int u = w; u < nout; u += MHA_NW) {
         const int mt = u / NP, n0 = (u - mt * NP) * PAIR * 16;
-        const float* a = Pm + (mt * 16 + lr) * SS + lq * KSEG;
-        const unsigned short* bp = Vs + (lq * KSEG) * HDB + n0 + lr;
         f32x4_t acc[PAIR];
 #pragma unroll
         for (int q = 0; q < PAIR; ++q) acc[q] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int k = 0; k < KSEG; ++k) {
-            const float av = a[k];
+        for (int ks = 0; ks < ST; ++ks) {
+            const int k0 = ks * 16 + 4 * lq;
+            const mha_s16x4_t af = *reinterpret_cast<const mha_s16x4_t*>(Pb + (mt * 16 + lr) * SS + k0);
+            mha_s16x4_t bf[PAIR];
+            const unsigned short* bp = Vs + (k0 + tq) * HDB + n0 + 4 * tp;
+            if constexpr (PAIR == 2) mha_tr_read2(bp, bp + 16, bf[0], bf[PAIR - 1]);
+            else bf[0] = mha_tr_read(bp);
 #pragma unroll
-            for (int q = 0; q < PAIR; ++q)
-                acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, __uint_as_float((uint32_t)bp[k * HDB + q * 16] << 16), acc[q], 0, 0, 0);
+            for (int q = 0; q < PAIR; ++q) acc[q] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(bf[q], af, acc[q], 0, 0, 0);
         }
+        const int mrow = mt * 16 + lr;
+        if (mrow < S) {
 #pragma unroll
-        for (int q = 0; q < PAIR; ++q) {
-            const int n = n0 + q * 16 + lr;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int mrow = mt * 16 + lq * 4 + r;
-                if (mrow < S) {
-                    if (ob) ob[(long)mrow * d + n] = acc[q][r];
-                    if (outb) {
-                        __bf16 hh = (__bf16)acc[q][r];
-                        outb[((long)b * S + mrow) * ldob + h * HD + n] = __builtin_bit_cast(unsigned short, hh);
-                    }
+            for (int q = 0; q < PAIR; ++q) {
+                const int n = n0 + q * 16 + 4 * lq;
+                if (ob) *reinterpret_cast<f32x4_t*>(ob + (long)mrow * d + n) = acc[q];
+                if (outb) {
+                    uint2 pk;
+                    { __bf16 h0 = (__bf16)acc[q][0], h1 = (__bf16)acc[q][1], h2 = (__bf16)acc[q][2], h3 = (__bf16)acc[q][3];
+                      pk.x = (uint32_t)__builtin_bit_cast(unsigned short, h0) | ((uint32_t)__builtin_bit_cast(unsigned short, h1) << 16);
+                      pk.y = (uint32_t)__builtin_bit_cast(unsigned short, h2) | ((uint32_t)__builtin_bit_cast(unsigned short, h3) << 16); }
+                    *reinterpret_cast<uint2*>(outb + ((long)b * S + mrow) * ldob + h * HD + n) = pk;
                 }
             }
         }
@@ -388,6 +423,8 @@ static int mha_fwd_any(const void* qkv, int qkv_bf16, float* out, float* lse, in
     hipStream_t st = (hipStream_t)stream;
     static const bool hb_off = getenv("CST_MHA_HB_OFF") != nullptr;          // A/B switch: fp32 LDS images for the bf16-input forward
     if (qkv_bf16 && (hd == 64 || hd == 96) && !hb_off) {
+        CST_REQUIRE((((uintptr_t)out) & 15) == 0 && (((uintptr_t)out_bf16) & 7) == 0 && (!out_bf16 || ldob % 4 == 0),
+                    "cst_mha_fwd_h: out must be 16-byte aligned, its bf16 twin 8-byte aligned with a leading dimension that is a multiple of 4");
         const size_t ldsb = mha_fwd_hb_lds_bytes(S, hd);
 #define MHA_HB_LAUNCH(HDV, STV)                                                                                    \
         {                                                                                                          \
@@ -665,32 +702,6 @@ extern "C" int cst_mha_bwd(const float* qkv, const float* dout, const float* lse
 __host__ __device__ inline size_t mha_bwd_hb_lds_bytes(int S, int hd) {
     const size_t SP = (size_t)((S + 15) / 16) * 16;
     return 4 * SP * (hd + 8) * 2 + 64 + 2 * SP * (SP + 4) * 2 + sizeof(float) * (SP * 4 + SP);
-}
-
-typedef __attribute__((ext_vector_type(4))) short mha_s16x4_t;
-// ds_read_b64_tr_b16: the 16 lanes of a group read a 4-row x 16-column block of bf16 (lane 4q + p supplies the address of row q, columns
-// 4p .. 4p + 3) and each lane receives COLUMN (lane % 16) of it, rows 0 .. 3 -- the MFMA operand of a product whose contraction index
-// is the image's row index, without a transposed copy.  EXEC must be all ones (cdna_hip_programming.md T10).
-// two / three transposed reads and ONE wait in one statement (the compiler believes an asm's outputs are valid when the statement ends)
-__device__ __forceinline__ void mha_tr_read3(const unsigned short* p0, const unsigned short* p1, const unsigned short* p2,
-                                             mha_s16x4_t& v0, mha_s16x4_t& v1, mha_s16x4_t& v2) {
-    const unsigned a0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const unsigned short*)p0;
-    const unsigned a1 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const unsigned short*)p1;
-    const unsigned a2 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const unsigned short*)p2;
-    asm volatile("ds_read_b64_tr_b16 %0, %3\n\tds_read_b64_tr_b16 %1, %4\n\tds_read_b64_tr_b16 %2, %5\n\ts_waitcnt lgkmcnt(0)"
-                 : "=&v"(v0), "=&v"(v1), "=&v"(v2) : "v"(a0), "v"(a1), "v"(a2) : "memory");
-}
-__device__ __forceinline__ void mha_tr_read2(const unsigned short* p0, const unsigned short* p1, mha_s16x4_t& v0, mha_s16x4_t& v1) {
-    const unsigned a0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const unsigned short*)p0;
-    const unsigned a1 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const unsigned short*)p1;
-    asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %3\n\ts_waitcnt lgkmcnt(0)"
-                 : "=&v"(v0), "=&v"(v1) : "v"(a0), "v"(a1) : "memory");
-}
-__device__ __forceinline__ mha_s16x4_t mha_tr_read(const unsigned short* p) {
-    mha_s16x4_t v;
-    const unsigned addr = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const unsigned short*)p;
-    asm volatile("ds_read_b64_tr_b16 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(addr) : "memory");
-    return v;
 }
 
 template <int HD, int ST>

@@ -429,9 +429,9 @@ def test_mha(ops, B, S, H, hd, p):
 
 @pytest.mark.parametrize("B,S,H,hd,p", [(2, 36, 8, 64, 0.1), (3, 18, 8, 96, 0.1), (1, 64, 2, 64, 0.0), (2, 36, 8, 96, 0.0), (2, 7, 3, 96, 0.1)])
 def test_mha_bf16_io_equals_fp32_io_on_rounded_inputs(ops, B, S, H, hd, p):
-    """cst_mha_fwd_h / cst_mha_bwd_h: bf16 qkv and d(output) in HBM, bf16 LDS images, Q K^T / dO V^T on the bf16 matrix pipe (exact
-    products of bf16 values), everything else fp32: the fp32-I/O kernels run on the bf16-rounded values give the same results up to
-    summation order, with or without the optional fp32 results."""
+    """cst_mha_fwd_h / cst_mha_bwd_h: bf16 qkv and d(output) in HBM, bf16 LDS images, every product on the bf16 matrix pipe (Q K^T / dO V^T:
+    exact products of bf16 values; Pd V, dS K, dS^T Q, Pd^T dO: Pd / dS rounded to bf16 once): the fp32-I/O kernels run on the bf16-rounded
+    values give the same results up to that one rounding, with or without the optional fp32 results."""
     from consistent__style_transfer_amd._lib import call
     d = H * hd
     qkv = _bf16_round(rnd(B * S, 3 * d, seed=1, scale=0.7))
@@ -446,15 +446,14 @@ def test_mha_bf16_io_equals_fp32_io_on_rounded_inputs(ops, B, S, H, hd, p):
     outb2, outb3 = torch.zeros_like(outb), torch.zeros_like(outb)
     call("cst_mha_fwd_h", qb, out2, lse2, B, S, H, hd, *drop.args(), outb2, d)
     call("cst_mha_fwd_h", qb, None, lse2, B, S, H, hd, *drop.args(), outb3, d)          # bf16 result only
-    def ulp_close(x, y):                                                                 # bf16 results: at most one ulp apart, rarely
-        a, b = x.view(torch.bfloat16).float(), y.view(torch.bfloat16).float()
-        assert ((a - b).abs() <= 2.0 ** -7 * b.abs() + 1e-6).all()
-        assert (a != b).float().mean().item() < 0.01
-    # bf16 LDS images, Q K^T on the bf16 matrix pipe: exact products, another summation order (a few ulps)
-    close(out2, out, 2e-5, 2e-6)
+    # bf16 LDS images, Q K^T on the bf16 matrix pipe: exact products, another summation order (a few ulps: lse); round 3: Pd is rounded to
+    # bf16 for Pd V on the bf16 pipe, so the output carries one bf16 rounding of a factor (relative L2 <= 3e-3)
     close(lse2, lse, 2e-6, 2e-6)
+    relf = ((out2 - out).norm() / out.norm()).item()
+    assert relf < 3e-3, relf
+    close(out2, out, 2.0 ** -6, 2.0 ** -7 * out.abs().max().item())
     assert torch.equal(outb3, outb2)
-    ulp_close(outb2, outb)
+    assert torch.equal(outb2.view(torch.bfloat16).float().cpu(), _bf(out2.cpu()))
     dq = torch.empty(B * S, 3 * d, device="cuda")
     dqb = torch.zeros(B * S, 3 * d, device="cuda", dtype=torch.int16)
     call("cst_mha_bwd_b", dev(qkv), dev(w), lse, dq, B, S, H, hd, *drop.args(), dqb, 3 * d)
