@@ -525,6 +525,14 @@ extern "C" int cst_sumsq_accumulate(const float* g, long n, float* out, float* p
     return CST_OK;
 }
 
+// *out += sum of n partial sums of squares, in a fixed order (the partials cst_multi_accumulate left)
+extern "C" int cst_sumsq_partials(const float* partials, int n, float* out, void* stream) {
+    CST_REQUIRE(partials && out && n > 0, "cst_sumsq_partials: bad arguments");
+    hipLaunchKernelGGL(sumsq_final_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, partials, n, out);
+    CST_LAUNCH_CHECK("cst_sumsq_partials");
+    return CST_OK;
+}
+
 // torch.nn.utils.clip_grad_norm_: coef = max_norm / (norm + 1e-6), applied only when < 1
 __global__ void clip_scale_kernel(float* __restrict__ g, long n, const float* __restrict__ sumsq, float max_norm) {
     const float norm = sqrtf(*sumsq);
@@ -628,13 +636,16 @@ extern "C" int cst_add_i32(int* p, int inc, void* stream) {
 // clip / Adam kernels and the RCCL all-reduce work on.
 // ---------------------------------------------------------------------------------------------
 #define MT_CHUNK 4096
+// ssq (optional, [gridDim.x]): the sum of squares of what the chunk's slot of `flat` holds afterwards -- the global-norm clip that follows
+// (clip_grad_norm_) then needs no pass of its own over the gradients, only the fixed-order sum of these partials (cst_sumsq_partials).
 __global__ __launch_bounds__(256) void multi_accumulate_kernel(const float* const* __restrict__ srcs, const long* __restrict__ dst_off,
                                                                const long* __restrict__ sizes, const int* __restrict__ chunk_tensor,
                                                                const long* __restrict__ chunk_start, float* __restrict__ flat,
-                                                               int accumulate) {
+                                                               int accumulate, float* __restrict__ ssq) {
+    __shared__ float red[16];
     const int t = chunk_tensor[blockIdx.x];
     const float* src = srcs[t];
-    if (!src) return;
+    if (!src && !ssq) return;
     const long s0 = chunk_start[blockIdx.x], n = sizes[t];
     float* dst = flat + dst_off[t];
     const long end = min(n, s0 + MT_CHUNK);
@@ -643,23 +654,31 @@ __global__ __launch_bounds__(256) void multi_accumulate_kernel(const float* cons
 #pragma unroll
     for (int k = 0; k < NIT; ++k) {
         const long i = min(s0 + threadIdx.x + 256L * k, end - 1);
-        v[k] = src[i];
-        if (accumulate) v[k] += dst[i];
+        v[k] = src ? src[i] : dst[i];                           // no gradient for this tensor: the slot keeps what it holds (zero, or what accumulated)
+        if (src && accumulate) v[k] += dst[i];
     }
+    float q = 0.f;
 #pragma unroll
     for (int k = 0; k < NIT; ++k) {
         const long i = s0 + threadIdx.x + 256L * k;
-        if (i < end) dst[i] = v[k];
+        if (i < end) {
+            if (src) dst[i] = v[k];
+            q += v[k] * v[k];
+        }
+    }
+    if (ssq) {
+        q = block_sum(q, red);
+        if (threadIdx.x == 0) ssq[blockIdx.x] = q;
     }
 }
 
 extern "C" int cst_multi_accumulate(const void* srcs_dev, const long* dst_off_dev, const long* sizes_dev,
                                     const int* chunk_tensor_dev, const long* chunk_start_dev, int nchunks,
-                                    float* flat, int accumulate, void* stream) {
+                                    float* flat, int accumulate, float* ssq_partials, void* stream) {
     CST_REQUIRE(srcs_dev && dst_off_dev && sizes_dev && chunk_tensor_dev && chunk_start_dev && flat && nchunks > 0,
                 "cst_multi_accumulate: bad arguments");
     hipLaunchKernelGGL(multi_accumulate_kernel, dim3(nchunks), dim3(256), 0, (hipStream_t)stream,
-                       (const float* const*)srcs_dev, dst_off_dev, sizes_dev, chunk_tensor_dev, chunk_start_dev, flat, accumulate);
+                       (const float* const*)srcs_dev, dst_off_dev, sizes_dev, chunk_tensor_dev, chunk_start_dev, flat, accumulate, ssq_partials);
     CST_LAUNCH_CHECK("cst_multi_accumulate");
     return CST_OK;
 }

@@ -70,7 +70,7 @@ class FlatGroup:
         self.m = torch.zeros(tot, device=dev, dtype=torch.float32)
         self.v = torch.zeros(tot, device=dev, dtype=torch.float32)
         self.step_dev = torch.zeros(1, device=dev, dtype=torch.int32)
-        self._ssq_partials = torch.zeros(1024, device=dev, dtype=torch.float32)     # per-block partial sums of squares (cst_sumsq_accumulate)
+        self._ssq_ready = False                           # _gather_ssq holds the per-chunk sums of squares of flat_g as it is NOW
         self.has_grad = False                             # flat_g holds gradients not yet consumed by a step
         self.direct = False                               # ops may write weight gradients straight into grad_view() (bucketed backward only)
         self.version = 0                                  # bumped by every step(): invalidates cached bf16 weight copies
@@ -82,12 +82,14 @@ class FlatGroup:
                 ct.append(t)
                 cs.append(s)
         self.nchunks = len(ct)
+        self._gather_ssq = torch.zeros(self.nchunks, device=dev, dtype=torch.float32)     # written by every gather_grads (cst_multi_accumulate)
         self.chunk_tensor = torch.tensor(ct, dtype=torch.int32, device=dev)
         self.chunk_start = torch.tensor(cs, dtype=torch.int64, device=dev)
         self.dst_off = torch.tensor(offs, dtype=torch.int64, device=dev)
         self.sizes_dev = torch.tensor(sizes, dtype=torch.int64, device=dev)
         self._src_host = torch.zeros(len(sizes), dtype=torch.int64).pin_memory() if dev.type == "cuda" else None
         self.srcs = torch.zeros(len(sizes), dtype=torch.int64, device=dev)
+        self._null_srcs = torch.zeros(len(sizes), dtype=torch.int64, device=dev)   # "no gradient for any tensor": sumsq_into's read-only pass
         self._keep = None
         # gradient-pointer tables for hipGraph captures: a captured graph re-reads its pinned table on every replay, so
         # every capture owns the tables it used.  They are allocated here and in eager calls only (never while a
@@ -140,7 +142,10 @@ class FlatGroup:
         srcs.copy_(src_host, non_blocking=True)
         self._keep = grads                                 # keep sources alive until the kernel ran
         call("cst_multi_accumulate", srcs, self.dst_off, self.sizes_dev, self.chunk_tensor, self.chunk_start,
-             self.nchunks, self.flat_g, int(accumulate))
+             self.nchunks, self.flat_g, int(accumulate), self._gather_ssq)
+        # the gather has just seen every element of flat_g: its per-chunk sums of squares stand until something else writes flat_g
+        # (an all-reduce, an in-place clip, a direct-slot write, zero_grad) -- parallel.GradReducer and the methods below reset the flag
+        self._ssq_ready = not self.direct
         for p in self.params:
             p.grad = None
         self.has_grad = True
@@ -173,6 +178,7 @@ class FlatGroup:
         if dst:
             torch._foreach_copy_(dst, src)
         self.has_grad = True
+        self._ssq_ready = False
 
     def span(self, params):
         """(lo, hi) of the flat range covered by `params`, which must be adjacent in the group's order."""
@@ -182,9 +188,17 @@ class FlatGroup:
         return self.offsets[ks[0]], hi
 
     def sumsq_into(self, out):
-        call("cst_sumsq_accumulate", self.flat_g, self.total, out, self._ssq_partials)
+        if not self._ssq_ready:
+            # the same launch with no sources: it reads every chunk of flat_g and leaves the same per-chunk partials in the same
+            # summation order, so the norm does not depend on which path produced them (bit for bit: the clip coefficient scales every
+            # parameter, and Adam turns a last-bit difference of it into lr-sized differences)
+            call("cst_multi_accumulate", self._null_srcs, self.dst_off, self.sizes_dev, self.chunk_tensor, self.chunk_start,
+                 self.nchunks, self.flat_g, 1, self._gather_ssq)
+            self._ssq_ready = True
+        call("cst_sumsq_partials", self._gather_ssq, self.nchunks, out)          # added in index order by one block
 
     def clip(self, sumsq, max_norm):
+        self._ssq_ready = False                           # scaled in place (by a coefficient that lives on the device)
         call("cst_clip_scale", self.flat_g, self.total, sumsq, float(max_norm))
 
     def step(self):
@@ -205,6 +219,7 @@ class FlatGroup:
     def zero_grad(self):
         call("cst_zero", self.flat_g, 4 * self.total)      # a kernel, not a memset node (cst_common.h)
         self.has_grad = False
+        self._ssq_ready = False
 
     def grad_of(self, p):
         i = next(k for k, q in enumerate(self.params) if q is p)

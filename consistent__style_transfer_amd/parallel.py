@@ -67,6 +67,8 @@ class GradReducer:
         current stream wait for everything outstanding."""
         if self.world == 1 and not self.force:
             return
+        for g in groups:
+            g._ssq_ready = False                          # flat_g is about to change: the gather's sums of squares no longer describe it
         if self.avg:
             for g in groups:
                 flat = g.flat_g

@@ -487,10 +487,13 @@ int cst_adam_step_clipped(float* p, const float* g, float* m, float* v, long n, 
                           const int* step_dev, const float* sumsq_dev, float max_norm, void* stream);
 int cst_add_i32(int* p, int inc, void* stream);
 /* flat[dst_off[t] + i] (+)= srcs[t][i] for all tensors in one launch (null source = skipped);
- * chunk tables (4096 elements per chunk) are built by the host once per parameter set. */
+ * chunk tables (4096 elements per chunk) are built by the host once per parameter set.  ssq_partials (optional, [nchunks]): every chunk's
+ * sum of squares of what its slot holds AFTER the call (skipped tensors included), so that the clip_grad_norm_ that follows
+ * (main_pretrain.py:139, main_warmup.py:103, main_optimize.py:211) needs no pass of its own: cst_sumsq_partials adds them in index order. */
 int cst_multi_accumulate(const void* srcs_dev, const long* dst_off_dev, const long* sizes_dev,
                          const int* chunk_tensor_dev, const long* chunk_start_dev, int nchunks,
-                         float* flat, int accumulate, void* stream);
+                         float* flat, int accumulate, float* ssq_partials, void* stream);
+int cst_sumsq_partials(const float* partials, int n, float* out, void* stream);
 
 #ifdef __cplusplus
 }

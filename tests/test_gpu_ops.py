@@ -1284,3 +1284,48 @@ def test_dec_dxe(ops, M, V, p):
     ref = C0[:, V:2 * V] + _bf(want_gx) @ _bf(E).t()
     close(C[:, V:2 * V], ref, 2e-3, 2e-3 * math.sqrt(K), f"{M}x{V}")
     assert torch.equal(C[:, :V].cpu(), C0[:, :V]) and torch.equal(C[:, 2 * V:].cpu(), C0[:, 2 * V:])
+
+
+def test_gather_grads_leaves_the_sum_of_squares_for_the_clip(ops):
+    """optim.FlatGroup.gather_grads: the multi-tensor accumulate also leaves per-chunk sums of squares of the flat gradient buffer as it is
+    afterwards (overwrite and += modes, parameters without a gradient included), so clip_groups needs no pass of its own; anything that
+    rewrites flat_g in between (in-place clip, zero_grad) falls back to the full pass."""
+    from consistent__style_transfer_amd import optim
+    torch.manual_seed(0)
+    shapes = [(300, 17), (4096,), (5000, 3), (7,), (64, 64)]
+    params = [torch.nn.Parameter(torch.randn(*s, device="cuda")) for s in shapes]
+    grp = optim.FlatGroup(params, 1e-3)
+
+    def norm2():
+        out = torch.zeros(1, device="cuda")
+        grp.sumsq_into(out)
+        return out.item()
+
+    g1 = [torch.randn(*s, device="cuda") for s in shapes]
+    for p, g in zip(params, g1):
+        p.grad = g.clone()
+    params[3].grad = None                                       # a parameter without a gradient: its slot is zero after an overwrite gather
+    grp.gather_grads(False)
+    assert grp._ssq_ready
+    want = sum((g.double() ** 2).sum().item() for i, g in enumerate(g1) if i != 3)
+    got = norm2()
+    assert abs(got - want) <= 1e-5 * want, (got, want)
+    assert abs((grp.flat_g.double() ** 2).sum().item() - want) <= 1e-9 * want
+    g2 = [torch.randn(*s, device="cuda") for s in shapes]
+    for p, g in zip(params, g2):
+        p.grad = g.clone()
+    params[1].grad = None                                       # += mode: this slot keeps what it accumulated, and it counts
+    grp.gather_grads(True)
+    want2 = (grp.flat_g.double() ** 2).sum().item()
+    got2 = norm2()
+    assert grp._ssq_ready and abs(got2 - want2) <= 1e-5 * want2, (got2, want2)
+    a, b = norm2(), norm2()
+    assert a == b                                               # fixed summation order
+    ss = torch.zeros(1, device="cuda")
+    grp.sumsq_into(ss)
+    grp.clip(ss, 1.0)                                           # in place: the partials no longer describe flat_g
+    assert not grp._ssq_ready
+    want3 = (grp.flat_g.double() ** 2).sum().item()
+    assert abs(norm2() - want3) <= 1e-5 * want3 and abs(want3 - 1.0) < 1e-3
+    grp.zero_grad()
+    assert not grp._ssq_ready and norm2() == 0.0

@@ -342,8 +342,15 @@ def test_pretrain_bucketed_backward_reduce_points_and_segmented_replay(prec):
         assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
     tol = 1e-5 if prec == "f32" else 2e-3
     np.testing.assert_allclose(buck, plain, rtol=tol, atol=tol)
-    for k in wp:                        # Adam turns rounding-level gradient differences (atomic column sums) into lr-sized steps
-        np.testing.assert_allclose(wb[k].cpu().numpy(), wp[k].cpu().numpy(), rtol=tol, atol=2e-4)
+    # Adam turns rounding-level gradient differences into lr-sized steps on the few elements whose gradient is noise: the bias / embedding
+    # gradients are float-atomic sums, so two runs of the SAME path already differ in the last bit of a handful of gradient elements in
+    # step 0 (measured: 4 - 36 elements, relative 1e-8), and six Adam steps at this lr spread that to <= 0.4 lr on <= 7 of 280 000 weights.
+    # Everything else must agree: at most 1e-4 of the elements outside (rtol, 2e-4), none further apart than 2 lr.
+    for k in wp:
+        a, b = wb[k].cpu().numpy(), wp[k].cpu().numpy()
+        bad = np.abs(a - b) > tol * np.abs(b) + 2e-4
+        assert bad.mean() <= 1e-4, (k, int(bad.sum()), a.size)
+        assert np.abs(a - b).max() <= 2 * lr, (k, float(np.abs(a - b).max()))
     if prec == "f32":
         np.testing.assert_allclose(buck, G["pretrain.curve"][:n], rtol=2e-3, atol=1e-3)
     assert [(k, t) for k, t, *_ in seen_p[:3]] == [("dn", "whole"), ("mat", "whole"), ("cls", "whole")]
