@@ -126,3 +126,10 @@ def test_decode_entry_points_validate_their_limits():
     assert L.fn["cst_gemm_bf16_skinny"](P, 2048, P, 2048, P, 512, None, 0, 256, 512, 2048, None, 0, 0.0, 0, 0, None, None) == 1 and "whole" in L.last_error()
     assert L.fn["cst_dec_fn2"](P, 640, P, 640, P, 10000, 256, 10000, 640, None, None) == 1 and "K = 512" in L.last_error()
     assert L.fn["cst_dec_attn"](P, 1024, P, P, 1024, P, 4, 18, 256, None, 0, 0.0, 0, 0, None, None) == 1 and "D == 512" in L.last_error()
+    # the soft decode's backward step (round 3)
+    assert L.fn["cst_dec_dxe"](P, 640, None, 0, P, 128, P, 10000, 256, 10000, 64, 0.0, 0, 0, None, None) == 1 and "K == 128" in L.last_error()
+    assert L.fn["cst_dec_dxe"](P, 640, None, 0, P, 128, P, 10002, 256, 10002, 128, 0.0, 0, 0, None, None) == 1 and "multiples of 4" in L.last_error()
+    assert L.fn["cst_dec_attn_cell_bwd"](P, 1024, P, P, P, 4, 18, 256, P, 1024, P, 256, P, 256, None, 0, None, 0, P, 1024, P, 256, None, 0, None) == 1 \
+        and "D == 512" in L.last_error()
+    assert L.fn["cst_dec_attn_dmem"](P, 1024, 1024, P, 1024, 1024, P, P, P, 4, 21, 80, 512, None) == 1 and "L <= 64" in L.last_error()
+    assert L.fn["cst_sumsq_partials"](None, 4, P, None) == 1 and "bad arguments" in L.last_error()
