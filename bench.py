@@ -582,6 +582,8 @@ def main():
                        "rccl": rccl},
             "roofline": roofline, "cpu_baseline": cpu, "host_path": host, "per_stage": per_stage, "f32_mode": f32_mode, "fp8w_mode": fp8w_mode, "workloads": others,
         }
+        from consistent__style_transfer_amd.gen_fn import check_exchange_timeouts
+        check_exchange_timeouts()                        # the split encoder kernel's bounded spins: a timeout would have falsified the run
         print(json.dumps(line), flush=True)
     if torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()

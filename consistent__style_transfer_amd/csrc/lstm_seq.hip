@@ -214,6 +214,226 @@ extern "C" int cst_lstm_seq_fwd(const void* whh0, const void* whh1, const float*
 }
 
 // =============================================================================================
+// Split forward (round 3): TWO workgroups per (direction, 16-row group), each owning half of the hidden units of all four gates.
+//
+// The one-workgroup kernel above is bound by the W_hh stream out of L2 (320 of 512 KB per step and workgroup, ~8.7 us a step against
+// ~1 us of MFMA).  Halved, a workgroup's share of W_hh is 256 KB and stays ON CHIP for the whole launch: 128 KB in LDS (tiles 4..7 of each
+// wave) and 128 KB in registers (tiles 0..3: 128 VGPRs a lane) -- nothing is streamed, and the price is one exchange per step: each
+// workgroup needs the other's half of h_t (16 rows x 128 units, 4 KB in bf16) before step t + 1.  That is the guide's smallest hand-off
+// (cdna_hip_programming.md Guideline 16, recipe R2; MI355X_MICROARCH.md price list, handoff-1to1: ~1.0-1.5 us for <= 4 KB): the data IS the
+// flag -- 8-byte granules {epoch = step + 1, two bf16 values} written with agent-scope (write-through) atomic stores and re-read with
+// agent-scope atomic loads until every tag carries the epoch; two buffers by step parity (a workgroup can run at most one step ahead of its
+// partner); the buffers are zeroed by a kernel in front of every launch (epochs repeat from launch to launch); every spin is bounded and
+// reports through a timeout word instead of hanging.  The fragment order of W_hh is the one-workgroup kernel's: wave w of half p reads the
+// fragments of old wave 2p + w / 2, tiles 2 (w % 2) + {0, 1}.
+// =============================================================================================
+constexpr int SQ2_NREG = 4;                                  // of a wave's 8 tiles (4 gates x 2): tiles 0..3 in registers, 4..7 in LDS
+constexpr int SQ2_FWD_LDS = 16 * SQ_HS * 2 + 4 * (8 - SQ2_NREG) * SQ_KK * 1024;
+constexpr int SQ2_GRAN = 1024;                               // granules per half and step
+constexpr unsigned SQ2_SPIN_MAX = 1u << 17;                  // sweeps before a wave gives up (a normal exchange takes 1-10; this is ~0.2 s)
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void lstm_seq_fwd2_kernel(LstmSeqArgs a, unsigned long long* xchg,
+                                                                                                       unsigned* tmo) {
+    constexpr int H = SQ_H;
+    extern __shared__ __attribute__((aligned(16))) char sq_smem[];
+    bf16_t* hA = reinterpret_cast<bf16_t*>(sq_smem);                       // [16][SQ_HS], all 256 units
+    const int d = blockIdx.y, p = blockIdx.z;
+    const LstmSeqDir& D = a.dir[d];
+    const int r0 = blockIdx.x * 16;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int lr = lane & 15, lq = lane >> 4;
+    const int L = a.L, B = a.B;
+    const int ub = 128 * p + 32 * w;                                       // first hidden unit of this wave
+    {
+        const int t0 = D.reverse ? L - 1 : 0;
+        for (int i = threadIdx.x; i < 16 * H; i += 256) {
+            const int r = i / H, u = i - r * H;
+            const float v = D.h0[(long)(r0 + r) * a.ldh0 + u];
+            hA[r * SQ_HS + u] = sq_f2bf(v);
+            if ((u >> 7) == p) {                                           // each half records its own units
+                D.hprev[(long)(r0 + r) * L * H + (long)t0 * H + u] = v;
+                if (D.hprevb) D.hprevb[(long)(r0 + r) * L * H + (long)t0 * H + u] = sq_f2bf(v);
+            }
+        }
+    }
+    float c[2][4];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) c[j][r] = 0.f;
+    // tile ti = 2 q + j (gate q, units ub + 16 j ..) = old fragment tile (wave 2p + w / 2, gate q, tile 2 (w % 2) + j)
+    const bf16_t* wfrag = D.whh + ((long)(2 * p + (w >> 1)) * 16 * SQ_KK * 64 + lane) * 8;
+    auto frag_of = [&](int ti, int kk) { return wfrag + ((long)((ti >> 1) * 4 + 2 * (w & 1) + (ti & 1)) * SQ_KK + kk) * 64 * 8; };
+    char* wl = sq_smem + 16 * SQ_HS * 2 + (w * (8 - SQ2_NREG) * SQ_KK * 64 + lane) * 16;
+#pragma unroll
+    for (int ti = SQ2_NREG; ti < 8; ++ti)
+#pragma unroll
+        for (int kk = 0; kk < SQ_KK; ++kk)
+            *reinterpret_cast<u32x4_t*>(wl + ((ti - SQ2_NREG) * SQ_KK + kk) * 1024) = *reinterpret_cast<const u32x4_t*>(frag_of(ti, kk));
+    u32x4_t wreg[SQ2_NREG][SQ_KK];
+#pragma unroll
+    for (int ti = 0; ti < SQ2_NREG; ++ti)
+#pragma unroll
+        for (int kk = 0; kk < SQ_KK; ++kk) wreg[ti][kk] = *reinterpret_cast<const u32x4_t*>(frag_of(ti, kk));
+    // exchange buffers of this (direction, row group): [half][parity][SQ2_GRAN]; thread (w, lane) owns granules 4 (64 w + lane) + k
+    typedef __attribute__((address_space(1))) unsigned long long gu64;
+    const long gbase = ((long)d * gridDim.x + blockIdx.x) * 2;
+    gu64* mine = (gu64*)(xchg + ((gbase + p) * 2) * SQ2_GRAN + 4 * (64 * w + lane));
+    gu64* theirs = (gu64*)(xchg + ((gbase + (p ^ 1)) * 2) * SQ2_GRAN + 4 * (64 * w + lane));
+    const int upb = 128 * (p ^ 1) + 32 * w;                                // the partner thread (w, lane) holds units upb + 16 j + lr
+
+    // input projection of a time index: 32 scattered 4-byte loads a lane, requested a step ahead (right after the MFMAs of the step before,
+    // so that their latency runs next to the exchange's)
+    float xv[4][2][4];
+    auto load_x = [&](int t) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    xv[q][j][r] = D.xp[(long)(r0 + 4 * lq + r) * L * 4 * H + (long)t * 4 * H + q * H + ub + 16 * j + lr];
+    };
+    load_x(D.reverse ? L - 1 : 0);
+    for (int n = 0; n < L; ++n) {
+        const int t = D.reverse ? L - 1 - n : n;
+        __syncthreads();                                  // h tile of this step complete (own half + the partner's)
+        u32x4_t af[SQ_KK];
+#pragma unroll
+        for (int kk = 0; kk < SQ_KK; ++kk)
+            af[kk] = *reinterpret_cast<const u32x4_t*>(&hA[lr * SQ_HS + kk * 32 + lq * 8]);
+        __syncthreads();                                  // every wave holds its A fragments: the tile may be overwritten
+        f32x4_t acc[8];
+#pragma unroll
+        for (int ti = 0; ti < 8; ++ti) {
+            f32x4_t s = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kk = 0; kk < SQ_KK; ++kk) {
+                const u32x4_t bfr = ti < SQ2_NREG ? wreg[ti < SQ2_NREG ? ti : 0][kk]
+                                                  : *reinterpret_cast<const u32x4_t*>(wl + ((ti - SQ2_NREG) * SQ_KK + kk) * 1024);
+                s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, af[kk]), __builtin_bit_cast(bf16x8_t, bfr), s, 0, 0, 0);
+            }
+            acc[ti] = s;
+        }
+        const bool last = n == L - 1;
+        const int tn = D.reverse ? t - 1 : t + 1;
+        // cell in registers; the step's results are kept until the exchange is under way
+        float og[4][2][4], ocn[2][4], oh[2][4];
+        unsigned hv[2][2];                                 // this lane's h values as bf16 pairs: [j][rows (0, 1) | rows (2, 3)]
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int u = ub + 16 * j + lr;
+            bf16_t hb4[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float gi = sq_sigmoid(acc[0 + j][r] + xv[0][j][r]);
+                const float gf = sq_sigmoid(acc[2 + j][r] + xv[1][j][r]);
+                const float gg = sq_tanh(acc[4 + j][r] + xv[2][j][r]);
+                const float go = sq_sigmoid(acc[6 + j][r] + xv[3][j][r]);
+                const float cn = gf * c[j][r] + gi * gg;
+                const float h = go * sq_tanh(cn);
+                c[j][r] = cn;
+                og[0][j][r] = gi; og[1][j][r] = gf; og[2][j][r] = gg; og[3][j][r] = go;
+                ocn[j][r] = cn; oh[j][r] = h;
+                hb4[r] = sq_f2bf(h);
+                hA[(4 * lq + r) * SQ_HS + u] = hb4[r];
+            }
+            hv[j][0] = (unsigned)hb4[0] | ((unsigned)hb4[1] << 16);
+            hv[j][1] = (unsigned)hb4[2] | ((unsigned)hb4[3] << 16);
+        }
+        unsigned pv[4] = {0u, 0u, 0u, 0u};
+        if (!last) {
+            load_x(tn);                                    // next step's input projection: in flight during the exchange
+            // publish this half of h_t, then take the partner's: granule k = 2 j + (row pair) of thread (w, lane).  The polling loads sit
+            // behind the x loads in this wave's (in-order) memory queue, and in front of the step's output stores.
+            const unsigned long long tag = (unsigned long long)(n + 1) << 32;
+            gu64* mo_ = mine + (long)(n & 1) * SQ2_GRAN;
+            gu64* to_ = theirs + (long)(n & 1) * SQ2_GRAN;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) __hip_atomic_store(mo_ + k, tag | hv[k >> 1][k & 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (unsigned spins = 0;; ++spins) {
+                bool ok = true;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const unsigned long long x = __hip_atomic_load(to_ + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    pv[k] = (unsigned)x;
+                    ok &= (x >> 32) == (unsigned long long)(n + 1);
+                }
+                if (__all(ok)) break;
+                if (spins >= SQ2_SPIN_MAX) {               // never hang: report and carry on with whatever is there
+                    if (lane == 0) atomicOr(tmo, 1u);
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(1);
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int u = upb + 16 * (k >> 1) + lr, row = 4 * lq + 2 * (k & 1);
+                hA[row * SQ_HS + u] = (bf16_t)(pv[k] & 0xffffu);
+                hA[(row + 1) * SQ_HS + u] = (bf16_t)(pv[k] >> 16);
+            }
+        }
+        // the step's outputs: fire and forget (they drain under the next step's barrier and MFMAs)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int u = ub + 16 * j + lr;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = r0 + 4 * lq + r;
+                float* g = D.gates + ((long)t * B + row) * 4 * H + u;
+                g[0] = og[0][j][r]; g[H] = og[1][j][r]; g[2 * H] = og[2][j][r]; g[3 * H] = og[3][j][r];
+                if (last) D.c_last[(long)row * a.ldcl + u] = ocn[j][r];
+                else D.cenc[((long)t * B + row) * H + u] = ocn[j][r];
+                const long mo = (long)row * L * 2 * H + (long)t * 2 * H + d * H + u;
+                a.mem[mo] = oh[j][r];
+                const bf16_t hb = sq_f2bf(oh[j][r]);
+                a.memb[mo] = hb;
+                if (!last) {
+                    D.hprev[(long)row * L * H + (long)tn * H + u] = oh[j][r];
+                    if (D.hprevb) D.hprevb[(long)row * L * H + (long)tn * H + u] = hb;
+                }
+            }
+        }
+    }
+}
+
+// bytes of exchange workspace cst_lstm_seq_fwd_split needs for batch B (two directions x B / 16 row groups x 2 halves x 2 parities)
+extern "C" long cst_lstm_seq_xchg_bytes(int B) { return B > 0 ? (long)2 * (B / 16) * 2 * 2 * SQ2_GRAN * 8 + 16 : 0; }
+
+extern "C" int cst_lstm_seq_fwd_split(const void* whh0, const void* whh1, const float* xp0, const float* xp1,
+                                      const float* h0, long ldh0, float* gates0, float* gates1, float* cenc0, float* cenc1,
+                                      float* hprev0, float* hprev1, void* hprev0_bf16, void* hprev1_bf16,
+                                      float* c_last, long ldcl, float* mem, void* mem_bf16,
+                                      int B, int L, int H, void* xchg, long xchg_bytes, void* stream) {
+    CST_REQUIRE(whh0 && whh1 && xp0 && xp1 && h0 && gates0 && gates1 && cenc0 && cenc1 && hprev0 && hprev1 && c_last && mem && mem_bf16 && xchg,
+                "cst_lstm_seq_fwd_split: null pointer");
+    CST_REQUIRE(H == SQ_H && B > 0 && B % 16 == 0 && L > 0 && B <= 1024, "cst_lstm_seq_fwd_split: needs H == %d, B %% 16 == 0, B <= 1024 (H=%d, B=%d)", SQ_H, H, B);
+    CST_REQUIRE(((((uintptr_t)whh0) | ((uintptr_t)whh1) | ((uintptr_t)xchg)) & 15) == 0, "cst_lstm_seq_fwd_split: W_hh fragment copies / workspace must be 16-byte aligned");
+    CST_REQUIRE(xchg_bytes >= cst_lstm_seq_xchg_bytes(B), "cst_lstm_seq_fwd_split: exchange workspace of %ld bytes, need %ld", xchg_bytes, cst_lstm_seq_xchg_bytes(B));
+    CST_REQUIRE(!hprev0_bf16 == !hprev1_bf16, "cst_lstm_seq_fwd_split: pass both bf16 hprev twins or neither");
+    LstmSeqArgs a;
+    a.dir[0] = LstmSeqDir{(const bf16_t*)whh0, xp0, h0, gates0, cenc0, hprev0, (bf16_t*)hprev0_bf16, c_last, 0};
+    a.dir[1] = LstmSeqDir{(const bf16_t*)whh1, xp1, h0 + H, gates1, cenc1, hprev1, (bf16_t*)hprev1_bf16, c_last + H, 1};
+    a.mem = mem; a.memb = (bf16_t*)mem_bf16; a.B = B; a.L = L; a.ldw = 0; a.ldh0 = ldh0; a.ldcl = ldcl;
+    hipStream_t st = (hipStream_t)stream;
+    // every polled word starts at zero in every launch (epochs repeat); the last 16 bytes are the timeout word, which is sticky (zeroed
+    // by whoever allocates the workspace, never here: a later launch must not erase an earlier one's report)
+    const long bytes = cst_lstm_seq_xchg_bytes(B);
+    if (cst_zero_words(xchg, (bytes - 16) / 4, st) != CST_OK) { cst_set_error("cst_lstm_seq_fwd_split: zero fill failed"); return CST_ERR_LAUNCH; }
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void*)lstm_seq_fwd2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SQ2_FWD_LDS);
+        attr_done = true;
+    }
+    // all 4 B / 16 workgroups must be resident together (a workgroup spins on its partner): one per CU, 256 CUs
+    CST_REQUIRE((B / 16) * 4 <= 256, "cst_lstm_seq_fwd_split: %d workgroups would not be co-resident", (B / 16) * 4);
+    hipLaunchKernelGGL(lstm_seq_fwd2_kernel, dim3(B / 16, 2, 2), dim3(256), SQ2_FWD_LDS, st, a,
+                       (unsigned long long*)xchg, (unsigned*)((char*)xchg + bytes - 16));
+    CST_LAUNCH_CHECK("cst_lstm_seq_fwd_split");
+    return CST_OK;
+}
+
+// =============================================================================================
 // Backward of the same recurrences: per step the LSTM cell backward in registers, dgates (bf16) to LDS as the A
 // operand of dh_{t-1}[16, H] = dgates[16, 4H] W_hh, whose accumulator tiles are the register slots the next cell
 // backward reads.  W_hh^T is streamed in fragment order [wave][k step 32][tile 4][lane 64][8].

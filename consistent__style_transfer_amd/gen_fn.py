@@ -76,6 +76,29 @@ def _cell_bwd(gates, c_prev, c_new, dh, dh2, dc, dgates, dc_prev, B, H, dgb=None
          dgb, _st(dgb), B, H)
 
 
+_XCHG = {}
+
+
+def _xchg_workspace(dev, B):
+    """Exchange workspace of cst_lstm_seq_fwd_split for batch B on `dev`: one persistent buffer per (device, B) -- launches on a stream are
+    ordered and the entry point zeroes it in front of each.  Its last 16 bytes are the timeout word check_exchange_timeouts() reads."""
+    key = (dev.index if dev.index is not None else torch.cuda.current_device(), B)
+    ws = _XCHG.get(key)
+    if ws is None:
+        nb = call_plain("cst_lstm_seq_xchg_bytes", B)
+        ws = _XCHG[key] = torch.empty(nb, device=dev, dtype=torch.uint8)
+        call("cst_zero", ws, nb)                              # a kernel, not a memset node: the first use may be inside a capture
+    return ws
+
+
+def check_exchange_timeouts():
+    """Raise if a workgroup of the split encoder kernel ever gave up waiting for its partner (its results were then computed from stale
+    hidden states).  Reads the device: call at synchronisation points only (validation, end of a run, the end of bench.py)."""
+    for (idx, B), ws in _XCHG.items():
+        if int(ws[-16:].view(torch.int32)[0].item()) != 0:
+            raise RuntimeError(f"cst_lstm_seq_fwd_split (device {idx}, batch {B}): a workgroup timed out waiting for its partner's hidden states")
+
+
 def _lstm_frag_order(wb, H):
     """bf16 W_hh [4H, H] (K contiguous) -> the MFMA-fragment order cst_lstm_seq_fwd streams:
     [wave][gate][tile][k step][lane = 16 lq + lr][8], element = W_hh[q*H + 64w + 16j + lr][32kk + 8lq + e]."""
@@ -169,8 +192,14 @@ class GeneratorFn(torch.autograd.Function):
         if seq_fused:
             # both directions, all L' steps, one launch: 16 batch rows per workgroup, no inter-workgroup dependencies
             (_, wb0, xp0, _, _), (_, wb1, xp1, _, _) = enc
-            call("cst_lstm_seq_fwd", _lstm_frag_order(wb0, H), _lstm_frag_order(wb1, H), xp0, xp1, h0cat, 2 * H, genc[0], genc[1], cenc[0], cenc[1],
-                 hprev[0], hprev[1], hprevb[0] if enc_b else None, hprevb[1] if enc_b else None, c_cat, 2 * H, memory, memb, B, Lp, H)
+            seq_args = (_lstm_frag_order(wb0, H), _lstm_frag_order(wb1, H), xp0, xp1, h0cat, 2 * H, genc[0], genc[1], cenc[0], cenc[1],
+                        hprev[0], hprev[1], hprevb[0] if enc_b else None, hprevb[1] if enc_b else None, c_cat, 2 * H, memory, memb, B, Lp, H)
+            if (B // 16) * 4 <= 256 and os.environ.get("CST_LSTM_SPLIT", "1") != "0":
+                # two workgroups per row group, W_hh resident on chip, one 4 KB exchange of h_t per step (lstm_seq.hip)
+                xchg = _xchg_workspace(dev, B)
+                call("cst_lstm_seq_fwd_split", *seq_args, xchg, xchg.numel())
+            else:
+                call("cst_lstm_seq_fwd", *seq_args)
         for n in (() if seq_fused else range(Lp)):
             probs = []
             for d, (w_hh, whh_b, xp, order, hp2) in enumerate(enc):

@@ -135,6 +135,8 @@ class Trainer:
                         break
                     outs.append(stage.validation_step(self, self.put(batch)))
             stage.train()
+            from .gen_fn import check_exchange_timeouts
+            check_exchange_timeouts()                                       # a synchronisation point anyway (validation_step reads losses)
             return stage.validation_end(self, outs)
 
         validate(limit=self.sanity_batches)                     # sanity check, side effects included

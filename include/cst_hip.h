@@ -274,6 +274,16 @@ int cst_lstm_seq_fwd(const void* whh0, const void* whh1, const float* xp0, const
                      float* c_last, long ldcl, float* mem, void* mem_bf16,
                      int B, int L, int H, void* stream);
 
+/* cst_lstm_seq_fwd with TWO workgroups per (direction, 16-row group), each keeping its half of W_hh on chip for the whole launch (LDS +
+ * registers: nothing is streamed) and exchanging its half of h_t with its partner once per step through tagged 8-byte granules in `xchg`
+ * (cdna_hip_programming.md Guideline 16, recipe R2; zeroed by the entry point in front of every launch; bounded spins: a timeout sets the
+ * last word of the workspace instead of hanging).  Same arguments and results as cst_lstm_seq_fwd; B <= 1024 (all workgroups co-resident). */
+long cst_lstm_seq_xchg_bytes(int B);
+int cst_lstm_seq_fwd_split(const void* whh0, const void* whh1, const float* xp0, const float* xp1,
+                           const float* h0, long ldh0, float* gates0, float* gates1, float* cenc0, float* cenc1,
+                           float* hprev0, float* hprev1, void* hprev0_bf16, void* hprev1_bf16,
+                           float* c_last, long ldcl, float* mem, void* mem_bf16,
+                           int B, int L, int H, void* xchg, long xchg_bytes, void* stream);
 /* Backward of cst_lstm_seq_fwd, also one launch: per step the cell backward in registers and dh_{prev} = dgates W_hh on
  * the bf16 matrix pipe.  wt{0,1}: W_hh^T in bf16 fragment order [wave 4][k step 32][tile 4][lane 64][8] (element
  * [w][kk][j][16*lq + lr][e] = W_hh[32kk + 8lq + e][64w + 16j + lr]); gates / cenc / c_last as the forward wrote them;

@@ -992,6 +992,22 @@ def test_lstm_seq_fwd_equals_per_step_path(ops):
     call("cst_lstm_seq_fwd", gen_fn._lstm_frag_order(wb[0], H), gen_fn._lstm_frag_order(wb[1], H), xp[0], xp[1], h0, 2 * H, f["genc"][0], f["genc"][1], f["cenc"][0], f["cenc"][1],
          f["hprev"][0], f["hprev"][1], hpb[0], hpb[1], f["c_cat"], 2 * H, f["mem"], f["memb"], B, L, H)
     torch.cuda.synchronize()
+    # round 3: the split form (two workgroups per row group exchanging h_t every step) must give the one-workgroup kernel's results
+    # bit for bit (same products, same summation order), with its timeout word untouched
+    from consistent__style_transfer_amd._lib import call_plain
+    s2 = bufs()
+    hpb2 = torch.empty(2, B, L, H, device="cuda", dtype=torch.int16)
+    nb = call_plain("cst_lstm_seq_xchg_bytes", B)
+    xchg = torch.full((nb,), 0x5A, device="cuda", dtype=torch.uint8)                  # dirty workspace: the entry point zeroes it ...
+    xchg[-16:] = 0                                                                  # ... but for the sticky timeout word at its end
+    for _ in range(3):                                                              # repeated launches reuse the workspace
+        call("cst_lstm_seq_fwd_split", gen_fn._lstm_frag_order(wb[0], H), gen_fn._lstm_frag_order(wb[1], H), xp[0], xp[1], h0, 2 * H, s2["genc"][0], s2["genc"][1],
+             s2["cenc"][0], s2["cenc"][1], s2["hprev"][0], s2["hprev"][1], hpb2[0], hpb2[1], s2["c_cat"], 2 * H, s2["mem"], s2["memb"], B, L, H, xchg, nb)
+    torch.cuda.synchronize()
+    assert int(xchg[-16:].view(torch.int32)[0].item()) == 0, "a workgroup gave up waiting for its partner"
+    for k in ("genc", "hprev", "c_cat", "mem", "memb"):
+        assert torch.equal(s2[k], f[k]), k
+    assert torch.equal(hpb2, hpb)
     assert torch.equal(hpb.view(torch.bfloat16), f["hprev"].to(torch.bfloat16))      # the optional bf16 twin of hprev
     for k in ("genc", "hprev", "c_cat", "mem"):
         close(f[k], r[k], 2e-3, 2e-3, k)                       # bf16 h feedback: rounding-level differences compound over the steps
