@@ -436,6 +436,7 @@ struct Fn2Args {
     float* C; long ldc;               // [M, V] fp32
     unsigned long long* amax;         // [DK_AMAX_GROUPS][M] packed words (zeroed by the caller) or null
     int M, V, nsub;                   // nsub = 32-column sub-tiles per workgroup
+    int vec4;                         // V, ldc multiples of 4 and C 16-byte aligned: 16-byte stores
 };
 
 constexpr int FN2_KT = 8;             // K = 512
@@ -491,8 +492,12 @@ __global__ __launch_bounds__(512) void dec_fn2_kernel(Fn2Args a) {
 #pragma unroll
         for (int ks = 0; ks < 2 * FN2_KT; ++ks) af[ks] = *reinterpret_cast<const u32x4_t*>(arow + ks * 32);
     }
-    float bestv[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
-    int besti[4] = {0x7fffffff, 0x7fffffff, 0x7fffffff, 0x7fffffff};
+    // Operands are swapped in the MFMAs below (W2 rows first): the 16 x 16 result comes out transposed, so a lane holds FOUR CONSECUTIVE
+    // columns (4 lq + r) of ONE row (16 wave + lr) -- a 16-byte store per tile instead of four 4-byte ones, and one running maximum a lane.
+    const long mrow = m0 + 16 * wave + lr;
+    const bool row_ok = mrow < a.M;
+    float bestv = -INFINITY;
+    int besti = 0x7fffffff;
     for (int j = 0; j < nsub; ++j) {
         __builtin_amdgcn_s_barrier();                       // barrier(j): sub-tile j has landed
         const unsigned bb = lds_base + (unsigned)(buf(j) - dk_smem);
@@ -518,34 +523,44 @@ __global__ __launch_bounds__(512) void dec_fn2_kernel(Fn2Args a) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const bf16x8_t av = __builtin_bit_cast(bf16x8_t, af[4 * g + q]);
-                acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, __builtin_bit_cast(bf16x8_t, bq[g & 1][2 * q]), acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, __builtin_bit_cast(bf16x8_t, bq[g & 1][2 * q + 1]), acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, bq[g & 1][2 * q]), av, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, bq[g & 1][2 * q + 1]), av, acc1, 0, 0, 0);
             }
             __builtin_amdgcn_sched_barrier(0);
         }
-        // C rows 16 wave + 4 lq + r, columns n0 + lr and n0 + 16 + lr
+        // C row 16 wave + lr, columns n0 + 4 lq + r (acc0) and n0 + 16 + 4 lq + r (acc1)
         const int n0 = (sub0 + j) * 32;
+        const int c0 = n0 + 4 * lq, c1 = n0 + 16 + 4 * lq;
+        if (row_ok) {
+            if (a.vec4) {                                   // V and ldc multiples of 4, C 16-byte aligned: a group of four columns is whole or absent
+                if (c0 < a.V) *reinterpret_cast<f32x4_t*>(a.C + mrow * a.ldc + c0) = acc0;
+                if (c1 < a.V) *reinterpret_cast<f32x4_t*>(a.C + mrow * a.ldc + c1) = acc1;
+            } else {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const long m = m0 + 16 * wave + 4 * lq + r;
-            if (m < a.M) {
-                if (n0 + lr < a.V) a.C[m * a.ldc + n0 + lr] = acc0[r];
-                if (n0 + 16 + lr < a.V) a.C[m * a.ldc + n0 + 16 + lr] = acc1[r];
+                for (int r = 0; r < 4; ++r) {
+                    if (c0 + r < a.V) a.C[mrow * a.ldc + c0 + r] = acc0[r];
+                    if (c1 + r < a.V) a.C[mrow * a.ldc + c1 + r] = acc1[r];
+                }
             }
-            if (n0 + lr < a.V && acc0[r] > bestv[r]) { bestv[r] = acc0[r]; besti[r] = n0 + lr; }
-            if (n0 + 16 + lr < a.V && acc1[r] > bestv[r]) { bestv[r] = acc1[r]; besti[r] = n0 + 16 + lr; }
         }
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (c0 + r < a.V && acc0[r] > bestv) { bestv = acc0[r]; besti = c0 + r; }
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (c1 + r < a.V && acc1[r] > bestv) { bestv = acc1[r]; besti = c1 + r; }
     }
     if (a.amax) {
-        // the columns a lane saw were ascending, so its strict > kept the FIRST maximal column; now the 16 lanes of a DPP row
+        // a lane saw its columns in ascending order, so its strict > kept its FIRST maximal column; the four lanes of a row (lq = 0 .. 3) then
+        // agree on (largest value, smallest column) and lane lq = 0 folds it into the row's group word
         const int grp = slice & (DK_AMAX_GROUPS - 1);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const float rm = row16_max(bestv[r]);
-            const int ri = dk_row16_min_i(bestv[r] == rm ? besti[r] : 0x7fffffff);
-            const long m = m0 + 16 * wave + 4 * lq + r;
-            if (lr == 0 && m < a.M) atomicMax(a.amax + (long)grp * a.M + m, dk_pack_max(rm, ri));
+        for (int sh = 16; sh <= 32; sh <<= 1) {
+            const float ov = __shfl_xor(bestv, sh);
+            const int oi = __shfl_xor(besti, sh);
+            if (ov > bestv || (ov == bestv && oi < besti)) { bestv = ov; besti = oi; }
         }
+        if (lq == 0 && row_ok) atomicMax(a.amax + (long)grp * a.M + mrow, dk_pack_max(bestv, besti));
     }
 }
 
@@ -559,6 +574,7 @@ extern "C" int cst_dec_fn2(const void* A, long lda, const void* W, long ldw, flo
     Fn2Args a;
     a.A = (const bf16_t*)A; a.lda = lda; a.W = (const bf16_t*)W; a.ldw = ldw; a.C = C; a.ldc = ldc;
     a.amax = (unsigned long long*)amax_packed; a.M = M; a.V = V;
+    a.vec4 = (V % 4 == 0 && ldc % 4 == 0 && (((uintptr_t)C) & 15) == 0) ? 1 : 0;
     const int mt = (M + 63) / 64, nsub_tot = (V + 31) / 32;
     int slices = 256 / mt; if (slices < 1) slices = 1; if (slices > nsub_tot) slices = nsub_tot;
     a.nsub = (nsub_tot + slices - 1) / slices;
