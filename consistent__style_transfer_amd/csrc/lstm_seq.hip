@@ -474,14 +474,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int lr = lane & 15, lq = lane >> 4;
     const int L = a.L, B = a.B;
+    // The MFMAs below take W_hh^T as the FIRST operand: the 16 x 16 result comes out transposed, so a lane holds FOUR CONSECUTIVE units
+    // (64 w + 16 j + 4 lq + r) of ONE batch row (lr).  Every operand of the cell backward is then a 16-byte load and every result a 16-byte
+    // (fp32) or 8-byte (bf16) store: 28 loads and 32 stores a lane and step where the element-per-lane layout needed 112 and 128.
+    const int row = r0 + lr;
     float dc[SQ_J][4], dhr[SQ_J][4];
 #pragma unroll
-    for (int j = 0; j < SQ_J; ++j)
+    for (int j = 0; j < SQ_J; ++j) {
+        const f32x4_t v = *reinterpret_cast<const f32x4_t*>(D.dc_last + (long)row * a.lddcl + 64 * w + 16 * j + 4 * lq);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            dc[j][r] = D.dc_last[(long)(r0 + 4 * lq + r) * a.lddcl + 64 * w + 16 * j + lr];
-            dhr[j][r] = 0.f;
-        }
+        for (int r = 0; r < 4; ++r) { dc[j][r] = v[r]; dhr[j][r] = 0.f; }
+    }
     const bf16_t* wfrag = D.wt + ((long)w * SQ_KB * SQ_J * 64 + lane) * 8;
     char* wl = sq_smem + 16 * SQ_GS * 2 + (w * SQ_NLB * SQ_J * 64 + lane) * 16;
 #pragma unroll
@@ -497,34 +500,45 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     for (int n = L - 1; n >= 0; --n) {
         const int t = D.reverse ? L - 1 - n : n;
         const int tp = D.reverse ? t + 1 : t - 1;          // time index of the forward step before this one
-        // ---- cell backward of step n (element r of tile j = (row 4lq + r, unit 64w + 16j + lr)) ----
+        // ---- cell backward of step n (element r of tile j = (row lr, unit 64w + 16j + 4lq + r)) ----
 #pragma unroll
         for (int j = 0; j < SQ_J; ++j) {
-            const int u = 64 * w + 16 * j + lr;
+            const int u = 64 * w + 16 * j + 4 * lq;
+            const float* g = D.gates + ((long)t * B + row) * 4 * H + u;
+            const f32x4_t gi = *reinterpret_cast<const f32x4_t*>(g), gf = *reinterpret_cast<const f32x4_t*>(g + H);
+            const f32x4_t gg = *reinterpret_cast<const f32x4_t*>(g + 2 * H), go = *reinterpret_cast<const f32x4_t*>(g + 3 * H);
+            const f32x4_t cn = *reinterpret_cast<const f32x4_t*>((n == L - 1) ? D.c_last + (long)row * a.ldcl + u : D.cenc + ((long)t * B + row) * H + u);
+            const f32x4_t cp = (n == 0) ? (f32x4_t){0.f, 0.f, 0.f, 0.f} : *reinterpret_cast<const f32x4_t*>(D.cenc + ((long)tp * B + row) * H + u);
+            const f32x4_t dm = *reinterpret_cast<const f32x4_t*>(a.dmem + (long)row * L * 2 * H + (long)t * 2 * H + d * H + u);
+            f32x4_t d0, d1, d2, d3;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int row = r0 + 4 * lq + r;
-                const float* g = D.gates + ((long)t * B + row) * 4 * H + u;
-                const float gi = g[0], gf = g[H], gg = g[2 * H], go = g[3 * H];
-                const float cn = (n == L - 1) ? D.c_last[(long)row * a.ldcl + u] : D.cenc[((long)t * B + row) * H + u];
-                const float cp = (n == 0) ? 0.f : D.cenc[((long)tp * B + row) * H + u];
-                const float dht = a.dmem[(long)row * L * 2 * H + (long)t * 2 * H + d * H + u] + dhr[j][r];
-                const float tc = sq_tanh(cn);
-                const float dct = dc[j][r] + dht * go * (1.f - tc * tc);
-                const float d0 = dct * gg * gi * (1.f - gi);
-                const float d1 = dct * cp * gf * (1.f - gf);
-                const float d2 = dct * gi * (1.f - gg * gg);
-                const float d3 = dht * tc * go * (1.f - go);
-                dc[j][r] = dct * gf;
-                float* dg = D.dgates + (long)row * L * 4 * H + (long)t * 4 * H + u;
-                dg[0] = d0; dg[H] = d1; dg[2 * H] = d2; dg[3 * H] = d3;
-                bf16_t* ga = gA + (4 * lq + r) * SQ_GS + u;
-                const bf16_t b0 = sq_f2bf(d0), b1 = sq_f2bf(d1), b2 = sq_f2bf(d2), b3 = sq_f2bf(d3);
-                ga[0] = b0; ga[H] = b1; ga[2 * H] = b2; ga[3 * H] = b3;
-                if (D.dgatesb) {
-                    bf16_t* gb = D.dgatesb + (long)row * L * 4 * H + (long)t * 4 * H + u;
-                    gb[0] = b0; gb[H] = b1; gb[2 * H] = b2; gb[3 * H] = b3;
-                }
+                const float dht = dm[r] + dhr[j][r];
+                const float tc = sq_tanh(cn[r]);
+                const float dct = dc[j][r] + dht * go[r] * (1.f - tc * tc);
+                d0[r] = dct * gg[r] * gi[r] * (1.f - gi[r]);
+                d1[r] = dct * cp[r] * gf[r] * (1.f - gf[r]);
+                d2[r] = dct * gi[r] * (1.f - gg[r] * gg[r]);
+                d3[r] = dht * tc * go[r] * (1.f - go[r]);
+                dc[j][r] = dct * gf[r];
+            }
+            float* dg = D.dgates + (long)row * L * 4 * H + (long)t * 4 * H + u;
+            *reinterpret_cast<f32x4_t*>(dg) = d0; *reinterpret_cast<f32x4_t*>(dg + H) = d1;
+            *reinterpret_cast<f32x4_t*>(dg + 2 * H) = d2; *reinterpret_cast<f32x4_t*>(dg + 3 * H) = d3;
+            auto pack4 = [](const f32x4_t& v) {
+                uint2 q;
+                q.x = (uint32_t)sq_f2bf(v[0]) | ((uint32_t)sq_f2bf(v[1]) << 16);
+                q.y = (uint32_t)sq_f2bf(v[2]) | ((uint32_t)sq_f2bf(v[3]) << 16);
+                return q;
+            };
+            const uint2 b0 = pack4(d0), b1 = pack4(d1), b2 = pack4(d2), b3 = pack4(d3);
+            bf16_t* ga = gA + lr * SQ_GS + u;
+            *reinterpret_cast<uint2*>(ga) = b0; *reinterpret_cast<uint2*>(ga + H) = b1;
+            *reinterpret_cast<uint2*>(ga + 2 * H) = b2; *reinterpret_cast<uint2*>(ga + 3 * H) = b3;
+            if (D.dgatesb) {
+                bf16_t* gb = D.dgatesb + (long)row * L * 4 * H + (long)t * 4 * H + u;
+                *reinterpret_cast<uint2*>(gb) = b0; *reinterpret_cast<uint2*>(gb + H) = b1;
+                *reinterpret_cast<uint2*>(gb + 2 * H) = b2; *reinterpret_cast<uint2*>(gb + 3 * H) = b3;
             }
         }
         __syncthreads();                                  // the dgates tile is complete
@@ -554,8 +568,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int j = 0; j < SQ_J; ++j)
-                acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, af),
-                                                                 __builtin_bit_cast(bf16x8_t, kk < SQ_NRB ? wreg[kk < SQ_NRB ? kk : 0][j] : bb[kk % 3][j]), acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, kk < SQ_NRB ? wreg[kk < SQ_NRB ? kk : 0][j] : bb[kk % 3][j]),
+                                                                 __builtin_bit_cast(bf16x8_t, af), acc[j], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
 #pragma unroll
@@ -566,8 +580,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     }
 #pragma unroll
     for (int j = 0; j < SQ_J; ++j)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) D.dh0[(long)(r0 + 4 * lq + r) * a.lddh0 + 64 * w + 16 * j + lr] = dhr[j][r];
+        *reinterpret_cast<f32x4_t*>(D.dh0 + (long)row * a.lddh0 + 64 * w + 16 * j + 4 * lq) = (f32x4_t){dhr[j][0], dhr[j][1], dhr[j][2], dhr[j][3]};
 }
 
 extern "C" int cst_lstm_seq_bwd(const void* wt0, const void* wt1, const float* gates0, const float* gates1,
@@ -581,6 +594,13 @@ extern "C" int cst_lstm_seq_bwd(const void* wt0, const void* wt1, const float* g
     CST_REQUIRE(((((uintptr_t)wt0) | ((uintptr_t)wt1)) & 15) == 0, "cst_lstm_seq_bwd: W_hh^T fragment copies must be 16-byte aligned");
     LstmSeqBwdArgs a;
     CST_REQUIRE(!dgates0_bf16 == !dgates1_bf16, "cst_lstm_seq_bwd: pass both bf16 dgates twins or neither");
+    {   // 16-byte loads / stores of four consecutive units per lane
+        const uintptr_t al = (uintptr_t)gates0 | (uintptr_t)gates1 | (uintptr_t)cenc0 | (uintptr_t)cenc1 | (uintptr_t)c_last | (uintptr_t)dc_last |
+                             (uintptr_t)dmem | (uintptr_t)dgates0 | (uintptr_t)dgates1 | (uintptr_t)dh0;
+        CST_REQUIRE((al & 15) == 0 && ldcl % 4 == 0 && lddcl % 4 == 0 && lddh0 % 4 == 0 &&
+                    ((((uintptr_t)dgates0_bf16) | ((uintptr_t)dgates1_bf16)) & 7) == 0,
+                    "cst_lstm_seq_bwd: fp32 operands must be 16-byte aligned with leading dimensions that are multiples of 4 (bf16 twins: 8-byte)");
+    }
     a.dir[0] = LstmSeqBwdDir{(const bf16_t*)wt0, gates0, cenc0, c_last, dc_last, dgates0, (bf16_t*)dgates0_bf16, dh0, 0};
     a.dir[1] = LstmSeqBwdDir{(const bf16_t*)wt1, gates1, cenc1, c_last + H, dc_last + H, dgates1, (bf16_t*)dgates1_bf16, dh0 + H, 1};
     a.dmem = dmem; a.B = B; a.L = L; a.ldcl = ldcl; a.lddcl = lddcl; a.lddh0 = lddh0;
