@@ -372,6 +372,17 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
+    # The split encoder kernel (two workgroups per row group exchanging h_t inside the launch) relies on its workgroups being resident
+    # together; its spins are bounded and report through a sticky word.  Probe it with one eager step before anything is captured: if a
+    # workgroup ever gave up here, the one-workgroup kernel is used for the whole run (and the JSON line says so) instead of timing garbage.
+    from consistent__style_transfer_amd import gen_fn
+    run_step(stages_, batches, 0, reducer)               # with the run's own reducer: replicas stay identical
+    torch.cuda.synchronize()
+    split_ok = not gen_fn.exchange_timed_out(clear=True)
+    if not split_ok:
+        os.environ["CST_LSTM_SPLIT"] = "0"
+        print(f"[bench] rank {rank}: cst_lstm_seq_fwd_split timed out in the probe step -- falling back to cst_lstm_seq_fwd for this run",
+              file=sys.stderr, flush=True)
     if os.environ.get("CST_FORCE_SEGMENTS") and reducer is None:
         reducer = lambda groups, defer=False: None     # single-GPU rehearsal of the segmented (N > 1) launch path
     use_graph = not args.no_graph
@@ -579,7 +590,7 @@ def main():
                        "seq_len": w["L"], "vocab": w["V"], "critic_layers": w["n_layer"], "d_model": w["d_model"],
                        "parallelism": f"dp{world}", "stages": "pretrain+warmup+optimize(G+D)", "weights": "random-init",
                        "launch": ("hipGraph replay" if reducer is None else "hipGraph segments + eager all-reduce") if use_graph else "eager",
-                       "rccl": rccl},
+                       "rccl": rccl, "encoder_split": bool(split_ok and os.environ.get("CST_LSTM_SPLIT", "1") != "0")},
             "roofline": roofline, "cpu_baseline": cpu, "host_path": host, "per_stage": per_stage, "f32_mode": f32_mode, "fp8w_mode": fp8w_mode, "workloads": others,
         }
         from consistent__style_transfer_amd.gen_fn import check_exchange_timeouts

@@ -91,12 +91,20 @@ def _xchg_workspace(dev, B):
     return ws
 
 
+def exchange_timed_out(clear=False):
+    """(device, batch) keys of the split-encoder workspaces whose sticky timeout word is set (reads the device: synchronises)."""
+    bad = [k for k, ws in _XCHG.items() if int(ws[-16:].view(torch.int32)[0].item()) != 0]
+    if clear:
+        for k in bad:
+            _XCHG[k][-16:].zero_()
+    return bad
+
+
 def check_exchange_timeouts():
     """Raise if a workgroup of the split encoder kernel ever gave up waiting for its partner (its results were then computed from stale
     hidden states).  Reads the device: call at synchronisation points only (validation, end of a run, the end of bench.py)."""
-    for (idx, B), ws in _XCHG.items():
-        if int(ws[-16:].view(torch.int32)[0].item()) != 0:
-            raise RuntimeError(f"cst_lstm_seq_fwd_split (device {idx}, batch {B}): a workgroup timed out waiting for its partner's hidden states")
+    for idx, B in exchange_timed_out():
+        raise RuntimeError(f"cst_lstm_seq_fwd_split (device {idx}, batch {B}): a workgroup timed out waiting for its partner's hidden states")
 
 
 def _lstm_frag_order(wb, H):
