@@ -376,9 +376,11 @@ def main():
     # together; its spins are bounded and report through a sticky word.  Probe it with one eager step before anything is captured: if a
     # workgroup ever gave up here, the one-workgroup kernel is used for the whole run (and the JSON line says so) instead of timing garbage.
     from consistent__style_transfer_amd import gen_fn
-    run_step(stages_, batches, 0, reducer)               # with the run's own reducer: replicas stay identical
-    torch.cuda.synchronize()
-    split_ok = not gen_fn.exchange_timed_out(clear=True)
+    split_ok = True
+    if not args.no_graph:                                # eager runs (profiles: exact launch counts per step) are checked at the end instead
+        run_step(stages_, batches, 0, reducer)           # with the run's own reducer: replicas stay identical
+        torch.cuda.synchronize()
+        split_ok = not gen_fn.exchange_timed_out(clear=True)
     if not split_ok:
         os.environ["CST_LSTM_SPLIT"] = "0"
         print(f"[bench] rank {rank}: cst_lstm_seq_fwd_split timed out in the probe step -- falling back to cst_lstm_seq_fwd for this run",
