@@ -80,9 +80,13 @@ _XCHG = {}
 
 
 def _xchg_workspace(dev, B):
-    """Exchange workspace of cst_lstm_seq_fwd_split for batch B on `dev`: one persistent buffer per (device, B) -- launches on a stream are
-    ordered and the entry point zeroes it in front of each.  Its last 16 bytes are the timeout word check_exchange_timeouts() reads."""
-    key = (dev.index if dev.index is not None else torch.cuda.current_device(), B)
+    """Exchange workspace of cst_lstm_seq_fwd_split for batch B on `dev`: one persistent buffer per (device, B, stream) -- launches on a stream
+    are ordered and the entry point zeroes it in front of each.  Its last 16 bytes are the timeout word check_exchange_timeouts() reads."""
+    # one buffer per (device, B, stream): launches on ONE stream are ordered, two eager streams (stages.Fork) must not share granules.  A
+    # capture uses the default stream's buffer (created by the eager pass in front of every capture): a buffer created INSIDE a capture
+    # would have its zero fill -- sticky timeout word included -- replayed with the graph.
+    sid = 0 if torch.cuda.is_current_stream_capturing() else int(torch.cuda.current_stream(dev).cuda_stream)
+    key = (dev.index if dev.index is not None else torch.cuda.current_device(), B, sid)
     ws = _XCHG.get(key)
     if ws is None:
         nb = call_plain("cst_lstm_seq_xchg_bytes", B)
@@ -93,10 +97,10 @@ def _xchg_workspace(dev, B):
 
 def exchange_timed_out(clear=False):
     """(device, batch) keys of the split-encoder workspaces whose sticky timeout word is set (reads the device: synchronises)."""
-    bad = [k for k, ws in _XCHG.items() if int(ws[-16:].view(torch.int32)[0].item()) != 0]
+    bad = [k[:2] for k, ws in _XCHG.items() if int(ws[-16:].view(torch.int32)[0].item()) != 0]
     if clear:
-        for k in bad:
-            _XCHG[k][-16:].zero_()
+        for ws in _XCHG.values():
+            ws[-16:].zero_()
     return bad
 
 
