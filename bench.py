@@ -327,6 +327,22 @@ def main():
     ap.add_argument("--breakdown", action="store_true", help="print the per-entry-point time table to stderr")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` typed by hand (no torch.distributed.run around it): start the N ranks as CHILD processes before
+        # this process has touched the GPU (nothing above initialises HIP), relay their output -- rank 0 prints the JSON line -- and
+        # leave with their status.  Never an exec: a process that has initialised the GPU must not be replaced.
+        import socket
+        import subprocess
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        print(f"[bench] WORLD_SIZE unset: launching {args.gpus} ranks: {' '.join(cmd)}", file=sys.stderr, flush=True)
+        env = dict(os.environ)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        sys.exit(subprocess.call(cmd, env=env))
+
     from consistent__style_transfer_amd import _lib, ops
     from consistent__style_transfer_amd.parallel import GradReducer, init_distributed, max_over_ranks
     rank, local, world = init_distributed()
@@ -380,11 +396,7 @@ def main():
     if not args.no_graph:                                # eager runs (profiles: exact launch counts per step) are checked at the end instead
         run_step(stages_, batches, 0, reducer)           # with the run's own reducer: replicas stay identical
         torch.cuda.synchronize()
-        split_ok = not gen_fn.exchange_timed_out(clear=True)
-    if not split_ok:
-        os.environ["CST_LSTM_SPLIT"] = "0"
-        print(f"[bench] rank {rank}: cst_lstm_seq_fwd_split timed out in the probe step -- falling back to cst_lstm_seq_fwd for this run",
-              file=sys.stderr, flush=True)
+        split_ok = gen_fn.probe_split()                  # a timeout here switches the process to cst_lstm_seq_fwd (and says so)
     if os.environ.get("CST_FORCE_SEGMENTS") and reducer is None:
         reducer = lambda groups, defer=False: None     # single-GPU rehearsal of the segmented (N > 1) launch path
     use_graph = not args.no_graph
@@ -592,7 +604,7 @@ def main():
                        "seq_len": w["L"], "vocab": w["V"], "critic_layers": w["n_layer"], "d_model": w["d_model"],
                        "parallelism": f"dp{world}", "stages": "pretrain+warmup+optimize(G+D)", "weights": "random-init",
                        "launch": ("hipGraph replay" if reducer is None else "hipGraph segments + eager all-reduce") if use_graph else "eager",
-                       "rccl": rccl, "encoder_split": bool(split_ok and os.environ.get("CST_LSTM_SPLIT", "1") != "0")},
+                       "rccl": rccl, "encoder_split": bool(split_ok and gen_fn.split_enabled(w["B"]))},
             "roofline": roofline, "cpu_baseline": cpu, "host_path": host, "per_stage": per_stage, "f32_mode": f32_mode, "fp8w_mode": fp8w_mode, "workloads": others,
         }
         from consistent__style_transfer_amd.gen_fn import check_exchange_timeouts

@@ -30,6 +30,17 @@ void cst_set_error(const char* fmt, ...);
 
 #define CST_WAVE 64
 
+// Function attributes (the dynamic-LDS limit) are per DEVICE: a launcher sets them the first time it runs on each device of the
+// process, not once per process.  `static CstPerDevice done; if (cst_first_on_device(done)) hipFuncSetAttribute(...)`.
+struct CstPerDevice { bool done[64] = {}; };
+static inline bool cst_first_on_device(CstPerDevice& f) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return true;
+    if (f.done[dev]) return false;
+    f.done[dev] = true;
+    return true;
+}
+
 // Zero n 4-byte words with a KERNEL (csrc/pointwise.hip).  Never hipMemsetAsync inside a library call: under segmented
 // hipGraph capture (capture_error_mode thread_local, needed next to RCCL's threads) a memset issued by the autograd engine
 // thread was replayed out of order -- the column-sum target of the last encoder layer got zeroed BEFORE an earlier tenant of

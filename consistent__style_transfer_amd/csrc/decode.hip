@@ -227,10 +227,9 @@ extern "C" int cst_dec_gates(const void* A, long lda, const void* W, long ldw,
     a.xb_out = (bf16_t*)x_bf16_out; a.ldxb = ldxb; a.bias = bias; a.c_prev = c_prev; a.ldcp = ldcp;
     a.gates = gates; a.ldg = ldg; a.c_out = c_out; a.ldc = ldc; a.h_out = h_out; a.ldh = ldh;
     a.hb_next = (bf16_t*)h_bf16_next; a.ldhb = ldhb; a.B = B; a.E = E; a.Hd = Hd; a.K = K;
-    static bool attr_done = false;
-    if (!attr_done) {
+    static CstPerDevice attr_done;
+    if (cst_first_on_device(attr_done)) {
         (void)hipFuncSetAttribute((const void*)dec_gates_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_done = true;
     }
     hipLaunchKernelGGL(dec_gates_kernel, dim3((B + 31) / 32, Hd / 16), dim3(512), (size_t)lds, (hipStream_t)stream, a);
     CST_LAUNCH_CHECK("cst_dec_gates");
@@ -382,10 +381,9 @@ extern "C" int cst_gemm_bf16_skinny(const void* A, long lda, const void* B, long
     a.A = (const bf16_t*)A; a.lda = lda; a.B = (const bf16_t*)B; a.ldb = ldb; a.C = C; a.ldc = ldc; a.Cb = (bf16_t*)Cb; a.ldcb = ldcb;
     a.bias = bias; a.act = act; a.M = M; a.N = N; a.K = K;
     a.drop = cst_make_drop(drop_p, drop_seed, drop_stream, drop_seed_dev, (long)M * N);
-    static bool attr_done = false;
-    if (!attr_done) {
+    static CstPerDevice attr_done;
+    if (cst_first_on_device(attr_done)) {
         (void)hipFuncSetAttribute((const void*)gemm_bf16_skinny_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_done = true;
     }
     hipLaunchKernelGGL(gemm_bf16_skinny_kernel, dim3((M + 31) / 32, N / 32), dim3(512), (size_t)(K / 64) * 64 * 128, (hipStream_t)stream, a);
     CST_LAUNCH_CHECK("cst_gemm_bf16_skinny");
@@ -579,10 +577,9 @@ extern "C" int cst_dec_fn2(const void* A, long lda, const void* W, long ldw, flo
     int slices = 256 / mt; if (slices < 1) slices = 1; if (slices > nsub_tot) slices = nsub_tot;
     a.nsub = (nsub_tot + slices - 1) / slices;
     slices = ((nsub_tot + a.nsub - 1) / a.nsub + 7) / 8 * 8;        // a multiple of 8 (XCD grouping in the kernel); surplus slices exit at once
-    static bool attr_done = false;
-    if (!attr_done) {
+    static CstPerDevice attr_done;
+    if (cst_first_on_device(attr_done)) {
         (void)hipFuncSetAttribute((const void*)dec_fn2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_done = true;
     }
     hipLaunchKernelGGL(dec_fn2_kernel, dim3(mt, slices), dim3(512), (size_t)FN2_NB * FN2_SUB, (hipStream_t)stream, a);
     CST_LAUNCH_CHECK("cst_dec_fn2");
@@ -910,10 +907,9 @@ extern "C" int cst_dec_dxe(const float* g, long ldg, float* gx_out, long ldgx, c
     if (a.cps > 16) a.cps = 16;                             // 16 chunks = 128 KB of table rows in LDS
     ns = (nchunks + a.cps - 1) / a.cps;
     a.rb = rb; a.ns = ns;
-    static bool attr_done = false;
-    if (!attr_done) {
+    static CstPerDevice attr_done;
+    if (cst_first_on_device(attr_done)) {
         (void)hipFuncSetAttribute((const void*)dec_dxe_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-        attr_done = true;
     }
     hipLaunchKernelGGL(dec_dxe_kernel, dim3((rb * ns + 7) / 8 * 8), dim3(256), (size_t)a.cps * 32 * 256, (hipStream_t)stream, a);
     CST_LAUNCH_CHECK("cst_dec_dxe");

@@ -1227,10 +1227,9 @@ static int bgemm_lc_launch(const BGemmArgs& g, hipStream_t st) {
     const size_t lds = (size_t)LC_NST * LC_STAGE;
     static const int gn = getenv("CST_GB_GN") ? atoi(getenv("CST_GB_GN")) : 2;
     static const int ncu = []() { int dev = 0, n = 256; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n > 0 ? n : 256; }();
-    static bool attr_done = false;
-    if (!attr_done) {
+    static CstPerDevice attr_done;
+    if (cst_first_on_device(attr_done)) {
         (void)hipFuncSetAttribute((const void*)cst_gemm_bf16_lc_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_done = true;
     }
     const int ntiles = (g.M / LC_BM) * (g.N / LC_BN);
     dim3 grid(ntiles < ncu ? ntiles : ncu, 1, 1), block(512);
@@ -1256,10 +1255,9 @@ static int bgemm_big_launch_t(const BGemmArgs& g, hipStream_t st) {
     static const int gn0 = getenv("CST_GB_GN") ? atoi(getenv("CST_GB_GN")) : 2;       // tile columns per XCD strip (A/B panel sharing)
     const char* ab = getenv("CST_GB_ABL");                                             // timing ablations (tools/gemm_bench.py abl): results are wrong
     const int gn = gn0 | ((ab ? atoi(ab) : 0) << 16);
-    static bool attr_done = false;
-    if (!attr_done) {
+    static CstPerDevice attr_done;
+    if (cst_first_on_device(attr_done)) {
         (void)hipFuncSetAttribute((const void*)cst_gemm_bf16_big_kernel<WR, NST>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_done = true;
     }
     dim3 grid((g.M / (128 * WR)) * (g.N / GB_T), 1, 1), block(256 * WR);
     if (cst_prof_on()) {
@@ -1280,10 +1278,9 @@ static int bgemm_big_launch_t(const BGemmArgs& g, hipStream_t st) {
 template <int BM, int BN, int NSTAGE, bool TT = false, bool BF8 = false, int NW = 4>
 static int bgemm_launch(const BGemmArgs& g, hipStream_t st) {
     const size_t lds = (size_t)NSTAGE * (BM * BROW + BN * (BF8 ? 64 : BROW));
-    static bool attr_done = false;
-    if (!attr_done && lds > 64 * 1024) {
+    static CstPerDevice attr_done;
+    if (lds > 64 * 1024 && cst_first_on_device(attr_done)) {
         (void)hipFuncSetAttribute((const void*)cst_gemm_bf16_kernel<BM, BN, NSTAGE, TT, BF8, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_done = true;
     }
     dim3 grid(cst_div_up(g.M, BM) * cst_div_up(g.N, BN), g.splits, g.A2 ? 2 : 1), block(64 * NW);
     if (cst_prof_on()) {

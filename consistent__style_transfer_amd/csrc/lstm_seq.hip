@@ -203,10 +203,9 @@ extern "C" int cst_lstm_seq_fwd(const void* whh0, const void* whh1, const float*
     a.dir[0] = LstmSeqDir{(const bf16_t*)whh0, xp0, h0, gates0, cenc0, hprev0, (bf16_t*)hprev0_bf16, c_last, 0};
     a.dir[1] = LstmSeqDir{(const bf16_t*)whh1, xp1, h0 + H, gates1, cenc1, hprev1, (bf16_t*)hprev1_bf16, c_last + H, 1};
     a.mem = mem; a.memb = (bf16_t*)mem_bf16; a.B = B; a.L = L; a.ldw = 0; a.ldh0 = ldh0; a.ldcl = ldcl;
-    static bool attr_done = false;
-    if (!attr_done) {
+    static CstPerDevice attr_done;
+    if (cst_first_on_device(attr_done)) {
         (void)hipFuncSetAttribute((const void*)lstm_seq_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SQ_FWD_LDS);
-        attr_done = true;
     }
     hipLaunchKernelGGL(lstm_seq_fwd_kernel, dim3(B / 16, 2), dim3(256), SQ_FWD_LDS, (hipStream_t)stream, a);
     CST_LAUNCH_CHECK("cst_lstm_seq_fwd");
@@ -360,8 +359,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                     ok &= (x >> 32) == (unsigned long long)(n + 1);
                 }
                 if (__all(ok)) break;
-                if (spins >= SQ2_SPIN_MAX) {               // never hang: report and carry on with whatever is there
+                if (spins >= SQ2_SPIN_MAX) {
+                    // never hang -- and never compute on stale hidden states either: report through the sticky word and poison the
+                    // partner's half of h_t with NaN, so that every later gate, mem row and c_last of this row group is NaN and the
+                    // loss of THIS step fails loudly (the host reads the word at its next synchronisation point)
                     if (lane == 0) atomicOr(tmo, 1u);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) pv[k] = 0x7FC07FC0u;
                     break;
                 }
                 __builtin_amdgcn_s_sleep(1);
@@ -400,37 +404,78 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 // bytes of exchange workspace cst_lstm_seq_fwd_split needs for batch B (two directions x B / 16 row groups x 2 halves x 2 parities)
 extern "C" long cst_lstm_seq_xchg_bytes(int B) { return B > 0 ? (long)2 * (B / 16) * 2 * 2 * SQ2_GRAN * 8 + 16 : 0; }
 
-extern "C" int cst_lstm_seq_fwd_split(const void* whh0, const void* whh1, const float* xp0, const float* xp1,
-                                      const float* h0, long ldh0, float* gates0, float* gates1, float* cenc0, float* cenc1,
-                                      float* hprev0, float* hprev1, void* hprev0_bf16, void* hprev1_bf16,
-                                      float* c_last, long ldcl, float* mem, void* mem_bf16,
-                                      int B, int L, int H, void* xchg, long xchg_bytes, void* stream) {
+// CUs of the current device (one lookup per device; the split kernel's workgroups need a whole CU each: 136 KB of LDS, 512 registers a lane)
+static int sq_device_cus() {
+    static int cus[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
+    if (cus[dev] == 0) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 0;
+        cus[dev] = n > 0 ? n : -1;
+    }
+    return cus[dev] > 0 ? cus[dev] : 0;
+}
+
+// workgroups cst_lstm_seq_fwd_split launches for batch B, and how many this device can keep resident together (its CU count): the caller
+// (gen_fn.split_enabled) takes the split kernel only when the first is well inside the second
+extern "C" int cst_lstm_seq_split_workgroups(int B) { return B > 0 ? (B / 16) * 4 : 0; }
+extern "C" int cst_lstm_seq_split_capacity() { return sq_device_cus(); }
+
+static int sq_fwd_split_launch(const char* who, int halves, const void* whh0, const void* whh1, const float* xp0, const float* xp1,
+                               const float* h0, long ldh0, float* gates0, float* gates1, float* cenc0, float* cenc1,
+                               float* hprev0, float* hprev1, void* hprev0_bf16, void* hprev1_bf16,
+                               float* c_last, long ldcl, float* mem, void* mem_bf16,
+                               int B, int L, int H, void* xchg, long xchg_bytes, void* stream) {
     CST_REQUIRE(whh0 && whh1 && xp0 && xp1 && h0 && gates0 && gates1 && cenc0 && cenc1 && hprev0 && hprev1 && c_last && mem && mem_bf16 && xchg,
-                "cst_lstm_seq_fwd_split: null pointer");
-    CST_REQUIRE(H == SQ_H && B > 0 && B % 16 == 0 && L > 0 && B <= 1024, "cst_lstm_seq_fwd_split: needs H == %d, B %% 16 == 0, B <= 1024 (H=%d, B=%d)", SQ_H, H, B);
-    CST_REQUIRE(((((uintptr_t)whh0) | ((uintptr_t)whh1) | ((uintptr_t)xchg)) & 15) == 0, "cst_lstm_seq_fwd_split: W_hh fragment copies / workspace must be 16-byte aligned");
-    CST_REQUIRE(xchg_bytes >= cst_lstm_seq_xchg_bytes(B), "cst_lstm_seq_fwd_split: exchange workspace of %ld bytes, need %ld", xchg_bytes, cst_lstm_seq_xchg_bytes(B));
-    CST_REQUIRE(!hprev0_bf16 == !hprev1_bf16, "cst_lstm_seq_fwd_split: pass both bf16 hprev twins or neither");
+                "%s: null pointer", who);
+    CST_REQUIRE(H == SQ_H && B > 0 && B % 16 == 0 && L > 0 && B <= 1024, "%s: needs H == %d, B %% 16 == 0, B <= 1024 (H=%d, B=%d)", who, SQ_H, H, B);
+    CST_REQUIRE(((((uintptr_t)whh0) | ((uintptr_t)whh1) | ((uintptr_t)xchg)) & 15) == 0, "%s: W_hh fragment copies / workspace must be 16-byte aligned", who);
+    CST_REQUIRE(xchg_bytes >= cst_lstm_seq_xchg_bytes(B), "%s: exchange workspace of %ld bytes, need %ld", who, xchg_bytes, cst_lstm_seq_xchg_bytes(B));
+    CST_REQUIRE(!hprev0_bf16 == !hprev1_bf16, "%s: pass both bf16 hprev twins or neither", who);
+    // all 4 B / 16 workgroups must be resident together (a workgroup spins on its partner), one per CU: checked against THIS device's CU
+    // count before anything is launched or captured.  Residency beside other kernels (RCCL, forked streams) is the caller's margin.
+    const int cus = sq_device_cus();
+    CST_REQUIRE(cus > 0 && (B / 16) * 4 <= cus, "%s: %d workgroups would not be co-resident on %d CUs", who, (B / 16) * 4, cus);
     LstmSeqArgs a;
     a.dir[0] = LstmSeqDir{(const bf16_t*)whh0, xp0, h0, gates0, cenc0, hprev0, (bf16_t*)hprev0_bf16, c_last, 0};
     a.dir[1] = LstmSeqDir{(const bf16_t*)whh1, xp1, h0 + H, gates1, cenc1, hprev1, (bf16_t*)hprev1_bf16, c_last + H, 1};
     a.mem = mem; a.memb = (bf16_t*)mem_bf16; a.B = B; a.L = L; a.ldw = 0; a.ldh0 = ldh0; a.ldcl = ldcl;
     hipStream_t st = (hipStream_t)stream;
+    // the dynamic-LDS limit is a per-device property of the function: set it on every call (cheap), not once per process
+    if (hipFuncSetAttribute((const void*)lstm_seq_fwd2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SQ2_FWD_LDS) != hipSuccess) {
+        (void)hipGetLastError();
+        cst_set_error("%s: cannot raise the dynamic LDS limit to %d bytes", who, SQ2_FWD_LDS);
+        return CST_ERR_LAUNCH;
+    }
     // every polled word starts at zero in every launch (epochs repeat); the last 16 bytes are the timeout word, which is sticky (zeroed
     // by whoever allocates the workspace, never here: a later launch must not erase an earlier one's report)
     const long bytes = cst_lstm_seq_xchg_bytes(B);
-    if (cst_zero_words(xchg, (bytes - 16) / 4, st) != CST_OK) { cst_set_error("cst_lstm_seq_fwd_split: zero fill failed"); return CST_ERR_LAUNCH; }
-    static bool attr_done = false;
-    if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)lstm_seq_fwd2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SQ2_FWD_LDS);
-        attr_done = true;
-    }
-    // all 4 B / 16 workgroups must be resident together (a workgroup spins on its partner): one per CU, 256 CUs
-    CST_REQUIRE((B / 16) * 4 <= 256, "cst_lstm_seq_fwd_split: %d workgroups would not be co-resident", (B / 16) * 4);
-    hipLaunchKernelGGL(lstm_seq_fwd2_kernel, dim3(B / 16, 2, 2), dim3(256), SQ2_FWD_LDS, st, a,
+    if (cst_zero_words(xchg, (bytes - 16) / 4, st) != CST_OK) { cst_set_error("%s: zero fill failed", who); return CST_ERR_LAUNCH; }
+    hipLaunchKernelGGL(lstm_seq_fwd2_kernel, dim3(B / 16, 2, halves), dim3(256), SQ2_FWD_LDS, st, a,
                        (unsigned long long*)xchg, (unsigned*)((char*)xchg + bytes - 16));
-    CST_LAUNCH_CHECK("cst_lstm_seq_fwd_split");
+    CST_LAUNCH_CHECK(who);
     return CST_OK;
+}
+
+extern "C" int cst_lstm_seq_fwd_split(const void* whh0, const void* whh1, const float* xp0, const float* xp1,
+                                      const float* h0, long ldh0, float* gates0, float* gates1, float* cenc0, float* cenc1,
+                                      float* hprev0, float* hprev1, void* hprev0_bf16, void* hprev1_bf16,
+                                      float* c_last, long ldcl, float* mem, void* mem_bf16,
+                                      int B, int L, int H, void* xchg, long xchg_bytes, void* stream) {
+    return sq_fwd_split_launch("cst_lstm_seq_fwd_split", 2, whh0, whh1, xp0, xp1, h0, ldh0, gates0, gates1, cenc0, cenc1, hprev0, hprev1,
+                               hprev0_bf16, hprev1_bf16, c_last, ldcl, mem, mem_bf16, B, L, H, xchg, xchg_bytes, stream);
+}
+
+// TEST ONLY (tests/test_gpu_ops.py): the same launch with the second half of every workgroup pair missing, i.e. what a lost co-residency
+// looks like -- every first-half workgroup runs into its bounded spin at the first exchange, sets the sticky word and poisons its outputs.
+extern "C" int cst_lstm_seq_fwd_split_lone_half(const void* whh0, const void* whh1, const float* xp0, const float* xp1,
+                                                const float* h0, long ldh0, float* gates0, float* gates1, float* cenc0, float* cenc1,
+                                                float* hprev0, float* hprev1, void* hprev0_bf16, void* hprev1_bf16,
+                                                float* c_last, long ldcl, float* mem, void* mem_bf16,
+                                                int B, int L, int H, void* xchg, long xchg_bytes, void* stream) {
+    return sq_fwd_split_launch("cst_lstm_seq_fwd_split_lone_half", 1, whh0, whh1, xp0, xp1, h0, ldh0, gates0, gates1, cenc0, cenc1, hprev0, hprev1,
+                               hprev0_bf16, hprev1_bf16, c_last, ldcl, mem, mem_bf16, B, L, H, xchg, xchg_bytes, stream);
 }
 
 // =============================================================================================
@@ -604,10 +649,9 @@ extern "C" int cst_lstm_seq_bwd(const void* wt0, const void* wt1, const float* g
     a.dir[0] = LstmSeqBwdDir{(const bf16_t*)wt0, gates0, cenc0, c_last, dc_last, dgates0, (bf16_t*)dgates0_bf16, dh0, 0};
     a.dir[1] = LstmSeqBwdDir{(const bf16_t*)wt1, gates1, cenc1, c_last + H, dc_last + H, dgates1, (bf16_t*)dgates1_bf16, dh0 + H, 1};
     a.dmem = dmem; a.B = B; a.L = L; a.ldcl = ldcl; a.lddcl = lddcl; a.lddh0 = lddh0;
-    static bool attr_done = false;
-    if (!attr_done) {
+    static CstPerDevice attr_done;
+    if (cst_first_on_device(attr_done)) {
         (void)hipFuncSetAttribute((const void*)lstm_seq_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SQ_BWD_LDS);
-        attr_done = true;
     }
     hipLaunchKernelGGL(lstm_seq_bwd_kernel, dim3(B / 16, 2), dim3(256), SQ_BWD_LDS, (hipStream_t)stream, a);
     CST_LAUNCH_CHECK("cst_lstm_seq_bwd");

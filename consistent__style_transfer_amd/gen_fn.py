@@ -77,22 +77,64 @@ def _cell_bwd(gates, c_prev, c_new, dh, dh2, dc, dgates, dc_prev, B, H, dgb=None
 
 
 _XCHG = {}
+_SPLIT = {"disabled": False, "why": None}
+
+
+def disable_split(why):
+    """Use the one-workgroup encoder kernel (cst_lstm_seq_fwd) for the rest of the process: called when the split kernel's workgroups
+    were ever not resident together (Trainer's probe, bench.py's probe)."""
+    _SPLIT["disabled"], _SPLIT["why"] = True, why
+
+
+def split_enabled(B, dev=None):
+    """May the encoder forward of batch B run as cst_lstm_seq_fwd_split (two workgroups per row group exchanging h_t inside the launch)?
+    Its 4 B / 16 workgroups need a whole CU each and must be resident TOGETHER, so: never after a timeout was seen in this process;
+    never beyond the device's CU count (asked from the library: hipDeviceAttributeMultiprocessorCount); and with other ranks' collectives
+    possibly resident on the same device (world > 1: RCCL kernels hold CUs while a stage's all-reduces run), only up to half of the
+    CUs.  CST_LSTM_SPLIT=0 switches it off by hand."""
+    if _SPLIT["disabled"] or os.environ.get("CST_LSTM_SPLIT", "1") == "0":
+        return False
+    cap = call_plain("cst_lstm_seq_split_capacity")
+    if torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
+        cap //= 2
+    return 0 < call_plain("cst_lstm_seq_split_workgroups", B) <= cap
+
+
+def _xchg_key(dev, B, sid):
+    return (dev.index if dev.index is not None else torch.cuda.current_device(), B, sid)
+
+
+def _xchg_alloc(key, dev):
+    nb = call_plain("cst_lstm_seq_xchg_bytes", key[1])
+    ws = _XCHG[key] = torch.empty(nb, device=dev, dtype=torch.uint8)
+    call("cst_zero", ws, nb)
+    return ws
 
 
 def _xchg_workspace(dev, B):
     """Exchange workspace of cst_lstm_seq_fwd_split for batch B on `dev`: one persistent buffer per (device, B, stream) -- launches on a stream
     are ordered and the entry point zeroes it in front of each.  Its last 16 bytes are the timeout word check_exchange_timeouts() reads."""
     # one buffer per (device, B, stream): launches on ONE stream are ordered, two eager streams (stages.Fork) must not share granules.  A
-    # capture uses the default stream's buffer (created by the eager pass in front of every capture): a buffer created INSIDE a capture
-    # would have its zero fill -- sticky timeout word included -- replayed with the graph.
-    sid = 0 if torch.cuda.is_current_stream_capturing() else int(torch.cuda.current_stream(dev).cuda_stream)
-    key = (dev.index if dev.index is not None else torch.cuda.current_device(), B, sid)
+    # capture uses the (device, B, 0) buffer, which must exist BEFORE the capture begins (reserve_capture_workspaces, called by
+    # graphs.GraphedStep after its eager pass): a buffer created INSIDE a capture would have its zero fill -- sticky timeout word
+    # included -- replayed with the graph, erasing earlier reports, and would live in the graph's private pool.
+    if torch.cuda.is_current_stream_capturing():
+        ws = _XCHG.get(_xchg_key(dev, B, 0))
+        if ws is None:
+            raise RuntimeError(f"cst_lstm_seq_fwd_split: no exchange workspace for batch {B} was reserved before this capture "
+                               "(gen_fn.reserve_capture_workspaces() after one eager pass of the step)")
+        return ws
+    key = _xchg_key(dev, B, int(torch.cuda.current_stream(dev).cuda_stream))
     ws = _XCHG.get(key)
-    if ws is None:
-        nb = call_plain("cst_lstm_seq_xchg_bytes", B)
-        ws = _XCHG[key] = torch.empty(nb, device=dev, dtype=torch.uint8)
-        call("cst_zero", ws, nb)                              # a kernel, not a memset node: the first use may be inside a capture
-    return ws
+    return ws if ws is not None else _xchg_alloc(key, dev)
+
+
+def reserve_capture_workspaces():
+    """Outside any capture: make sure every (device, batch) the eager passes have used also has the buffer captured launches take."""
+    assert not torch.cuda.is_current_stream_capturing()
+    for (idx, B, sid), ws in list(_XCHG.items()):
+        if sid != 0 and (idx, B, 0) not in _XCHG:
+            _xchg_alloc((idx, B, 0), ws.device)
 
 
 def exchange_timed_out(clear=False):
@@ -105,10 +147,29 @@ def exchange_timed_out(clear=False):
 
 
 def check_exchange_timeouts():
-    """Raise if a workgroup of the split encoder kernel ever gave up waiting for its partner (its results were then computed from stale
-    hidden states).  Reads the device: call at synchronisation points only (validation, end of a run, the end of bench.py)."""
-    for idx, B in exchange_timed_out():
-        raise RuntimeError(f"cst_lstm_seq_fwd_split (device {idx}, batch {B}): a workgroup timed out waiting for its partner's hidden states")
+    """Raise if a workgroup of the split encoder kernel ever gave up waiting for its partner (the kernel then poisoned that row group's
+    encoder states with NaN, so the step's loss is NaN as well).  Reads the device: call at synchronisation points only (every loss
+    readback, validation, the end of the transfer writer, the end of bench.py).  The split kernel is switched off for the rest of
+    the process before raising, so a caller that catches the error continues on the one-workgroup kernel."""
+    bad = exchange_timed_out()
+    if bad:
+        idx, B = bad[0]
+        disable_split(f"timeout on device {idx}, batch {B}")
+        raise RuntimeError(f"cst_lstm_seq_fwd_split (device {idx}, batch {B}): a workgroup timed out waiting for its partner's hidden states "
+                           "(its encoder states were set to NaN); the split kernel is now disabled in this process")
+
+
+def probe_split():
+    """After ONE eager pass through the generator (a sanity validation, a first step): if a workgroup of the split kernel gave up, clear
+    the report, fall back to the one-workgroup kernel for the rest of the process and say so.  -> True when the split kernel stays on."""
+    bad = exchange_timed_out(clear=True)
+    if bad:
+        disable_split(f"probe: timeout on (device, batch) {bad}")
+        import sys
+        print(f"[cst] cst_lstm_seq_fwd_split timed out in the probe pass {bad}: using cst_lstm_seq_fwd (one workgroup per row group) "
+              "for the rest of this process", file=sys.stderr, flush=True)
+        return False
+    return True
 
 
 def _lstm_frag_order(wb, H):
@@ -202,11 +263,12 @@ class GeneratorFn(torch.autograd.Function):
             order = list(range(Lp)) if d == 0 else list(range(Lp - 1, -1, -1))
             enc.append((w_hh, weight_bf16(w_hh)[0] if use_b else None, xp, order, hprev[d].view(B, Lp * H)))
         if seq_fused:
-            # both directions, all L' steps, one launch: 16 batch rows per workgroup, no inter-workgroup dependencies
+            # both directions, all L' steps, one launch: 16 batch rows per workgroup (cst_lstm_seq_fwd: no inter-workgroup dependencies;
+            # cst_lstm_seq_fwd_split: two workgroups per row group that exchange their halves of h_t every step)
             (_, wb0, xp0, _, _), (_, wb1, xp1, _, _) = enc
             seq_args = (_lstm_frag_order(wb0, H), _lstm_frag_order(wb1, H), xp0, xp1, h0cat, 2 * H, genc[0], genc[1], cenc[0], cenc[1],
                         hprev[0], hprev[1], hprevb[0] if enc_b else None, hprevb[1] if enc_b else None, c_cat, 2 * H, memory, memb, B, Lp, H)
-            if (B // 16) * 4 <= 256 and os.environ.get("CST_LSTM_SPLIT", "1") != "0":
+            if split_enabled(B, dev):
                 # two workgroups per row group, W_hh resident on chip, one 4 KB exchange of h_t per step (lstm_seq.hip)
                 xchg = _xchg_workspace(dev, B)
                 call("cst_lstm_seq_fwd_split", *seq_args, xchg, xchg.numel())
@@ -420,6 +482,12 @@ class GeneratorFn(torch.autograd.Function):
             else:
                 dgrad(dout.view(B * T, V), P["fn_2.weight"], out=dpre1.view(B * T, Hd), aux=r1.view(B * T, Hd), act=4)
                 dgrad(dpre1.view(B * T, Hd), P["fn_1.weight"], out=diffn_all.view(B * T, W_))
+                if ifdb is not None and (B * T) % 64 == 0 and E % 8 == 0 and Hd % 64 == 0:
+                    # dout came without bf16 dlogits (any loss other than token_ce(unit_grad=True)): the fn_1 weight gradient below must
+                    # still take the bf16 dropout(i_ffn) the forward wrote -- the fast decode loop writes NO fp32 copy of it (iffn_d is
+                    # then an unwritten buffer when drop.p > 0) -- so give it the bf16 twin of d(fn_1 pre-activation) here
+                    dp1b_all = cast_bf16(dpre1.view(B * T, Hd), want_t=False)[0].view(B, T * Hd)
+                    dp1b_ok = True
         dXH_all = _new(dev, T, B, E + Hd)              # step s writes [d x_s | d h_{s-1}] into slice s
         etok_b = weight_bf16(E_tok)[0] if (soft and use_b) else None
         dxe_all = _new(dev, max(T - 1, 1), B, E) if (soft and drop.p > 0) else None
@@ -531,6 +599,7 @@ class GeneratorFn(torch.autograd.Function):
         if tt_ok and dp1b_ok and ifdb is not None:
             G["fn_1.weight"] = ops.gemm_bf16_tt(dp1b_all.view(B * T, Hd), ifdb.view(B * T, W_), Hd, W_)
         else:
+            # (fp32 dropout(i_ffn): written by the per-step decode loop only -- every configuration the fast loop accepts takes the branch above)
             G["fn_1.weight"] = wgrad(dp1, iffn_d.view(B * T, W_))
         G["fn_1.bias"] = colsum(dp1)
         dg2 = dgd.view(T * B, 4 * Hd)

@@ -50,6 +50,8 @@ class GraphedStep:
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
         ops.capture_scope_reset()
+        from . import gen_fn
+        gen_fn.reserve_capture_workspaces()               # the split encoder kernel's exchange buffers: never created inside a capture
         self.graphs, self.points = [], []
         self.record = CaptureRecord()
         for grp in list(FlatGroup._live):                 # pointer tables for every gather the capture will record

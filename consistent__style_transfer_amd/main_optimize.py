@@ -12,7 +12,7 @@ import os
 
 import torch
 
-from . import ops
+from . import gen_fn, ops
 from .arguments import apply_model_constants, fetch_args
 from .loader import StyleDataset, collate_optimize, load_s2l
 from .stages import OptimizeStage
@@ -87,6 +87,12 @@ class OptimizeAdapter(OptimizeStage):
                 lo = rank * per
                 xs, ls = x[lo:lo + per].to(trainer.device), labels[lo:lo + per].to(trainer.device)
                 ids = self.transfer((xs, ls)).cpu().tolist()
+                # .cpu() synchronised: the split encoder kernel's sticky timeout word can be read.  The first batch doubles as the
+                # residency probe (fall back to the one-workgroup kernel and decode it again); after that a timeout is an error --
+                # the kernel poisoned the row group with NaN, and no .tsf line may be written from it
+                if s == 0 and not gen_fn.probe_split():
+                    ids = self.transfer((xs, ls)).cpu().tolist()
+                gen_fn.check_exchange_timeouts()
                 for j, (tsf, label) in enumerate(zip(ids, ls.tolist())):
                     if lo + j < real:
                         fp.write(f"{idx[lo + j]}\t{label}\t{self.vocab.decode(tsf)}\n")

@@ -135,11 +135,16 @@ class Trainer:
                         break
                     outs.append(stage.validation_step(self, self.put(batch)))
             stage.train()
-            from .gen_fn import check_exchange_timeouts
-            check_exchange_timeouts()                                       # a synchronisation point anyway (validation_step reads losses)
-            return stage.validation_end(self, outs)
+            return outs
 
-        validate(limit=self.sanity_batches)                     # sanity check, side effects included
+        from . import gen_fn
+        outs = validate(limit=self.sanity_batches)              # sanity check, side effects included (validation_end below)
+        if not gen_fn.probe_split():
+            # the sanity pass is also the split encoder kernel's residency probe (eager, before anything is captured): a workgroup that gave
+            # up poisoned its rows with NaN, so the pass is repeated on the one-workgroup kernel before its side effects (checkpoints) fire
+            outs = validate(limit=self.sanity_batches)
+        gen_fn.check_exchange_timeouts()
+        stage.validation_end(self, outs)
         t_last, n_last = time.time(), 0
         done = False
         workers = int(getattr(args, "prefetch_workers", 0) or 0)
@@ -153,6 +158,7 @@ class Trainer:
                 self.global_step += 1
                 if self.global_step % 10 == 0:
                     vals = {k: _to_float(v) for k, v in scalars.items() if v is not None}
+                    gen_fn.check_exchange_timeouts()             # the readback above synchronised: a timed-out (NaN) step stops here
                     now = time.time()
                     vals["sentences_per_sec"] = n_last / max(now - t_last, 1e-9)
                     t_last, n_last = now, 0
@@ -164,7 +170,9 @@ class Trainer:
                     break
             if self.world > 1:
                 check_replicas(stage.replicated_tensors(), f"end of epoch {epoch}")
-            val_loss = validate(limit=args.val_batches)
+            outs = validate(limit=args.val_batches)
+            gen_fn.check_exchange_timeouts()                     # before validation_end saves a checkpoint
+            val_loss = stage.validation_end(self, outs)
             self.logger.log(self.global_step, {"val_loss": val_loss, "epoch": epoch})
             if self.rank == 0:
                 print(f"epoch {epoch}: val_loss {val_loss:.6f}", flush=True)

@@ -284,6 +284,20 @@ int cst_lstm_seq_fwd_split(const void* whh0, const void* whh1, const float* xp0,
                            float* hprev0, float* hprev1, void* hprev0_bf16, void* hprev1_bf16,
                            float* c_last, long ldcl, float* mem, void* mem_bf16,
                            int B, int L, int H, void* xchg, long xchg_bytes, void* stream);
+/* Residency of the split kernel: workgroups it launches for batch B (one whole CU each: 136 KB of LDS, 512 registers a lane) and the CU
+ * count of the current device.  cst_lstm_seq_fwd_split refuses (status 1, before anything is launched or captured) when the first exceeds
+ * the second; the caller keeps a margin beside other resident kernels (gen_fn.split_enabled).  On a timeout the kernel sets the sticky
+ * word AND writes NaN into the partner's half of h_t, so every later gate, encoder state and c_last of that row group is NaN: the loss
+ * of the same step is NaN, never a number computed from stale hidden states (rnn.py:62's encoder has no such failure mode to mirror). */
+int cst_lstm_seq_split_workgroups(int B);
+int cst_lstm_seq_split_capacity(void);
+/* TEST ONLY: cst_lstm_seq_fwd_split with the second workgroup of every pair missing -- what lost co-residency looks like.  Every launched
+ * workgroup times out at its first exchange (bounded spin, ~0.2 s), sets the sticky word and poisons its outputs with NaN. */
+int cst_lstm_seq_fwd_split_lone_half(const void* whh0, const void* whh1, const float* xp0, const float* xp1,
+                                     const float* h0, long ldh0, float* gates0, float* gates1, float* cenc0, float* cenc1,
+                                     float* hprev0, float* hprev1, void* hprev0_bf16, void* hprev1_bf16,
+                                     float* c_last, long ldcl, float* mem, void* mem_bf16,
+                                     int B, int L, int H, void* xchg, long xchg_bytes, void* stream);
 /* Backward of cst_lstm_seq_fwd, also one launch: per step the cell backward in registers and dh_{prev} = dgates W_hh on
  * the bf16 matrix pipe.  wt{0,1}: W_hh^T in bf16 fragment order [wave 4][k step 32][tile 4][lane 64][8] (element
  * [w][kk][j][16*lq + lr][e] = W_hh[32kk + 8lq + e][64w + 16j + lr]); gates / cenc / c_last as the forward wrote them;

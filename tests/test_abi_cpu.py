@@ -8,6 +8,8 @@ import pytest
 
 from consistent__style_transfer_amd import _lib
 
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
 
 def test_header_symbols_exported():
     protos = _lib.parse_header()
@@ -133,3 +135,19 @@ def test_decode_entry_points_validate_their_limits():
         and "D == 512" in L.last_error()
     assert L.fn["cst_dec_attn_dmem"](P, 1024, 1024, P, 1024, 1024, P, P, P, 4, 21, 80, 512, None) == 1 and "L <= 64" in L.last_error()
     assert L.fn["cst_sumsq_partials"](None, 4, P, None) == 1 and "bad arguments" in L.last_error()
+
+
+def test_bench_gpus_n_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with WORLD_SIZE unset must start the ranks itself (child processes of
+    torch.distributed.run, before the parent touches the GPU), relay their output and leave with their status.  Here (no GPU) the
+    children stop at bench.py's own "needs a GPU" assertion: what is checked is the launch, the relay and the status."""
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["CUDA_VISIBLE_DEVICES"] = env["HIP_VISIBLE_DEVICES"] = ""
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--no-cpu-baseline"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert "launching 2 ranks" in r.stderr and "torch.distributed.run" in r.stderr, r.stderr[-2000:]
+    assert "--nproc-per-node=2" in r.stderr
+    assert r.returncode != 0                                  # the children's failure (no GPU here) is the parent's status
+    assert "bench.py needs a GPU" in r.stderr or "WORLD_SIZE=2" in r.stderr or "ChildFailedError" in r.stderr, r.stderr[-2000:]

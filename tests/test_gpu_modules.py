@@ -344,3 +344,35 @@ def test_generator_bf16_path_matches_f32_path(cst):
     for k in gf:
         nf, nb = np.linalg.norm(gf[k]), np.linalg.norm(gb[k] - gf[k])
         assert nb <= 1e-1 * max(nf, 1e-6), (k, nb, nf)      # bf16 rounding compounds through fn_2, fn_1, the cell and transfer
+
+
+def test_generator_generic_loss_fast_decode_equals_per_step_decode(cst, monkeypatch):
+    """ADVICE r3 (gen_fn.py): a hard, teacher-forced decode in TRAIN mode (dropout on) under a loss that is NOT token_ce(unit_grad=True) --
+    here sum(logits * w) -- reaches the backward without bf16 dlogits.  The fast decode loop writes only the bf16 dropout(i_ffn), so
+    the fn_1 weight gradient must be taken from that copy; it used to read an unwritten fp32 buffer.  Every parameter gradient of the
+    fast loop must equal the per-step loop's (CST_DECODE_SLOW=1: same masks, same products up to bf16 rounding of the operands)."""
+    pkg, model, ops = cst
+    name = "b16"
+    c, G = CONFIGS[name], load_golden("modules", name)
+    x, nx, labels = torch.from_numpy(G["x"]).cuda(), torch.from_numpy(G["nx"]).cuda(), torch.from_numpy(G["labels"]).cuda()
+    coins = [1, 0] * (x.shape[1] // 2) + [1] * (x.shape[1] % 2)
+    ops.set_precision("bf16")
+    res = {}
+    for slow in ("0", "1"):
+        monkeypatch.setenv("CST_DECODE_SLOW", slow)
+        m = build(model, name, "G")
+        m.train()
+        y = m(nx, labels, x, labels, coins=coins, seed=977)
+        w = torch.from_numpy(np.random.RandomState(5).standard_normal(tuple(y.shape)).astype(np.float32)).cuda()
+        m.zero_grad()
+        (y * w).sum().backward()
+        res[slow] = (y.detach().float().cpu().numpy(), {k: p.grad.detach().float().cpu().numpy() for k, p in m.named_parameters() if p.grad is not None})
+    (yf, gf), (ys, gs) = res["0"], res["1"]
+    assert np.isfinite(yf).all() and rel_l2(yf, ys) < 2e-2
+    worst = {}
+    for k in gs:
+        assert np.isfinite(gf[k]).all(), k
+        worst[k] = float(np.linalg.norm(gf[k] - gs[k]) / max(np.linalg.norm(gs[k]), 1e-12))
+    report("gen.generic_loss.fast_vs_slow", config=name, mode="bf16", **worst)
+    assert worst["fn_1.weight"] < 5e-2, worst
+    assert max(worst.values()) < 0.1, worst

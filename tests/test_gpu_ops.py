@@ -1018,6 +1018,57 @@ def test_lstm_seq_fwd_equals_per_step_path(ops):
     close(f["memb"].view(torch.bfloat16).float(), r["memb"].view(torch.bfloat16).float(), 2e-2, 2e-2)
 
 
+def test_lstm_seq_split_timeout_poisons_reports_and_falls_back(ops):
+    """what happens when the split encoder kernel's workgroup pairs are NOT resident together.  The test-only entry
+    point launches the first half of every pair alone: every workgroup runs into its bounded spin at the first exchange (~0.2 s), and must
+    (a) set the sticky timeout word, (b) leave NaN -- not numbers computed from stale hidden states -- in every later encoder state and in
+    c_last, (c) make gen_fn.check_exchange_timeouts() raise and switch the process to the one-workgroup kernel, (d) leave a workspace
+    that the next (healthy) launch can use after the word is cleared."""
+    from consistent__style_transfer_amd import gen_fn
+    from consistent__style_transfer_amd._lib import call, call_plain
+    B, L, H = 16, 2, 256                                     # one row group, ONE exchange (the last step has none)
+    whh = [dev(rnd(4 * H, H, seed=1 + d, scale=0.08)) for d in range(2)]
+    wb = [ops.cast_bf16(w, want_t=False)[0] for w in whh]
+    xp = [dev(rnd(B, L * 4 * H, seed=3 + d, scale=0.5)) for d in range(2)]
+    h0 = dev(rnd(B, 2 * H, seed=5, scale=0.5))
+    assert call_plain("cst_lstm_seq_split_workgroups", B) == 4
+    assert call_plain("cst_lstm_seq_split_capacity") == torch.cuda.get_device_properties(0).multi_processor_count
+
+    def run(entry, xchg):
+        b = dict(genc=torch.zeros(2, L, B, 4 * H, device="cuda"), cenc=torch.zeros(2, L, B, H, device="cuda"),
+                 hprev=torch.zeros(2, B, L, H, device="cuda"), c_cat=torch.zeros(B, 2 * H, device="cuda"),
+                 mem=torch.zeros(B, L, 2 * H, device="cuda"), memb=torch.zeros(B, L * 2 * H, device="cuda", dtype=torch.int16))
+        call(entry, gen_fn._lstm_frag_order(wb[0], H), gen_fn._lstm_frag_order(wb[1], H), xp[0], xp[1], h0, 2 * H, b["genc"][0], b["genc"][1],
+             b["cenc"][0], b["cenc"][1], b["hprev"][0], b["hprev"][1], None, None, b["c_cat"], 2 * H, b["mem"], b["memb"], B, L, H, xchg, xchg.numel())
+        torch.cuda.synchronize()
+        return b
+
+    saved = dict(gen_fn._XCHG), dict(gen_fn._SPLIT)
+    try:
+        gen_fn._XCHG.clear()
+        xchg = gen_fn._xchg_workspace(torch.device("cuda", 0), B)         # registered: exchange_timed_out() reads its last word
+        bad = run("cst_lstm_seq_fwd_split_lone_half", xchg)
+        assert int(xchg[-16:].view(torch.int32)[0].item()) == 1
+        # half p = 0 owns hidden units 0..127 of each direction; its second (= last) step ran on a NaN partner half
+        for d, t_last in ((0, L - 1), (1, 0)):
+            assert torch.isnan(bad["mem"][:, t_last, d * H:d * H + 128]).all(), "stale numbers instead of NaN in the encoder states"
+            assert torch.isnan(bad["c_cat"][:, d * H:d * H + 128]).all(), "stale numbers instead of NaN in c_last"
+        assert gen_fn.split_enabled(B)
+        with pytest.raises(RuntimeError, match="timed out"):
+            gen_fn.check_exchange_timeouts()
+        assert not gen_fn.split_enabled(B), "a timeout must switch the process to cst_lstm_seq_fwd"
+        # probe form: clears the word and reports instead of raising
+        gen_fn._SPLIT.update(disabled=False, why=None)
+        assert gen_fn.probe_split() is False and not gen_fn.split_enabled(B)
+        assert int(xchg[-16:].view(torch.int32)[0].item()) == 0
+        good = run("cst_lstm_seq_fwd_split", xchg)
+        assert int(xchg[-16:].view(torch.int32)[0].item()) == 0
+        assert torch.isfinite(good["mem"]).all() and torch.isfinite(good["c_cat"]).all()
+    finally:
+        gen_fn._XCHG.clear(); gen_fn._XCHG.update(saved[0])
+        gen_fn._SPLIT.clear(); gen_fn._SPLIT.update(saved[1])
+
+
 def test_lstm_seq_bwd_equals_per_step_path(ops):
     """The one-launch BiLSTM encoder backward against the per-step cell backward + dh GEMM launches it replaces."""
     from consistent__style_transfer_amd import gen_fn
