@@ -10,7 +10,7 @@ import sys
 
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB = os.path.join(CSRC, "libcst_hip.so")
-SOURCES = ["common.hip", "gemm.hip", "gemm_bf16.hip", "rowwise.hip", "attention.hip", "attention_long.hip", "pointwise.hip", "relconv.hip", "lstm_seq.hip", "decode.hip"]
+SOURCES = ["common.hip", "gemm.hip", "gemm_bf16.hip", "gemm_pp.hip", "rowwise.hip", "attention.hip", "attention_long.hip", "pointwise.hip", "relconv.hip", "lstm_seq.hip", "decode.hip"]
 ARCH = "gfx950"
 
 
@@ -52,22 +52,30 @@ def build_lib(force=False, verbose=True):
     hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
     objs = []
     bench = os.environ.get("CST_BENCH_VARIANTS") == "1"
+    # the two flavours never share an object file (-DCST_BENCH_VARIANTS changes what gemm_bf16 / gemm_pp hold), and the library records
+    # which flavour it was linked from: switching the flavour relinks even when every object is up to date
+    suffix = ".bench.o" if bench else ".o"
+    stamp = os.path.join(CSRC, ".lib_flavour")
+    flavour = "bench" if bench else "ship"
     for s in SOURCES + (BENCH_SOURCES if bench else []):
         src = os.path.join(CSRC, s)
-        obj = os.path.join(CSRC, s.replace(".hip", ".o"))
+        obj = os.path.join(CSRC, s.replace(".hip", suffix))
         objs.append(obj)
         if force or _stale(obj, [src] + hdrs):
             cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-fPIC", "-std=c++17", "-c", src, "-o", obj]
-            if bench:                                                # bench-only GEMM variants + timing ablations (gemm_bf16.hip)
+            if bench:                                                # bench-only GEMM variants + timing ablations (gemm_bf16.hip, gemm_pp.hip)
                 cmd.insert(-4, "-DCST_BENCH_VARIANTS")
             if verbose:
                 print(" ".join(cmd), flush=True)
             subprocess.check_call(cmd)
-    if force or _stale(LIB, objs):
+    have = open(stamp).read().strip() if os.path.exists(stamp) else None
+    if force or have != flavour or _stale(LIB, objs):
         cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB] + objs
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)
+        with open(stamp, "w") as f:
+            f.write(flavour + "\n")
     return LIB
 
 

@@ -22,12 +22,12 @@
 // Reference call sites served: the packed in_proj / out_proj / linear1 / linear2 products of
 // nn.TransformerEncoderLayer (mlm.py:20-22, match.py:18-20), forward, dgrad and wgrad.
 #include "cst_common.h"
+#include "bgemm.h"
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef __attribute__((address_space(1))) const void* gbl_ptr_t;
-typedef unsigned short bf16_t;
 
 __device__ __forceinline__ bf16_t f2bf16(float f) {
     __bf16 b = (__bf16)f;
@@ -176,25 +176,6 @@ extern "C" int cst_colsum_bf16(const void* X, long ld, int M, int N, float* out,
 // =============================================================================================
 // GEMM
 // =============================================================================================
-struct BGemmArgs {
-    const bf16_t* A; const bf16_t* B;
-    const bf16_t* A2; const bf16_t* B2;   // second independent problem of the same shape (gridDim.z == 2; slab output only)
-    float* C; bf16_t* Cb;           // either or both
-    const float* bias; const float* addend; const bf16_t* aux;
-    const float* bscale;            // per-output-column scale (fp8 B operand: B[n][k] = fp8[n][k] * bscale[n]); null = none
-    long lda, ldb, ldc, ldcb, ldadd, ldaux;
-    int M, N, K;                    // K multiple of 64
-    int act;                        // 0 none, 1 relu, 2 leaky(0.1), 3 aux>0 ? v*gate_scale : 0, 4 aux>0 ? v : 0.1 v
-    int accumulate;                 // C += v (fp32 output only)
-    float alpha, gate_scale;
-    CstDrop drop;
-    int splits, k_per_split;        // k_per_split multiple of 64
-    int slab_only;                  // write the raw partial product(s) to the slab even when splits == 1
-    float* slab;
-    unsigned long long* amax;       // optional [AMAX_GROUPS][M]: packed arg-max words of every output row, folded in with 64-bit atomic max (cst_gemm_bf16_argmax)
-    int gn;                         // tile columns per XCD strip (0: the default, 8)
-    int abl;                        // timing ablations (CST_GB_ABL, tools/gemm_bench.py abl): 1 no DMA, 2 no MFMA, 4 no fragment reads, 8 no write-out
-};
 
 // Bench-only code (tools/gemm_bench.py): the timing ablations and the kernel variants that were measured and never dispatch (256-wide
 // tiles, the loader / consumer kernel, 3- and 4-stage rings) are compiled only with -DCST_BENCH_VARIANTS (CST_BENCH_VARIANTS=1 python -m
@@ -787,9 +768,6 @@ __global__ __launch_bounds__(256) void cst_gemm_bf16_reduce(BGemmArgs g) {
 
 // kernel-precise timing shared with gemm.hip (cst_gemm_profile_enable / _read)
 #include <hip/hip_ext.h>
-extern bool cst_prof_on();
-extern void cst_prof_push(hipEvent_t a, hipEvent_t b, double flops, double bytes, int which);
-extern void cst_prof_push_shape(hipEvent_t a, hipEvent_t b, double flops, double bytes, int which, int m, int n, int k);
 
 #ifdef CST_BENCH_VARIANTS
 // =============================================================================================
@@ -1421,6 +1399,32 @@ static int bgemm_entry(const void* A, long lda, const void* B, long ldb,
     // tile / ring / split choice (tools/gemm_bench.py bf16nt): the 2-stage ring with two workgroups per
     // CU beats the 3-stage one at these sizes; 64x128 tiles when they alone give >= 256 workgroups,
     // 128x128 + split-K for long-K products with few output tiles (wgrad), 64x128 (+split) otherwise.
+    // round 4 (gemm_pp.hip): the big-tile ping-pong kernel takes the large whole-K products (the encoder-layer forward and dgrad products)
+    // unless a tile code asks for the tile kernels (64, 128, 136, 999 = "never").  Tile code 1000 + cfg forces one of its builds.  Which
+    // build -- or the tile kernels below after all -- runs a shape is measured on the shape's first eager call: the tile kernels enter
+    // that comparison through `again`, this same entry point with tile code 999.
+    {
+        int pp_force = 0;
+        if (tile >= 1000) { pp_force = tile - 1000; tile = 0; }
+        else if (tile != 0) pp_force = -1;
+        if (tile == 999) tile = 0;
+        if (pp_force >= 0 && splitk <= 1 && !amax) {
+            struct Again {
+                const void* A; long lda; const void* B; long ldb; float* C; long ldc; void* Cb; long ldcb; int M, N, K;
+                const float* bias; const float* addend; long ldadd; const void* aux; long ldaux; int act; float gate_scale, alpha; int accumulate;
+                float drop_p; uint32_t drop_seed, drop_stream; const void* drop_seed_dev; float* workspace; long workspace_floats; void* stream;
+                static int run(void* p) {
+                    const Again& a = *static_cast<const Again*>(p);
+                    return bgemm_entry(a.A, a.lda, a.B, a.ldb, a.C, a.ldc, a.Cb, a.ldcb, a.M, a.N, a.K, a.bias, a.addend, a.ldadd, a.aux, a.ldaux, a.act, a.gate_scale,
+                                       a.alpha, a.accumulate, a.drop_p, a.drop_seed, a.drop_stream, a.drop_seed_dev, 999, 0, a.workspace, a.workspace_floats, a.stream, nullptr);
+                }
+            } again{A, lda, B, ldb, C, ldc, Cb, ldcb, M, N, K, bias, addend, ldadd, aux, ldaux, act, gate_scale, alpha, accumulate,
+                    drop_p, drop_seed, drop_stream, drop_seed_dev, workspace, workspace_floats, stream};
+            g.splits = 1; g.k_per_split = K; g.slab = nullptr;
+            const int rc = bgemm_pp_try(g, pp_force, (hipStream_t)stream, splitk == 0 ? &Again::run : nullptr, &again);
+            if (rc > 0) { CST_LAUNCH_CHECK("cst_gemm_bf16 (ping-pong kernel)"); return CST_OK; }
+        }
+    }
     int ring = tile & 3;                         // tile code + 1 / + 2: force the 3- / 4-stage ring
     tile &= ~3;
     // 128 x 128 tiles run on 8 waves (sixteen DMA-issuing waves per CU) unless the 4-wave form is asked for: 0.15 ms per step at the

@@ -93,6 +93,12 @@ int cst_gemm_bf16(const void* A, long lda, const void* B, long ldb,
                   int tile, int splitk, float* workspace, long workspace_floats, void* stream);
 /* The same query for cst_gemm_bf16 (and cst_gemm_bf16_w8: pass tile = 64). */
 long cst_gemm_bf16_workspace_floats(int M, int N, int K, int tile, int splitk);
+/* Round 4: which kernel cst_gemm_bf16 (tile = 0, no split asked for) runs a product of this shape on.  100 TM + TN > 0: the big-tile
+ * ping-pong kernel of csrc/gemm_pp.hip with workgroup tiles of (32 TM) x (64 TN) -- eight waves in two groups half a phase apart, one
+ * persistent workgroup per CU, the tile shape chosen so that the tile count fills whole rounds of the CUs; 0: the LDS-DMA tile kernels
+ * (64 x 128 / 128 x 128, split-K through the workspace).  Tile code 1000 + 100 TM + TN forces a wave tile, any other non-zero tile code
+ * (64, 128, 136, 999) keeps the product on the tile kernels.  Same results up to fp32 summation order (one K order per output element). */
+int cst_gemm_bf16_pp_config(int M, int N, int K);
 /* out[r, 0..ldo) = bf16(x[r,:] * dropmask) zero-padded, out_t[c, 0..ldot) = the transpose zero-padded
  * (either may be null); x is fp32, or bf16 when x_is_bf16 (pure transpose). */
 int cst_cast_bf16(const void* x, int x_is_bf16, long ldx, int R, int C,

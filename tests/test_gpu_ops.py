@@ -160,6 +160,87 @@ def test_gemm_bf16_256_tile(ops, shape, tile):
     assert torch.equal(C.cpu(), ref)
 
 
+# ------------------------------------------------------------------------------------------ big-tile ping-pong GEMM (csrc/gemm_pp.hip)
+def _pp_code(tm, tn, occ2=False, one_tile=False):
+    return 1000 + 100 * tm + tn + (10000 if occ2 else 0) + (20000 if one_tile else 0)
+
+
+def _bfview(x):
+    return x.view(torch.bfloat16).float()
+
+
+PP_BUILDS = [(8, 4, False, False), (7, 3, False, False), (5, 4, False, False), (5, 3, False, True), (6, 2, False, False), (4, 4, False, False),
+             (4, 3, True, False), (6, 2, True, True), (5, 2, True, True), (4, 2, True, False), (3, 3, True, True)]
+
+
+@pytest.mark.parametrize("shape", [(1280, 1024, 256), (1000, 520, 192), (3000, 1028, 320), (2304, 768, 768)])
+def test_gemm_pp_every_build_equals_the_tile_kernels_bit_for_bit(ops, shape):
+    """Round 4: every build of the ping-pong kernel (wave tile, one or two workgroups per CU, persistent or one tile per workgroup) against an
+    fp32 product of the same bf16-rounded operands AND against the LDS-DMA tile kernels (tile code 999).  All of them sum a dot product in the
+    same order -- K-tiles in sequence, two v_mfma_f32_16x16x32_bf16 per K-tile -- so the fp32 outputs must be IDENTICAL: which build the
+    measured choice picks can never change a result.  Ragged rows and columns, several tiles per workgroup, 3 to 12 K-tiles."""
+    M, N, K = shape
+    A, B = dev(rnd(M, K, seed=1)), dev(rnd(N, K, seed=2))
+    Ab, Bb = ops.cast_bf16(A, want_t=False)[0], ops.cast_bf16(B, want_t=False)[0]
+    ref = _bfview(Ab)[:, :K] @ _bfview(Bb)[:, :K].t()
+    base = torch.full((M, N), float("nan"), device="cuda")
+    ops.gemm_bf16(Ab, Bb, M, N, C=base, tile=999)
+    assert float((base - ref).abs().max()) < 2e-5 * float(ref.abs().max())
+    Np = (N + 63) // 64 * 64
+    for tm, tn, occ2, one in PP_BUILDS:
+        C = torch.full((M, N), float("nan"), device="cuda")
+        Cb = torch.full((M, Np), 0x7FC0, device="cuda", dtype=torch.int16)
+        ops.gemm_bf16(Ab, Bb, M, N, C=C, tile=_pp_code(tm, tn, occ2, one))
+        ops.gemm_bf16(Ab, Bb, M, N, Cb=Cb, tile=_pp_code(tm, tn, occ2, one))
+        assert torch.equal(C, base), (shape, tm, tn, occ2, one, float((C - base).abs().max()))
+        assert torch.equal(_bfview(Cb)[:, :N], base.to(torch.bfloat16).float()), (shape, tm, tn, occ2, one, "bf16 output")
+        if Np != N:
+            assert bool((Cb[:, N:] == 0x7FC0).all()), "columns beyond N were written"
+    auto = torch.full((M, N), float("nan"), device="cuda")
+    ops.gemm_bf16(Ab, Bb, M, N, C=auto)                       # the entry point's own (measured) choice
+    assert torch.equal(auto, base)
+
+
+@pytest.mark.parametrize("build", [(8, 4, False, False), (7, 3, False, False), (5, 3, False, True), (4, 3, True, False), (6, 2, True, True)])
+def test_gemm_pp_epilogues(ops, build):
+    """Every epilogue of cst_gemm_bf16 on the ping-pong kernel: bias, ReLU + dropout (same counter-based masks as the tile kernels: compared
+    with them), LeakyReLU, the two gates (act 3 / 4 with a bf16 aux), addend, C += (accumulate), alpha, fp32 + bf16 outputs together."""
+    tm, tn, occ2, one = build
+    code = _pp_code(tm, tn, occ2, one)
+    M, N, K = 1500, 776, 256
+    A, B = dev(rnd(M, K, seed=3)), dev(rnd(N, K, seed=4))
+    Ab, Bb = ops.cast_bf16(A, want_t=False)[0], ops.cast_bf16(B, want_t=False)[0]
+    raw = _bfview(Ab)[:, :K] @ _bfview(Bb)[:, :K].t()
+    Np = (N + 63) // 64 * 64
+    bias, add = dev(rnd(N, seed=5)), dev(rnd(M, N, seed=6))
+    aux = ops.cast_bf16(dev(rnd(M, N, seed=7)), want_t=False)[0]
+    gate = _bfview(aux)[:, :N] > 0
+    cases = {
+        "bias": (dict(bias=bias), raw + bias),
+        "leaky": (dict(act=2), torch.where(raw > 0, raw, 0.1 * raw)),
+        "gate3": (dict(aux=aux, act=3, gate_scale=1.25), torch.where(gate, raw * 1.25, torch.zeros_like(raw))),
+        "gate4": (dict(aux=aux, act=4), torch.where(gate, raw, 0.1 * raw)),
+        "addend": (dict(addend=add, bias=bias), raw + bias + add),
+        "alpha": (dict(alpha=0.5), 0.5 * raw),
+    }
+    for name, (kw, ref) in cases.items():
+        C = torch.full((M, N), float("nan"), device="cuda")
+        Cb = torch.zeros(M, Np, device="cuda", dtype=torch.int16)
+        ops.gemm_bf16(Ab, Bb, M, N, C=C, Cb=Cb, tile=code, **kw)
+        sc = float(ref.abs().max())
+        assert float((C - ref).abs().max()) < 2e-5 * sc, (build, name)
+        assert torch.equal(_bfview(Cb)[:, :N], C.to(torch.bfloat16).float()), (build, name, "bf16 twin")
+    C = torch.full((M, N), 7.0, device="cuda")
+    ops.gemm_bf16(Ab, Bb, M, N, C=C, tile=code, accumulate=True)
+    assert float((C - (raw + 7.0)).abs().max()) < 2e-5 * float(raw.abs().max()), (build, "accumulate")
+    drop = ops.Drop(0.1, 123, 5)
+    got, want = torch.zeros(M, Np, device="cuda", dtype=torch.int16), torch.zeros(M, Np, device="cuda", dtype=torch.int16)
+    ops.gemm_bf16(Ab, Bb, M, N, Cb=got, tile=code, bias=bias, act=1, drop=drop)
+    ops.gemm_bf16(Ab, Bb, M, N, Cb=want, tile=128, bias=bias, act=1, drop=drop)
+    assert torch.equal(got, want), (build, "ReLU + dropout: mask placement or arithmetic differs from the tile kernels")
+    assert 0.3 < float((_bfview(got)[:, :N] == 0).float().mean()) < 0.7
+
+
 @pytest.mark.parametrize("shape", [(64, 128, 64), (130, 300, 200), (4608, 2304, 768), (4608, 768, 2048), (256, 512, 1024), (96, 2048, 640)])
 def test_gemm_bf16_w8_fp8_weights(ops, shape):
     """W8A16 (BASELINE configs[4]): fp8 e4m3 (OCP) weights with per-output-channel scales.  The quantiser is checked against
