@@ -513,17 +513,19 @@ def main():
             # (NT kernel, K > 0) and weight gradients (transposed-read kernel, recorded with K < 0)
             agg = {}
             for which, M, N, K, ms in shape_recs:
-                if which != 1 or M < 1024 or ms <= 0:
+                if which not in (1, 2) or M < 1024 or ms <= 0:
                     continue
-                a = agg.setdefault((M, N, K), [0, 0.0])
+                a = agg.setdefault((M, N, K), [0, 0.0, 0])
                 a[0] += 1
                 a[1] += ms
+                a[2] += which == 2
             by_shape = {}
-            for (M, N, K), (n, ms) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:16]:
+            for (M, N, K), (n, ms, npp) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:16]:
                 kind = "nt" if K > 0 else "tt"
                 tf = 2.0 * M * N * abs(K) * n / (ms * 1e-3) / 1e12
-                by_shape[f"{M}x{N}x{abs(K)}.{kind}"] = {"launches_per_step": n / nprof, "avg_us": 1000.0 * ms / n, "tflops": tf,
-                                                        "frac": tf / MFMA_PEAK_TFLOPS}
+                # `pp_launches_per_step`: how many of the shape's launches ran on the ping-pong kernel (csrc/gemm_pp.hip), the rest on the tile kernels
+                by_shape[f"{M}x{N}x{abs(K)}.{kind}"] = {"launches_per_step": n / nprof, "pp_launches_per_step": npp / nprof, "avg_us": 1000.0 * ms / n,
+                                                        "tflops": tf, "frac": tf / MFMA_PEAK_TFLOPS}
             roofline["by_shape"] = by_shape
         if args.breakdown:
             timer = _lib.KernelTimer(by_shape=True)

@@ -162,7 +162,7 @@ def gemm_profile_shapes(max_records=200000):
 def gemm_profile_read():
     """-> {kernel: (total kernel ms, total FLOP, total minimal operand bytes, launches)} since enable."""
     out = {}
-    for which, name in ((0, "cst_gemm_kernel"), (1, "cst_gemm_bf16_kernel")):
+    for which, name in ((2, "cst_gemm_bf16_pp_kernel"), (0, "cst_gemm_kernel"), (1, "cst_gemm_bf16_kernel")):        # (reading 1 clears the records)
         ms, fl, by = ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
         n = ctypes.c_long()
         rc = lib().fn["cst_gemm_profile_read"](which, ctypes.byref(ms), ctypes.byref(fl), ctypes.byref(by), ctypes.byref(n))

@@ -455,7 +455,7 @@ __global__ __launch_bounds__(256) void cst_gemm_splitk_reduce(GemmArgs g) {
 // trace), so the measured duration excludes host launch gaps.
 #include <hip/hip_ext.h>
 #include <vector>
-struct GemmProf { hipEvent_t a, b; double flops; double bytes; int which; int m, n, k; };    // which: 0 cst_gemm_kernel, 1 cst_gemm_bf16_kernel
+struct GemmProf { hipEvent_t a, b; double flops; double bytes; int which; int m, n, k; };    // which: 0 cst_gemm_kernel, 1 cst_gemm_bf16_kernel, 2 cst_gemm_bf16_pp_kernel
 static bool g_prof_on = false;
 static std::vector<GemmProf> g_prof;
 bool cst_prof_on() { return g_prof_on; }
@@ -487,7 +487,7 @@ extern "C" int cst_gemm_profile_enable(int on) {
     return CST_OK;
 }
 
-// sums over the recorded launches of kernel `which` (0 = cst_gemm_kernel, 1 = cst_gemm_bf16_kernel);
+// sums over the recorded launches of kernel `which` (0 = cst_gemm_kernel, 1 = cst_gemm_bf16_kernel, 2 = cst_gemm_bf16_pp_kernel);
 // reading with which = 1 also destroys all events and clears the record list
 extern "C" int cst_gemm_profile_read(int which, double* total_ms, double* total_flops, double* total_min_bytes, long* launches) {
     double ms = 0, fl = 0, by = 0;

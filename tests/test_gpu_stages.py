@@ -90,15 +90,21 @@ def test_single_step_losses(name, prec):
     st = make_opt(name, lr=1e-5)
     r = st.g_losses((x, labels), coins=G["optimize.coins"])
     got = [r["loss"].item(), r["G"].item(), r["STI"].item(), r["CP_logits"].mean().item(), r["BK"].item()]
-    ids_ok = np.array_equal(r["sample_ids"].cpu().numpy(), G["optimize.g.sample_ids"])
+    same = r["sample_ids"].cpu().numpy() == G["optimize.g.sample_ids"]
+    ids_ok = bool(same.all())
+    # bf16: a near-tie of two logits can flip a sampled token, and a flipped token changes every later token of ITS sentence and that
+    # sentence's terms of every batch-mean loss below.  Nothing is skipped for that: each comparison is held to its
+    # bf16 bound WIDENED by the share of sentences whose ids differ -- a sentence contributes 1/B of a mean, and its terms move by at most
+    # about the size of the mean itself (factor 2 for losses, 4 for gradient norms, which are not means) -- and the deviation is reported.
+    flipped_rows = float(1.0 - same.all(axis=1).mean())
     if bf:
-        agree = float((r["sample_ids"].cpu().numpy() == G["optimize.g.sample_ids"]).mean())
-        report("stages.sample_ids", tag=name, token_agreement=agree)
+        agree = float(same.mean())
+        report("stages.sample_ids", tag=name, token_agreement=agree, row_agreement=1.0 - flipped_rows)
         assert agree >= 0.9, agree
     else:
         assert ids_ok
-    if ids_ok:                                            # a flipped sample token changes every downstream loss
-        _close(got, G["optimize.g.losses"], prec, 2e-3, BF16_LOSS, f"{name}.optimize.g.losses", atol=1e-4)
+    wl, wg = BF16_LOSS + 2.0 * flipped_rows, BF16_GNORM + 4.0 * flipped_rows
+    _close(got, G["optimize.g.losses"], prec, 2e-3, wl, f"{name}.optimize.g.losses", atol=1e-4)
     for p in st.parameters():
         p.requires_grad_(False)
     for p in st.generator.parameters():
@@ -106,8 +112,7 @@ def test_single_step_losses(name, prec):
     r = st.g_losses((x, labels), coins=G["optimize.coins"])
     r["loss"].backward()
     gn = float(torch.sqrt(sum((p.grad.double() ** 2).sum() for p in st.generator.parameters())))
-    if ids_ok:
-        _close(gn, G["optimize.g.gnorm"][0], prec, 1e-2, BF16_GNORM, f"{name}.optimize.g.gnorm")
+    _close(gn, G["optimize.g.gnorm"][0], prec, 1e-2, wg, f"{name}.optimize.g.gnorm")
     if not bf:
         np.testing.assert_allclose(st.generator.fn_1.bias.grad.cpu().numpy(), G["optimize.g.grad.fn_1.bias"], rtol=2e-2, atol=1e-4)
     for p in st.parameters():
@@ -116,15 +121,12 @@ def test_single_step_losses(name, prec):
     for p in st.disc.parameters():
         p.requires_grad_(True)
     d = st.d_losses((x, labels))
-    if ids_ok:
-        _close(d["D"].item(), G["optimize.d.losses"][0], prec, 1e-3, BF16_LOSS, f"{name}.optimize.d.losses")
+    _close(d["D"].item(), G["optimize.d.losses"][0], prec, 1e-3, wl, f"{name}.optimize.d.losses")
     d["loss"].backward()
     gn = float(torch.sqrt(sum((p.grad.double() ** 2).sum() for p in st.disc.parameters())))
-    if ids_ok:
-        _close(gn, G["optimize.d.gnorm"][0], prec, 5e-3, BF16_GNORM, f"{name}.optimize.d.gnorm")
+    _close(gn, G["optimize.d.gnorm"][0], prec, 5e-3, wg, f"{name}.optimize.d.gnorm")
     v = st.val_loss((x, labels))
-    if ids_ok:
-        _close(v.item(), G["optimize.val"][0], prec, 2e-3, BF16_LOSS, f"{name}.optimize.val")
+    _close(v.item(), G["optimize.val"][0], prec, 2e-3, wl, f"{name}.optimize.val")
     ops.set_precision("bf16")
 
 

@@ -23,6 +23,8 @@ def stats(path, steps, out):
     for r in rows:
         n = short(r["Name"])
         f = "cst_gemm_kernel<*>" if n.startswith("cst_gemm_kernel") else ("cst_gemm_bf16_kernel<*>" if n.startswith("cst_gemm_bf16_kernel") else n)
+        if "cst_gemm_bf16_pp_kernel" in n:
+            f = "cst_gemm_bf16_pp_kernel<*>"
         fam[f][0] += int(r["Calls"])
         fam[f][1] += float(r["TotalDurationNs"])
     with open(out, "w") as f:
@@ -45,6 +47,7 @@ def pmc(fetch, write, out, workload="yelp_6l_d768_b256"):
             k = short(r["Kernel_Name"])
             k = "cst_gemm_kernel" if k.startswith("cst_gemm_kernel") else k
             k = "cst_gemm_bf16_kernel" if k.startswith("cst_gemm_bf16_kernel") else k
+            k = "cst_gemm_bf16_pp_kernel" if "cst_gemm_bf16_pp_kernel" in k else k
             d[k][0] += 1
             d[k][1] += float(r["Counter_Value"])
             d[k][2] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
