@@ -356,7 +356,7 @@ class OptimizeStage(nn.Module):
         clip_groups([self.g_group, self.d_group], self.clip, self._scratch, stepping=[self.g_group])
         self.g_group.step()
         self.g_group.zero_grad()
-        logs.update(G=r["G"], STI=r["STI"], BK=r["BK"], CP_logits=r["CP_logits"], g_total=r["loss"])
+        logs.update(G=r["G"], STI=r["STI"], BK=r["BK"], CP_logits=r["CP_logits"], g_total=r["loss"], sample_ids=r["sample_ids"])
         # discriminator step
         _set_requires_grad(self._all, False)
         _set_requires_grad(self.d_group.params, True)
