@@ -479,7 +479,7 @@ def main():
         # HBM traffic per launch cannot be measured inside this process (PMC counters need rocprofv3 around it): it is
         # read from the committed summary of the same workload (tools/profile_pmc.sh) and the JSON line says so
         pmc, traffic_source = {}, None
-        for cand in ("round3_pmc_traffic.json", "round2_pmc_traffic.json", "round1_pmc_traffic.json"):
+        for cand in ("round4_pmc_traffic.json", "round3_pmc_traffic.json", "round2_pmc_traffic.json", "round1_pmc_traffic.json"):
             pmc_path = os.path.join(REPO, "profiles", cand)
             if os.path.exists(pmc_path):
                 blob = json.load(open(pmc_path))
@@ -487,16 +487,25 @@ def main():
                     pmc = blob["kernels"]
                     traffic_source = f"profiles/{cand} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload, not measured in this run)"
                     break
-        kernels = {}
-        for name, (ms, flops, min_bytes, n) in prof.items():
-            if not n or ms <= 0:
-                continue
+        # the bf16 GEMM (entry points cst_gemm_bf16 / cst_gemm_bf16_tt) runs on two kernels: the big-tile ping-pong kernel (csrc/gemm_pp.hip) for
+        # the shapes it wins, the LDS-DMA tile kernels for the rest and all TT products.  They are ONE family here, as the template
+        # instantiations of the tile kernels always were (profiles/*kernel_stats*: the combined row); `members` keeps them apart.
+        FAMILY = "cst_gemm_bf16_kernel+cst_gemm_bf16_pp_kernel"
+        members = {k: prof[k] for k in ("cst_gemm_bf16_kernel", "cst_gemm_bf16_pp_kernel") if k in prof}
+        prof = {k: v for k, v in prof.items() if k not in members}
+        prof[FAMILY] = tuple(sum(v[i] for v in members.values()) for i in range(4))
+
+        def entry(name, ms, flops, min_bytes, n):
             ach = flops / (ms * 1e-3) / 1e12
-            k = pmc.get(name)
-            kernels[name] = {"achieved": ach, "frac": ach / MFMA_PEAK_TFLOPS, "launches_per_step": n / nprof,
-                             "avg_launch_us": 1000.0 * ms / n, "flops_per_launch": flops / n,
-                             "min_operand_bytes_per_launch": min_bytes / n, "kernel_ms_per_step": ms / nprof,
-                             "traffic": (k["fetch_bytes_per_launch"] + k["write_bytes_per_launch"]) if k else None}
+            ks = [pmc[m] for m in (members if name == FAMILY else (name,)) if m in pmc]
+            traffic = None
+            if ks:                                      # launch-weighted HBM-side bytes per launch of the family's kernels
+                traffic = sum((k["fetch_bytes_per_launch"] + k["write_bytes_per_launch"]) * k["launches"] for k in ks) / sum(k["launches"] for k in ks)
+            return {"achieved": ach, "frac": ach / MFMA_PEAK_TFLOPS, "launches_per_step": n / nprof,
+                    "avg_launch_us": 1000.0 * ms / n, "flops_per_launch": flops / n,
+                    "min_operand_bytes_per_launch": min_bytes / n, "kernel_ms_per_step": ms / nprof, "traffic": traffic}
+
+        kernels = {name: entry(name, *v) for name, v in prof.items() if v[3] and v[0] > 0}
         if kernels:
             # the dominant kernel = the one with the most device time per step
             dom = max(kernels, key=lambda k: kernels[k]["kernel_ms_per_step"])
@@ -507,6 +516,7 @@ def main():
                         "avg_launch_us": d["avg_launch_us"], "flops_per_launch": d["flops_per_launch"],
                         "min_operand_bytes_per_launch": d["min_operand_bytes_per_launch"],
                         "kernel_ms_per_step": d["kernel_ms_per_step"],
+                        "members": {m: entry(m, *v) for m, v in members.items() if v[3] and v[0] > 0} if dom == FAMILY else None,
                         "other_mfma_kernels": {k: v for k, v in kernels.items() if k != dom}}
         if roofline is not None:
             # per-shape rates of the encoder-layer products (T = B*L tokens of the MLM, 2*B*L of the Matcher): forward / dgrad

@@ -849,6 +849,30 @@ int pp_tune(const BGemmArgs& g, hipStream_t st, int (*tiles)(void*), void* ctx) 
 }
 }  // namespace
 
+// CST_GEMM_PP_CACHE=<file>: the measured choices are read from it when the first product arrives and appended to it as shapes are measured,
+// so a second process (a profiled run, a production job) starts with them and measures nothing ("M N K kind cfg" per line, this device class
+// only -- the file is the caller's to keep per machine type).
+namespace {
+bool g_pp_cache_loaded = false;
+void pp_cache_load() {                                            // g_pp_mu held
+    if (g_pp_cache_loaded) return;
+    g_pp_cache_loaded = true;
+    const char* path = getenv("CST_GEMM_PP_CACHE");
+    if (!path) return;
+    if (FILE* f = fopen(path, "r")) {
+        unsigned long long key;
+        int cfg;
+        while (fscanf(f, "%llu %d", &key, &cfg) == 2) g_pp_pick[key] = cfg;
+        fclose(f);
+    }
+}
+void pp_cache_append(unsigned long long key, int cfg) {
+    const char* path = getenv("CST_GEMM_PP_CACHE");
+    if (!path) return;
+    if (FILE* f = fopen(path, "a")) { fprintf(f, "%llu %d\n", key, cfg); fclose(f); }
+}
+}  // namespace
+
 int bgemm_pp_try(const BGemmArgs& g, int force_cfg, hipStream_t st, int (*tiles)(void*), void* ctx) {
     static const int mode = getenv("CST_GEMM_PP") ? atoi(getenv("CST_GEMM_PP")) : 1;   // 0: never (A/B switch), 1: measured choice, 2: the model's choice only
     if (mode == 0 && force_cfg <= 0) return 0;
@@ -871,6 +895,7 @@ int bgemm_pp_try(const BGemmArgs& g, int force_cfg, hipStream_t st, int (*tiles)
     const unsigned long long key = pp_key(g);
     {
         std::lock_guard<std::mutex> lk(g_pp_mu);
+        pp_cache_load();
         auto it = g_pp_pick.find(key);
         if (it != g_pp_pick.end()) cfg = it->second;
     }
@@ -881,6 +906,7 @@ int bgemm_pp_try(const BGemmArgs& g, int force_cfg, hipStream_t st, int (*tiles)
             cfg = pp_tune(g, st, tiles, ctx);
             std::lock_guard<std::mutex> lk(g_pp_mu);
             g_pp_pick[key] = cfg;
+            pp_cache_append(key, cfg);
             return (cfg > 0 || tiles) ? 1 : 0;                    // every candidate computed the product; the winner ran last
         } else {
             cfg = cst_gemm_bf16_pp_config(g.M, g.N, g.K);          // not measurable here (capture, profiling run, C += ...): the model, not remembered

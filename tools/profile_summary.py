@@ -12,7 +12,7 @@ import sys
 
 
 def short(name):
-    name = name.replace("void ", "")
+    name = name.replace("void ", "").replace("(anonymous namespace)::", "")
     return name.split("(")[0]
 
 
@@ -20,6 +20,7 @@ def stats(path, steps, out):
     rows = list(csv.DictReader(open(path)))
     tot = sum(float(r["TotalDurationNs"]) for r in rows)
     fam = collections.defaultdict(lambda: [0, 0.0])
+    BOTH = "`cst_gemm_bf16_kernel<*>` + `cst_gemm_bf16_pp_kernel<*>` (the bf16 GEMM of cst_gemm_bf16 / _tt: its two kernels together)"
     for r in rows:
         n = short(r["Name"])
         f = "cst_gemm_kernel<*>" if n.startswith("cst_gemm_kernel") else ("cst_gemm_bf16_kernel<*>" if n.startswith("cst_gemm_bf16_kernel") else n)
@@ -27,11 +28,17 @@ def stats(path, steps, out):
             f = "cst_gemm_bf16_pp_kernel<*>"
         fam[f][0] += int(r["Calls"])
         fam[f][1] += float(r["TotalDurationNs"])
+        if f in ("cst_gemm_bf16_kernel<*>", "cst_gemm_bf16_pp_kernel<*>"):
+            fam[BOTH][0] += int(r["Calls"])
+            fam[BOTH][1] += float(r["TotalDurationNs"])
     with open(out, "w") as f:
-        f.write(f"rocprofv3 --kernel-trace --stats, {steps} steps: total kernel time {tot / 1e6:.2f} ms = {tot / 1e6 / steps:.2f} ms/step\n\n")
+        f.write(f"rocprofv3 --kernel-trace --stats, {steps} steps: total kernel time {tot / 1e6:.2f} ms = {tot / 1e6 / steps:.2f} ms/step\n")
+        f.write("(the first row is the SUM of the two rows of the bf16 GEMM's kernels below it -- the big-tile ping-pong kernel of csrc/gemm_pp.hip takes the shapes it wins,\n"
+                " the LDS-DMA tile kernels of csrc/gemm_bf16.hip the rest and all weight-gradient (TT) products; bench.py's roofline.kernel is this family)\n\n")
         f.write("| kernel (family) | calls/step | total ms/step | avg us | % |\n|---|---|---|---|---|\n")
-        for k, (c, t) in sorted(fam.items(), key=lambda kv: -kv[1][1])[:28]:
-            f.write(f"| `{k}` | {c / steps:.1f} | {t / 1e6 / steps:.3f} | {t / c / 1e3:.1f} | {100 * t / tot:.1f} |\n")
+        for k, (c, t) in sorted(fam.items(), key=lambda kv: -kv[1][1])[:29]:
+            name = k if k == BOTH else f"`{k}`"
+            f.write(f"| {name} | {c / steps:.1f} | {t / 1e6 / steps:.3f} | {t / c / 1e3:.1f} | {100 * t / tot:.1f} |\n")
         f.write("\nPer template instantiation of the GEMM:\n\n| kernel | calls/step | avg us | % |\n|---|---|---|---|\n")
         for r in rows:
             if "cst_gemm" in r["Name"]:
