@@ -154,6 +154,44 @@ def bench(shapes):
               f"best {per[best]:6.1f} ({tf(per[best]):5.0f}) {best}, fp32 out {t32:6.1f} | " + " ".join(f"{k}:{t:.1f}" for k, t in per.items()), flush=True)
 
 
+def gn(shapes):
+    """XCD strip width (tile columns per strip, CST_GEMM_GN is read once per process: one subprocess per value)."""
+    import subprocess
+    for g in (2, 4, 8, 16):
+        env = dict(os.environ, CST_GEMM_GN=str(g))
+        out = subprocess.run([sys.executable, os.path.abspath(__file__), "gn1"] + [str(v) for s3 in shapes for v in s3], env=env, capture_output=True, text=True).stdout
+        print(f"GN={g}: " + out.strip().replace("\n", " || "), flush=True)
+
+
+def gn1(shapes):
+    for M, N, K in shapes:
+        A, B = torch.randn(M, K, device="cuda"), torch.randn(N, K, device="cuda")
+        Ab, Bb = ops.cast_bf16(A, want_t=False)[0], ops.cast_bf16(B, want_t=False)[0]
+        Cb = torch.empty(M, (N + 63) // 64 * 64, device="cuda", dtype=torch.int16)
+        row = [f"{lab} {timed(lambda: ops.gemm_bf16(Ab, Bb, M, N, Cb=Cb, tile=t), n=10):.1f}" for lab, t in
+               (("5x4", code(5, 4)), ("7x3", code(7, 3)), ("4x4", code(4, 4)), ("5x3", code(5, 3)), ("6x2/2t", 30000 + code(6, 2)))]
+        print(f"{M}x{N}x{K}: " + " ".join(row))
+
+
+def epi(shapes):
+    """What the step's epilogues cost on top of the plain product (same launch-graph timing): FFN1 forward (bias + ReLU + dropout -> bf16),
+    the FFN hidden gradient (ReLU' / dropout' gate read from a bf16 aux -> bf16), the residual products (fp32 out, + addend)."""
+    for M, N, K in shapes:
+        A, B = torch.randn(M, K, device="cuda"), torch.randn(N, K, device="cuda")
+        Ab, Bb = ops.cast_bf16(A, want_t=False)[0], ops.cast_bf16(B, want_t=False)[0]
+        Cb = torch.empty(M, (N + 63) // 64 * 64, device="cuda", dtype=torch.int16)
+        C = torch.empty(M, N, device="cuda")
+        bias, add = torch.randn(N, device="cuda"), torch.randn(M, N, device="cuda")
+        aux = ops.cast_bf16(torch.randn(M, N, device="cuda"), want_t=False)[0]
+        kinds = {"plain bf16": dict(Cb=Cb), "bias+relu+drop bf16": dict(Cb=Cb, bias=bias, act=1, drop=ops.Drop(0.1, 1, 2)),
+                 "gate(aux) bf16": dict(Cb=Cb, aux=aux, act=3, gate_scale=1.1), "bias f32": dict(C=C, bias=bias), "addend f32": dict(C=C, addend=add)}
+        for label, tile in (("tile kernels", 999), ("auto", 0), ("5x4", code(5, 4)), ("7x3", code(7, 3)), ("6x2/2t", 30000 + code(6, 2)), ("4x4", code(4, 4)), ("5x3", code(5, 3))):
+            row = []
+            for kn, kw in kinds.items():
+                row.append(f"{kn} {timed(lambda: ops.gemm_bf16(Ab, Bb, M, N, tile=tile, **kw), n=10):.1f}")
+            print(f"{M}x{N}x{K} {label:12s}: " + " | ".join(row), flush=True)
+
+
 def abl(shapes, cfgs=((8, 4), (7, 3))):
     """Timing ablations (bench build: CST_BENCH_VARIANTS=1 python -m consistent__style_transfer_amd.build): what the K loop's parts cost.
     1 no LDS-DMA, 2 no MFMA, 4 no fragment reads, 8 one barrier per phase, 16 no vmcnt waits, 32 no epilogue."""
@@ -205,6 +243,12 @@ if __name__ == "__main__":
     mode = sys.argv[1] if len(sys.argv) > 1 else "check"
     if mode == "check":
         check()
+    elif mode in ("gn", "gn1"):
+        v = [int(x) for x in sys.argv[2:]]
+        (gn if mode == "gn" else gn1)([tuple(v[i:i + 3]) for i in range(0, len(v), 3)] or [(9216, 2048, 768), (9216, 768, 2048), (9216, 2304, 768)])
+    elif mode == "epi":
+        v = [int(x) for x in sys.argv[2:]]
+        epi([tuple(v[i:i + 3]) for i in range(0, len(v), 3)] or [(9216, 2048, 768), (9216, 768, 2048)])
     elif mode == "stamps":
         v = [int(x) for x in sys.argv[2:]]
         stamps([tuple(v[i:i + 3]) for i in range(0, len(v), 3)] or [(9216, 2048, 768), (9216, 768, 2048), (4096, 4096, 4096)])
