@@ -202,9 +202,30 @@ def _i16(dev, *shape):
     return torch.empty(*shape, device=dev, dtype=torch.int16)
 
 
+_GRAD_SHARE = [None]
+
+
+class shared_param_grads:
+    """`with shared_param_grads():` around SEVERAL generator calls whose outputs feed ONE backward pass (the optimize stage's generator
+    step decodes twice with the same parameters, main_optimize.py:97 and :104): the backward of the call that runs first keeps its parameter
+    gradients, the backward of every other call adds its own into those tensors with one multi-tensor launch and hands autograd nothing
+    -- instead of autograd summing the two sets parameter by parameter (44 small add launches per step).  Same sums,
+    same order of the two addends."""
+
+    def __enter__(self):
+        self.prev = _GRAD_SHARE[0]
+        _GRAD_SHARE[0] = {}
+        return self
+
+    def __exit__(self, *exc):
+        _GRAD_SHARE[0] = self.prev
+        return False
+
+
 class GeneratorFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, inp, label_i, x, label, coins, cfg, *params):
+        ctx.share = _GRAD_SHARE[0]
         """inp: (B,L') int64 ids or (B,L',V) fp32 probabilities; x: (B,T) int64 or None;
         coins: (T,) int32 device tensor (1 = feed back argmax) or None;
         cfg: dict(mode 'none'|'softmax', tau, max_len, drop Drop or NO_DROP)."""
@@ -682,4 +703,19 @@ class GeneratorFn(torch.autograd.Function):
             dinp = _new(dev, B * Lp, V)
             gemm(demb, True, E_tok, True, dinp, B * Lp, V, E)            # straight-through of rnn.py:61
             dinp = dinp.view(B, Lp, V)
-        return (dinp, None, None, None, None, None, *[G[k] for k in PARAM_KEYS])
+        grads = [G[k] for k in PARAM_KEYS]
+        share = ctx.share
+        if share is not None:
+            prev = share.get("grads")
+            here = torch.cuda.current_stream(dev) if dev.type == "cuda" else None
+            if prev is not None and share.get("stream") != here:
+                prev = None                                   # (CST_FORK=1: the two decodes ran on different streams -- autograd's own sums)
+            if prev is None:
+                share["grads"], share["stream"] = grads, here # the first backward of the group: autograd gets these tensors ...
+            else:
+                both = [(a, b) for a, b in zip(prev, grads) if a is not None and b is not None]
+                if both:
+                    torch._foreach_add_([a for a, _ in both], [b for _, b in both])       # ... and every later one adds into them
+                grads = [b if a is None else None for a, b in zip(prev, grads)]
+                share["grads"] = None                         # (drop the references: AccumulateGrad may take the tensors as they are)
+        return (dinp, None, None, None, None, None, *grads)

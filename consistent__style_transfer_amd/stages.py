@@ -17,7 +17,7 @@ import random
 import torch
 import torch.nn as nn
 
-from . import ops
+from . import gen_fn, ops
 from .model import MLM, DenoiseLSTM, Matcher, RelGAN_D, TextCNN
 from .optim import FlatGroup, FlatSlice, clip_groups
 
@@ -294,6 +294,10 @@ class OptimizeStage(nn.Module):
     # ---- optimizer_idx 0 (main_optimize.py:96-113) ------------------------------------------
     def g_losses(self, batch, coins=None, seed=None):
         x, labels = batch
+        with gen_fn.shared_param_grads():                                     # both decodes of this step feed one backward pass
+            return self._g_losses(x, labels, coins, seed)
+
+    def _g_losses(self, x, labels, coins, seed):
         sample_p = self.forward(x, labels, 1 - labels, self.tau, seed=seed)
         with torch.no_grad():
             tokens = self.generator.last_ids.t().contiguous()                 # == sample_p.argmax(-1)
