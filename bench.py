@@ -531,7 +531,7 @@ def main():
                 a[2] += which == 2
             by_shape = {}
             for (M, N, K), (n, ms, npp) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:16]:
-                kind = "nt" if K > 0 else "tt"
+                kind = "nt" if K > 0 else ("tt-group" if N == 128 else "tt")       # tt-group: the dW of one encoder layer in one launch, all outputs as rows of 128
                 tf = 2.0 * M * N * abs(K) * n / (ms * 1e-3) / 1e12
                 # `pp_launches_per_step`: how many of the shape's launches ran on the ping-pong kernel (csrc/gemm_pp.hip), the rest on the tile kernels
                 by_shape[f"{M}x{N}x{abs(K)}.{kind}"] = {"launches_per_step": n / nprof, "pp_launches_per_step": npp / nprof, "avg_us": 1000.0 * ms / n,

@@ -458,8 +458,10 @@ __device__ __forceinline__ void bgemm_write_rows(const BGemmArgs& g, uint32_t ds
 //             the epilogue (bscale).  gfx950 has no MFMA that mixes bf16 and fp8 operands.
 // NW = waves per workgroup: 4 (2 x 2 wave tiles of BM/2 x BN/2) or 8 (4 x 2 wave tiles of BM/4 x BN/2).  128 x 128 / 8 waves (tile code 136)
 // keeps the 128 x 128 tile's bytes per FLOP with sixteen DMA-issuing waves per CU instead of eight.
-template <int BM, int BN, int NSTAGE, bool TT = false, bool BF8 = false, int NW = 4>
-__global__ __launch_bounds__(64 * NW) void cst_gemm_bf16_kernel(BGemmArgs g) {
+// The body of one workgroup: `id` = its position in the XCD-ordered list of the product's output tiles, `by` = its K split, `bz` = which of
+// the two same-shape problems (A2 / B2).  Shared by the one-product kernel and the grouped weight-gradient kernel below.
+template <int BM, int BN, int NSTAGE, bool TT, bool BF8, int NW>
+__device__ __forceinline__ void bgemm_tile_body(const BGemmArgs& g, const int id, const int by, const int bz) {
     static_assert(!(TT && BF8), "fp8 B operand: NT products only");
     constexpr int A_BYTES = BM * BROW, B_BYTES = BN * (BF8 ? 64 : BROW), ST_BYTES = A_BYTES + B_BYTES;
     constexpr int A_CH = BM / 8 / NW, B_CH = BF8 ? BN / 16 / NW : BN / 8 / NW;   // 1-KiB chunks (8 rows; fp8 B: 16 rows) per wave per tile
@@ -471,11 +473,6 @@ __global__ __launch_bounds__(64 * NW) void cst_gemm_bf16_kernel(BGemmArgs g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tilesM = (g.M + BM - 1) / BM, tilesN = (g.N + BN - 1) / BN;
-    int id;
-    {
-        const int nblk = gridDim.x, q = nblk >> 3, r = nblk & 7, xcd = blockIdx.x & 7;
-        id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (blockIdx.x >> 3);
-    }
     // an XCD (consecutive ids) works on a strip GN tile columns wide: every A panel is then fetched by tilesN / GN XCDs instead of all
     // eight, while the strip's B panels (GN x BN rows of K) stay in its L2.  Sweep (tools/gemm_bench.py enc, CST_GEMM_GN = 2/4/8/16): 8 is
     // 5-10 % ahead of 4 on the long shapes (book FFN1, vocabulary projection), level on the d=768 ones; 16 overflows the L2 on the book shapes.
@@ -501,7 +498,7 @@ __global__ __launch_bounds__(64 * NW) void cst_gemm_bf16_kernel(BGemmArgs g) {
 #pragma unroll
         for (int c = 0; c < A_CH; ++c) {
             const int r = (wave * A_CH + c) * 8 + lrow;
-            asrc[c] = (blockIdx.z ? g.A2 : g.A) + (long)min(m0 + r, g.M - 1) * g.lda + ((lps ^ (r & 7)) << 3);
+            asrc[c] = (bz ? g.A2 : g.A) + (long)min(m0 + r, g.M - 1) * g.lda + ((lps ^ (r & 7)) << 3);
         }
         if constexpr (BF8) {
             // 16-row pieces of 64-byte rows: lane l lands at (row 16 c + l/4, physical 16-byte slot l%4) and fetches logical slot
@@ -517,7 +514,7 @@ __global__ __launch_bounds__(64 * NW) void cst_gemm_bf16_kernel(BGemmArgs g) {
 #pragma unroll
         for (int c = 0; c < B_CH; ++c) {
             const int r = (wave * B_CH + c) * 8 + lrow;
-            bsrc[c] = (blockIdx.z ? g.B2 : g.B) + (long)min(n0 + r, g.N - 1) * g.ldb + ((lps ^ (r & 7)) << 3);
+            bsrc[c] = (bz ? g.B2 : g.B) + (long)min(n0 + r, g.N - 1) * g.ldb + ((lps ^ (r & 7)) << 3);
         }
         }
     } else {
@@ -538,7 +535,7 @@ __global__ __launch_bounds__(64 * NW) void cst_gemm_bf16_kernel(BGemmArgs g) {
             bsrc[c] = g.B + (long)r * g.ldb + min(n0 + lc * 8, g.N - 8);
         }
     }
-    const int kbeg = blockIdx.y * g.k_per_split;
+    const int kbeg = by * g.k_per_split;
     const int kend = min(g.K, kbeg + g.k_per_split);
     const int nk = (kend - kbeg) / BBK;
 
@@ -675,7 +672,7 @@ __global__ __launch_bounds__(64 * NW) void cst_gemm_bf16_kernel(BGemmArgs g) {
     if (BGEMM_ABL(g) & 8) return;
 
     if (g.splits > 1 || g.slab_only) {
-        float* slab = g.slab + (((long)blockIdx.z * g.splits + blockIdx.y) * g.M) * g.N;
+        float* slab = g.slab + (((long)bz * g.splits + by) * g.M) * g.N;
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -727,6 +724,40 @@ __global__ __launch_bounds__(64 * NW) void cst_gemm_bf16_kernel(BGemmArgs g) {
                 if (n + e < g.N) bgemm_store(g, dseed, m, n + e, av[e]);
         }
     }
+}
+
+// consecutive workgroup ids go round the eight XCDs: id = the workgroup's place in an order that keeps each XCD's workgroups together
+__device__ __forceinline__ int bgemm_xcd_order(const int bid, const int nblk) {
+    const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+}
+
+template <int BM, int BN, int NSTAGE, bool TT = false, bool BF8 = false, int NW = 4>
+__global__ __launch_bounds__(64 * NW) void cst_gemm_bf16_kernel(BGemmArgs g) {
+    bgemm_tile_body<BM, BN, NSTAGE, TT, BF8, NW>(g, bgemm_xcd_order(blockIdx.x, gridDim.x), blockIdx.y, blockIdx.z);
+}
+
+// Several weight-gradient products C_p = A_p^T B_p in ONE launch (cst_gemm_bf16_tt_group_*): the four dW of an encoder layer each have
+// 36-108 output tiles of 128 x 128 over a long contraction (the token count) -- launched one by one each needs split-K slabs and a
+// reduce launch to fill the CUs; together they are 336 tiles, enough for whole-K workgroups (measured, tools/tt_group_probe.py:
+// 193.6 -> 128.7 us for the Matcher's layer, 119.5 -> 68.9 us for the MLM's).  The workgroups of the launch are numbered through the
+// problems in order; each finds its problem from the prefix sums of the tile counts and runs the one-product body on it.
+#define CST_TT_GROUP_MAX 8
+struct BTtProblem { const bf16_t* A; const bf16_t* B; float* C; long lda, ldb, ldc; int M, N, K, accumulate; };
+struct BTtGroup { BTtProblem p[CST_TT_GROUP_MAX]; int start[CST_TT_GROUP_MAX + 1]; int n; };
+
+__global__ __launch_bounds__(256) void cst_gemm_bf16_tt_group_kernel(BTtGroup q) {
+    const int id = bgemm_xcd_order(blockIdx.x, gridDim.x);
+    int p = 0;
+#pragma unroll
+    for (int i = 1; i < CST_TT_GROUP_MAX; ++i)
+        if (i < q.n && id >= q.start[i]) p = i;
+    const BTtProblem& t = q.p[p];
+    BGemmArgs g{};                                   // everything the weight gradients do not use is a compile-time null / zero here
+    g.A = t.A; g.B = t.B; g.C = t.C; g.lda = t.lda; g.ldb = t.ldb; g.ldc = t.ldc;
+    g.M = t.M; g.N = t.N; g.K = t.K; g.accumulate = t.accumulate;
+    g.alpha = 1.f; g.gate_scale = 1.f; g.splits = 1; g.k_per_split = t.K;
+    bgemm_tile_body<128, 128, 2, true, false, 4>(g, id - q.start[p], 0, 0);
 }
 
 // BATCH: four slab loads in flight at a time (same summation order).  A runtime-bounded loop of one load and one dependent
@@ -1511,6 +1542,79 @@ extern "C" int cst_gemm_bf16_argmax(const void* A, long lda, const void* B, long
                        0.f, 0, 0, nullptr, 64, 1, nullptr, 0, stream, (unsigned long long*)amax_packed);
 }
 
+// ---- grouped weight gradients: cst_gemm_bf16_tt calls between _group_begin and _group_end are collected (per host thread) and
+// launched together by _group_end.  A group whose tiles would not fill the chip is launched product by product, as without a group.
+struct TtDeferred { BTtProblem p; int splitk; float* ws; long ws_floats; };
+static thread_local struct { bool open; int n; TtDeferred d[CST_TT_GROUP_MAX]; } tt_group = {false, 0, {}};
+
+static int tt_single(const void* A, long lda, const void* B, long ldb, float* C, long ldc, int M, int N, int K,
+                     int accumulate, int splitk, float* workspace, long workspace_floats, void* stream);
+
+static int tt_group_min_tiles() {
+    static const int v = [] { const char* e = getenv("CST_TT_GROUP_MIN"); return e ? atoi(e) : 224; }();     // 0: never group
+    return v;
+}
+
+static int tt_group_flush(hipStream_t st) {
+    const int n = tt_group.n;
+    tt_group.n = 0;
+    if (n == 0) return CST_OK;
+    BTtGroup q{};
+    long tiles = 0;
+    double flops = 0, bytes = 0;
+    for (int i = 0; i < n; ++i) {
+        const BTtProblem& t = tt_group.d[i].p;
+        q.p[i] = t;
+        q.start[i] = (int)tiles;
+        tiles += (long)cst_div_up(t.M, 128) * cst_div_up(t.N, 128);
+        flops += 2.0 * t.M * t.N * t.K;
+        bytes += 2.0 * ((double)t.M * t.K + (double)t.N * t.K) + 4.0 * t.M * t.N;
+    }
+    q.start[n] = (int)tiles; q.n = n;
+    // whole-K workgroups need enough tiles to occupy the CUs: 336 tiles (d = 768 layers) always win; 192 tiles (d = 512) win while the
+    // contraction is short (9216 tokens: 127 -> 102 us, 4608: 90 -> 54, 15360: 186 -> 176) and lose to per-product split-K when it is
+    // long (30720 tokens: 344 -> 399 us) -- tools/tt_group_probe.py
+    const int min_tiles = tt_group_min_tiles();
+    int kmax = 0;
+    for (int i = 0; i < n; ++i) kmax = q.p[i].K > kmax ? q.p[i].K : kmax;
+    const bool fills = tiles >= min_tiles || (min_tiles == 224 && tiles >= 160 && kmax <= 16384);
+    if (n == 1 || min_tiles <= 0 || !fills) {
+        for (int i = 0; i < n; ++i) {
+            const TtDeferred& d = tt_group.d[i];
+            const int rc = tt_single(d.p.A, d.p.lda, d.p.B, d.p.ldb, d.p.C, d.p.ldc, d.p.M, d.p.N, d.p.K, d.p.accumulate, d.splitk, d.ws, d.ws_floats, st);
+            if (rc != CST_OK) return rc;
+        }
+        return CST_OK;
+    }
+    constexpr size_t lds = 2 * (128 * BROW + 128 * BROW);
+    static CstPerDevice attr_done;
+    if (lds > 64 * 1024 && cst_first_on_device(attr_done))
+        (void)hipFuncSetAttribute((const void*)cst_gemm_bf16_tt_group_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (cst_prof_on()) {
+        hipEvent_t ea, eb;
+        (void)hipEventCreate(&ea); (void)hipEventCreate(&eb);
+        // recorded as ONE product [sum of M_p N_p / 128] x 128 over the first problem's K (bench.py labels the 128-column TT shape a group)
+        cst_prof_push_shape(ea, eb, flops, bytes, 1, (int)(flops / (256.0 * q.p[0].K)), 128, -q.p[0].K);
+        hipExtLaunchKernelGGL(cst_gemm_bf16_tt_group_kernel, dim3((unsigned)tiles), dim3(256), lds, st, ea, eb, 0, q);
+    } else {
+        hipLaunchKernelGGL(cst_gemm_bf16_tt_group_kernel, dim3((unsigned)tiles), dim3(256), lds, st, q);
+    }
+    CST_LAUNCH_CHECK("cst_gemm_bf16_tt_group");
+    return CST_OK;
+}
+
+extern "C" int cst_gemm_bf16_tt_group_begin(void* /*stream: the products are launched by _group_end, on ITS stream*/) {
+    CST_REQUIRE(!tt_group.open, "cst_gemm_bf16_tt_group_begin: a group is already open on this thread");
+    tt_group.open = true; tt_group.n = 0;
+    return CST_OK;
+}
+
+extern "C" int cst_gemm_bf16_tt_group_end(void* stream) {
+    CST_REQUIRE(tt_group.open, "cst_gemm_bf16_tt_group_end: no group is open on this thread");
+    tt_group.open = false;
+    return tt_group_flush((hipStream_t)stream);
+}
+
 extern "C" int cst_gemm_bf16_tt(const void* A, long lda, const void* B, long ldb, float* C, long ldc, int M, int N, int K,
                                 int accumulate, int splitk, float* workspace, long workspace_floats, void* stream) {
     CST_REQUIRE(A && B && C, "cst_gemm_bf16_tt: null operand");
@@ -1518,6 +1622,21 @@ extern "C" int cst_gemm_bf16_tt(const void* A, long lda, const void* B, long ldb
                 "cst_gemm_bf16_tt: M=%d, N=%d must be multiples of 8 and K=%d a multiple of 64", M, N, K);
     CST_REQUIRE(lda >= M && ldb >= N && lda % 8 == 0 && ldb % 8 == 0 && ldc >= N && (((uintptr_t)A | (uintptr_t)B) & 15) == 0,
                 "cst_gemm_bf16_tt: operands must be 16-byte aligned, leading dimensions multiples of 8");
+    if (tt_group.open && splitk <= 1) {              // (an explicit split-K request is honoured at once, outside the group)
+        if (tt_group.n == CST_TT_GROUP_MAX) {
+            const int rc = tt_group_flush((hipStream_t)stream);
+            if (rc != CST_OK) return rc;
+        }
+        TtDeferred& d = tt_group.d[tt_group.n++];
+        d.p = BTtProblem{(const bf16_t*)A, (const bf16_t*)B, C, lda, ldb, ldc, M, N, K, accumulate};
+        d.splitk = splitk; d.ws = workspace; d.ws_floats = workspace_floats;
+        return CST_OK;
+    }
+    return tt_single(A, lda, B, ldb, C, ldc, M, N, K, accumulate, splitk, workspace, workspace_floats, stream);
+}
+
+static int tt_single(const void* A, long lda, const void* B, long ldb, float* C, long ldc, int M, int N, int K,
+                     int accumulate, int splitk, float* workspace, long workspace_floats, void* stream) {
     BGemmArgs g{};                                  // value-initialised: every pointer the entry point does not set is null
     g.A = (const bf16_t*)A; g.B = (const bf16_t*)B; g.A2 = nullptr; g.B2 = nullptr; g.C = C; g.Cb = nullptr;
     g.bias = nullptr; g.addend = nullptr; g.aux = nullptr;

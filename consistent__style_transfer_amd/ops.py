@@ -342,6 +342,20 @@ def gemm_bf16_tt(Ab, Bb, M, N, C=None, accumulate=False, splitk=0):
     return C
 
 
+class tt_group:
+    """`with tt_group():` -- the gemm_bf16_tt products issued inside are launched together when the block ends (cst_gemm_bf16_tt_group_*:
+    the weight gradients of one encoder layer in one whole-K launch instead of four split-K launches + four reduces).  Their results
+    are defined only after the block; operands must stay alive until then (they are locals of the calling backward)."""
+
+    def __enter__(self):
+        call("cst_gemm_bf16_tt_group_begin")
+        return self
+
+    def __exit__(self, *exc):
+        call("cst_gemm_bf16_tt_group_end")             # always closes the group (what was recorded is launched even on an error path)
+        return False
+
+
 def colsum_bf16(xb, N):
     out = _zeros_or_none(N, xb.device)
     pre = out is not None
@@ -838,10 +852,11 @@ class EncoderLayerBf16Fn(torch.autograd.Function):
         if wg:
             if tt:                                        # dW = dY^T X from the row-major copies
                 in_w, out_w, l1_w, l2_w = ctx.wrefs
-                dl2w = gemm_bf16_tt(dfb, wh, d, F, C=_gout(l2_w))
-                dl1w = gemm_bf16_tt(dhb, wy1, F, d, C=_gout(l1_w))
-                doutw = gemm_bf16_tt(dob, watt, d, d, C=_gout(out_w))
-                dinw = gemm_bf16_tt(dqb, wx, 3 * d, d, C=_gout(in_w))
+                with tt_group():                          # the four weight gradients of the layer: one launch
+                    dl2w = gemm_bf16_tt(dfb, wh, d, F, C=_gout(l2_w))
+                    dl1w = gemm_bf16_tt(dhb, wy1, F, d, C=_gout(l1_w))
+                    doutw = gemm_bf16_tt(dob, watt, d, d, C=_gout(out_w))
+                    dinw = gemm_bf16_tt(dqb, wx, 3 * d, d, C=_gout(in_w))
             else:
                 dht = cast_bf16(dhb[:, :F], want_rm=False)[1]
                 dl2w = gemm_bf16(dft, wh, d, F, C=new(d, F))

@@ -910,6 +910,47 @@ def test_gemm_bf16_tt(ops, K, M, N, splitk):
     close(acc, 1 + ref, 2e-4, 2e-4 * math.sqrt(K))
 
 
+def test_gemm_bf16_tt_group_equals_whole_k_products_bit_for_bit(ops):
+    """cst_gemm_bf16_tt_group_*: the products recorded inside `with ops.tt_group()` are launched as one kernel whose workgroups each run
+    the whole contraction of one 128 x 128 output tile -- the same workgroup body as a single product with splitk = 1, so every output
+    must equal that launch bit for bit (ragged M / N, an accumulating output, different K per problem, more problems than one launch
+    holds), and the fp32 reference to bf16-operand accuracy."""
+    shapes = [(768, 2048, 1152), (2048, 768, 1152), (776, 768, 1152), (2304, 520, 1152), (256, 384, 576),
+              (768, 768, 1152), (128, 2048, 1152), (1024, 136, 1152), (2048, 2048, 576), (896, 384, 576)]       # 10 > CST_TT_GROUP_MAX = 8
+    prob = []
+    for i, (M, N, K) in enumerate(shapes):
+        Ab = ops.cast_bf16(dev(rnd(K, M, seed=10 + i, scale=0.5)), want_t=False)[0]
+        Bb = ops.cast_bf16(dev(rnd(K, N, seed=40 + i, scale=0.5)), want_t=False)[0]
+        prob.append((Ab, Bb, M, N, K))
+    single = []
+    for i, (Ab, Bb, M, N, K) in enumerate(prob):
+        C = torch.full((M, N), 0.5, device="cuda") if i == 2 else torch.empty(M, N, device="cuda")
+        single.append(ops.gemm_bf16_tt(Ab, Bb, M, N, C=C, accumulate=i == 2, splitk=1))
+    outs = [torch.full((M, N), 0.5, device="cuda") if i == 2 else torch.full((M, N), float("nan"), device="cuda") for i, (_, _, M, N, _) in enumerate(prob)]
+    with ops.tt_group():
+        for i, (Ab, Bb, M, N, K) in enumerate(prob):
+            ops.gemm_bf16_tt(Ab, Bb, M, N, C=outs[i], accumulate=i == 2)
+    for i, (Ab, Bb, M, N, K) in enumerate(prob):
+        assert torch.equal(outs[i], single[i]), f"problem {i} ({M}x{N}x{K}): grouped launch differs from the whole-K single launch"
+        ref = (Ab.view(torch.bfloat16).float()[:, :M].cpu().double().T @ Bb.view(torch.bfloat16).float()[:, :N].cpu().double()).float()
+        close(outs[i], ref + (0.5 if i == 2 else 0.0), 2e-4, 2e-4 * math.sqrt(K))
+    # a group too small to fill the chip is launched product by product: the default (split-K) result, bit for bit
+    few = [prob[0], prob[4]]                                  # 96 + 6 tiles
+    dflt = [ops.gemm_bf16_tt(Ab, Bb, M, N) for Ab, Bb, M, N, K in few]
+    got = [torch.empty(M, N, device="cuda") for _, _, M, N, _ in few]
+    with ops.tt_group():
+        for (Ab, Bb, M, N, K), C in zip(few, got):
+            ops.gemm_bf16_tt(Ab, Bb, M, N, C=C)
+    for a, b in zip(got, dflt):
+        assert torch.equal(a, b)
+    # the group is closed again after the block, and a second begin inside an open group is refused
+    with ops.tt_group():
+        with pytest.raises(RuntimeError, match="already open"):
+            ops.call("cst_gemm_bf16_tt_group_begin")
+    with pytest.raises(RuntimeError, match="no group is open"):
+        ops.call("cst_gemm_bf16_tt_group_end")
+
+
 def test_encoder_layer_bf16_tt_weight_grads_match_exact_mode(ops):
     """Token count % 64 == 0 switches the bf16 encoder layer to the transposed-read weight-gradient GEMM; its
     gradients must agree with the exact-fp32 layer to bf16 accuracy (relative Frobenius error)."""
