@@ -610,89 +610,92 @@ class GeneratorFn(torch.autograd.Function):
         dpre_t = act_bwd(dc, c0, 0.1)
         G["transfer.weight"] = wgrad(dpre_t, c_cat)
         dc_cat = dgrad(dpre_t, P["transfer.weight"])
-        # batched weight gradients of the decoder
-        if dlb_all is not None and (B * T) % 64 == 0 and V % 8 == 0 and Hd % 8 == 0:
-            G["fn_2.weight"] = ops.gemm_bf16_tt(dlb_all.view(B * T, Vp), r1b.view(B * T, Hd), V, Hd)   # dlogits^T r1, no transposes
-        else:
-            G["fn_2.weight"] = wgrad(dout.view(B * T, V), r1.view(B * T, Hd))
-        dp1 = dpre1.view(B * T, Hd)
-        tt_ok = use_b and (B * T) % 64 == 0 and E % 8 == 0            # weight gradients straight from the bf16 row-major copies
-        if tt_ok and dp1b_ok and ifdb is not None:
-            G["fn_1.weight"] = ops.gemm_bf16_tt(dp1b_all.view(B * T, Hd), ifdb.view(B * T, W_), Hd, W_)
-        else:
-            # (fp32 dropout(i_ffn): written by the per-step decode loop only -- every configuration the fast loop accepts takes the branch above)
-            G["fn_1.weight"] = wgrad(dp1, iffn_d.view(B * T, W_))
-        G["fn_1.bias"] = colsum(dp1)
-        dg2 = dgd.view(T * B, 4 * Hd)
-        if tt_ok and XHb is not None:
-            dwcat = ops.gemm_bf16_tt(dgdb_all.view(T * B, 4 * Hd), XHb.view(T * B, E + Hd), 4 * Hd, E + Hd)
-        else:
-            dwcat = wgrad(dg2, XH.view(T * B, E + Hd))
+        # every weight gradient taken straight from bf16 row-major twins (cst_gemm_bf16_tt: decoder fn_2 / fn_1 / gates, encoder W_hh / W_ih of both
+        # directions) is recorded here and launched as ONE grouped kernel when the block ends -- their outputs are defined only after it
+        with ops.tt_group():
+            # batched weight gradients of the decoder
+            if dlb_all is not None and (B * T) % 64 == 0 and V % 8 == 0 and Hd % 8 == 0:
+                G["fn_2.weight"] = ops.gemm_bf16_tt(dlb_all.view(B * T, Vp), r1b.view(B * T, Hd), V, Hd)   # dlogits^T r1, no transposes
+            else:
+                G["fn_2.weight"] = wgrad(dout.view(B * T, V), r1.view(B * T, Hd))
+            dp1 = dpre1.view(B * T, Hd)
+            tt_ok = use_b and (B * T) % 64 == 0 and E % 8 == 0            # weight gradients straight from the bf16 row-major copies
+            if tt_ok and dp1b_ok and ifdb is not None:
+                G["fn_1.weight"] = ops.gemm_bf16_tt(dp1b_all.view(B * T, Hd), ifdb.view(B * T, W_), Hd, W_)
+            else:
+                # (fp32 dropout(i_ffn): written by the per-step decode loop only -- every configuration the fast loop accepts takes the branch above)
+                G["fn_1.weight"] = wgrad(dp1, iffn_d.view(B * T, W_))
+            G["fn_1.bias"] = colsum(dp1)
+            dg2 = dgd.view(T * B, 4 * Hd)
+            if tt_ok and XHb is not None:
+                dwcat = ops.gemm_bf16_tt(dgdb_all.view(T * B, 4 * Hd), XHb.view(T * B, E + Hd), 4 * Hd, E + Hd)
+            else:
+                dwcat = wgrad(dg2, XH.view(T * B, E + Hd))
+            db = colsum(dg2)
+            G["decoder.bias_ih_l0"] = db
+            G["decoder.bias_hh_l0"] = db.clone()
+
+            # ---- encoder BPTT --------------------------------------------------------------------
+            dh0cat = _new(dev, B, 2 * H)
+            demb = _new(dev, B * Lp, E)
+            dmem2 = dmem.view(B, Lp * 2 * H)
+            dge = _new(dev, 2, B, Lp, 4 * H)
+            dhr2 = _new(dev, 2, B, H)
+            dce2 = _new(dev, 2, B, H)
+            dgtb2 = _i16(dev, 2, B, 4 * H) if use_b else None
+            encb = []
+            for d, suf in enumerate(("", "_reverse")):
+                w_ih, w_hh = P["encoder.weight_ih_l0" + suf], P["encoder.weight_hh_l0" + suf]
+                order = list(range(Lp)) if d == 0 else list(range(Lp - 1, -1, -1))
+                encb.append((w_ih, w_hh, weight_bf16(w_hh)[1] if use_b else None, order, dge[d].view(B, Lp * 4 * H)))   # whh_t [H, 4H]
+            seq_bwd = use_b and H == 256 and B % 16 == 0
+            enc_b = seq_bwd and embb is not None
+            dgeb = _i16(dev, 2, B * Lp, 4 * H) if enc_b else None
+            if seq_bwd:
+                # both directions, all steps, one launch (mirror of cst_lstm_seq_fwd)
+                call("cst_lstm_seq_bwd", _lstm_frag_order_t(encb[0][2], H), _lstm_frag_order_t(encb[1][2], H), genc[0], genc[1],
+                     cenc[0], cenc[1], c_cat, 2 * H, dc_cat, dc_cat.stride(0), dmem, dge[0], dge[1],
+                     dgeb[0] if enc_b else None, dgeb[1] if enc_b else None, dh0cat, 2 * H, B, Lp, H)
+            for n_ in (() if seq_bwd else range(Lp - 1, -1, -1)):
+                probs = []
+                for d, (w_ih, w_hh, whh_t, order, dg2d) in enumerate(encb):
+                    t = order[n_]
+                    lastf = n_ == Lp - 1
+                    c_new = c_cat[:, d * H:(d + 1) * H] if lastf else cenc[d, t]
+                    c_prev = zeros_c if n_ == 0 else cenc[d, order[n_ - 1]]
+                    dgt = dg2d[:, t * 4 * H:(t + 1) * 4 * H]
+                    dmt = dmem2[:, t * 2 * H + d * H: t * 2 * H + (d + 1) * H]
+                    dce = dce2[d]
+                    if use_b and not lastf:
+                        # dgtb2[d] holds dgates of the step after; the fused reduce overwrites it with this step's
+                        probs.append(dict(Ab=dgtb2[d], Bb=whh_t, gates=genc[d, t], c_prev=c_prev, c_new=c_new, dh_extra=dmt, dc_in=dce,
+                                          dgates=dgt, dc_prev=dce, dgb=dgtb2[d]))
+                        continue
+                    _cell_bwd(genc[d, t], c_prev, c_new, dmt, None if lastf else dhr2[d], dc_cat[:, d * H:(d + 1) * H] if lastf else dce,
+                              dgt, dce, B, H, dgb=dgtb2[d] if use_b else None)
+                    if not use_b:
+                        dgrad(dgt, w_hh, out=dh0cat[:, d * H:(d + 1) * H] if n_ == 0 else dhr2[d])
+                if probs:
+                    _gemm_cell_bwd(probs, B, H)
+            for d, (w_ih, w_hh, whh_t, order, dg2d) in enumerate(encb):
+                if use_b and not seq_bwd:
+                    gemm_bf16(dgtb2[d], whh_t, B, H, C=dh0cat[:, d * H:(d + 1) * H])
+                dgf = dge[d].view(B * Lp, 4 * H)
+                suf = "" if d == 0 else "_reverse"
+                if enc_b:
+                    # dgates^T [h_prev], dgates^T emb through transposed LDS reads of the row-major bf16 twins; d emb on the bf16 GEMM
+                    G["encoder.weight_hh_l0" + suf] = ops.gemm_bf16_tt(dgeb[d], hprevb[d].view(B * Lp, H), 4 * H, H)
+                    G["encoder.weight_ih_l0" + suf] = ops.gemm_bf16_tt(dgeb[d], embb, 4 * H, E)
+                    gemm_bf16(dgeb[d], weight_bf16(w_ih)[1], B * Lp, E, C=demb, accumulate=d == 1)
+                else:
+                    G["encoder.weight_hh_l0" + suf] = wgrad(dgf, hprev[d].view(B * Lp, H))
+                    G["encoder.weight_ih_l0" + suf] = wgrad(dgf, emb)
+                    dgrad(dgf, w_ih, out=demb, accumulate=d == 1)
+                dbe = colsum(dgf)
+                G["encoder.bias_ih_l0" + suf] = dbe
+                G["encoder.bias_hh_l0" + suf] = dbe.clone()
         G["decoder.weight_ih_l0"] = dwcat[:, :E].contiguous()
         G["decoder.weight_hh_l0"] = dwcat[:, E:].contiguous()
-        db = colsum(dg2)
-        G["decoder.bias_ih_l0"] = db
-        G["decoder.bias_hh_l0"] = db.clone()
-
-        # ---- encoder BPTT --------------------------------------------------------------------
-        dh0cat = _new(dev, B, 2 * H)
-        demb = _new(dev, B * Lp, E)
-        dmem2 = dmem.view(B, Lp * 2 * H)
-        dge = _new(dev, 2, B, Lp, 4 * H)
-        dhr2 = _new(dev, 2, B, H)
-        dce2 = _new(dev, 2, B, H)
-        dgtb2 = _i16(dev, 2, B, 4 * H) if use_b else None
-        encb = []
-        for d, suf in enumerate(("", "_reverse")):
-            w_ih, w_hh = P["encoder.weight_ih_l0" + suf], P["encoder.weight_hh_l0" + suf]
-            order = list(range(Lp)) if d == 0 else list(range(Lp - 1, -1, -1))
-            encb.append((w_ih, w_hh, weight_bf16(w_hh)[1] if use_b else None, order, dge[d].view(B, Lp * 4 * H)))   # whh_t [H, 4H]
-        seq_bwd = use_b and H == 256 and B % 16 == 0
-        enc_b = seq_bwd and embb is not None
-        dgeb = _i16(dev, 2, B * Lp, 4 * H) if enc_b else None
-        if seq_bwd:
-            # both directions, all steps, one launch (mirror of cst_lstm_seq_fwd)
-            call("cst_lstm_seq_bwd", _lstm_frag_order_t(encb[0][2], H), _lstm_frag_order_t(encb[1][2], H), genc[0], genc[1],
-                 cenc[0], cenc[1], c_cat, 2 * H, dc_cat, dc_cat.stride(0), dmem, dge[0], dge[1],
-                 dgeb[0] if enc_b else None, dgeb[1] if enc_b else None, dh0cat, 2 * H, B, Lp, H)
-        for n_ in (() if seq_bwd else range(Lp - 1, -1, -1)):
-            probs = []
-            for d, (w_ih, w_hh, whh_t, order, dg2d) in enumerate(encb):
-                t = order[n_]
-                lastf = n_ == Lp - 1
-                c_new = c_cat[:, d * H:(d + 1) * H] if lastf else cenc[d, t]
-                c_prev = zeros_c if n_ == 0 else cenc[d, order[n_ - 1]]
-                dgt = dg2d[:, t * 4 * H:(t + 1) * 4 * H]
-                dmt = dmem2[:, t * 2 * H + d * H: t * 2 * H + (d + 1) * H]
-                dce = dce2[d]
-                if use_b and not lastf:
-                    # dgtb2[d] holds dgates of the step after; the fused reduce overwrites it with this step's
-                    probs.append(dict(Ab=dgtb2[d], Bb=whh_t, gates=genc[d, t], c_prev=c_prev, c_new=c_new, dh_extra=dmt, dc_in=dce,
-                                      dgates=dgt, dc_prev=dce, dgb=dgtb2[d]))
-                    continue
-                _cell_bwd(genc[d, t], c_prev, c_new, dmt, None if lastf else dhr2[d], dc_cat[:, d * H:(d + 1) * H] if lastf else dce,
-                          dgt, dce, B, H, dgb=dgtb2[d] if use_b else None)
-                if not use_b:
-                    dgrad(dgt, w_hh, out=dh0cat[:, d * H:(d + 1) * H] if n_ == 0 else dhr2[d])
-            if probs:
-                _gemm_cell_bwd(probs, B, H)
-        for d, (w_ih, w_hh, whh_t, order, dg2d) in enumerate(encb):
-            if use_b and not seq_bwd:
-                gemm_bf16(dgtb2[d], whh_t, B, H, C=dh0cat[:, d * H:(d + 1) * H])
-            dgf = dge[d].view(B * Lp, 4 * H)
-            suf = "" if d == 0 else "_reverse"
-            if enc_b:
-                # dgates^T [h_prev], dgates^T emb through transposed LDS reads of the row-major bf16 twins; d emb on the bf16 GEMM
-                G["encoder.weight_hh_l0" + suf] = ops.gemm_bf16_tt(dgeb[d], hprevb[d].view(B * Lp, H), 4 * H, H)
-                G["encoder.weight_ih_l0" + suf] = ops.gemm_bf16_tt(dgeb[d], embb, 4 * H, E)
-                gemm_bf16(dgeb[d], weight_bf16(w_ih)[1], B * Lp, E, C=demb, accumulate=d == 1)
-            else:
-                G["encoder.weight_hh_l0" + suf] = wgrad(dgf, hprev[d].view(B * Lp, H))
-                G["encoder.weight_ih_l0" + suf] = wgrad(dgf, emb)
-                dgrad(dgf, w_ih, out=demb, accumulate=d == 1)
-            dbe = colsum(dgf)
-            G["encoder.bias_ih_l0" + suf] = dbe
-            G["encoder.bias_hh_l0" + suf] = dbe.clone()
         dstyle_e = ops.zeros_like(P["enc_style_embedding.weight"])
         embed_scatter_add(dstyle_e, dh0cat, ids_a=label_i)
         G["enc_style_embedding.weight"] = dstyle_e

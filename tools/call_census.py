@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Census of one bench step's calls into libcst_hip.so: per entry point and argument shape, with the Python call
-site (innermost frame outside ops.py/_lib.py).  Usage: tools/call_census.py [entry-point substring]"""
+site (innermost frame outside ops.py/_lib.py).  Usage: tools/call_census.py [entry-point substring] [workload]"""
 import collections, os, sys, traceback
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -8,7 +8,7 @@ import bench
 from consistent__style_transfer_amd import _lib
 
 pat = sys.argv[1] if len(sys.argv) > 1 else ""
-w = bench.WORKLOADS["yelp_4l_d512_b256"]
+w = bench.WORKLOADS[sys.argv[2] if len(sys.argv) > 2 else bench.HEADLINE]
 dev = torch.device("cuda:0")
 stages_ = bench.build_stages(w, dev)
 batches = bench.make_batches(w, 0, dev)
