@@ -460,7 +460,9 @@ __device__ __forceinline__ void bgemm_write_rows(const BGemmArgs& g, uint32_t ds
 // keeps the 128 x 128 tile's bytes per FLOP with sixteen DMA-issuing waves per CU instead of eight.
 // The body of one workgroup: `id` = its position in the XCD-ordered list of the product's output tiles, `by` = its K split, `bz` = which of
 // the two same-shape problems (A2 / B2).  Shared by the one-product kernel and the grouped weight-gradient kernel below.
-template <int BM, int BN, int NSTAGE, bool TT, bool BF8, int NW>
+// SLAB_THROUGH: the partial tile goes to the slab with device-scope stores (written through the XCD's L2), for a reader in ANOTHER workgroup
+// of the same launch (grouped weight gradients); otherwise plain stores, made visible by the end of the kernel.
+template <int BM, int BN, int NSTAGE, bool TT, bool BF8, int NW, bool SLAB_THROUGH = false>
 __device__ __forceinline__ void bgemm_tile_body(const BGemmArgs& g, const int id, const int by, const int bz) {
     static_assert(!(TT && BF8), "fp8 B operand: NT products only");
     constexpr int A_BYTES = BM * BROW, B_BYTES = BN * (BF8 ? 64 : BROW), ST_BYTES = A_BYTES + B_BYTES;
@@ -682,7 +684,10 @@ __device__ __forceinline__ void bgemm_tile_body(const BGemmArgs& g, const int id
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int m = m0 + wm * WMR + i * 16 + lq * 4 + r;
-                    if (m < g.M) slab[(long)m * g.N + n] = acc[i][j][r];
+                    if (m < g.M) {
+                        if constexpr (SLAB_THROUGH) __hip_atomic_store(&slab[(long)m * g.N + n], acc[i][j][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        else slab[(long)m * g.N + n] = acc[i][j][r];
+                    }
                 }
             }
         return;
@@ -743,9 +748,13 @@ __global__ __launch_bounds__(64 * NW) void cst_gemm_bf16_kernel(BGemmArgs g) {
 // 193.6 -> 128.7 us for the Matcher's layer, 119.5 -> 68.9 us for the MLM's).  The workgroups of the launch are numbered through the
 // problems in order; each finds its problem from the prefix sums of the tile counts and runs the one-product body on it.
 #define CST_TT_GROUP_MAX 8
-struct BTtProblem { const bf16_t* A; const bf16_t* B; float* C; long lda, ldb, ldc; int M, N, K, accumulate; };
-struct BTtGroup { BTtProblem p[CST_TT_GROUP_MAX]; int start[CST_TT_GROUP_MAX + 1]; int n; };
+struct BTtProblem { const bf16_t* A; const bf16_t* B; float* C; long lda, ldb, ldc; int M, N, K, accumulate; float* slab; int kps; int cvec; };
+struct BTtGroup { BTtProblem p[CST_TT_GROUP_MAX]; int start[CST_TT_GROUP_MAX + 1]; int n; int splits; int* counters; };
 
+// splits == 1: one workgroup per output tile, the whole contraction.  splits = S > 1 (fewer tiles than fill the CUs twice over): S
+// workgroups per tile, each writes its partial tile to the problem's slab, and the one that finishes LAST (a counter per tile, no
+// waiting) adds the S partials in split order and writes C -- the sum does not depend on which workgroup that is.  The counter is
+// left at zero for the next launch.
 __global__ __launch_bounds__(256) void cst_gemm_bf16_tt_group_kernel(BTtGroup q) {
     const int id = bgemm_xcd_order(blockIdx.x, gridDim.x);
     int p = 0;
@@ -753,11 +762,59 @@ __global__ __launch_bounds__(256) void cst_gemm_bf16_tt_group_kernel(BTtGroup q)
     for (int i = 1; i < CST_TT_GROUP_MAX; ++i)
         if (i < q.n && id >= q.start[i]) p = i;
     const BTtProblem& t = q.p[p];
+    const int S = q.splits;
+    const int local = id - q.start[p];
+    const int tile = S > 1 ? local / S : local, by = local - tile * S;
     BGemmArgs g{};                                   // everything the weight gradients do not use is a compile-time null / zero here
     g.A = t.A; g.B = t.B; g.C = t.C; g.lda = t.lda; g.ldb = t.ldb; g.ldc = t.ldc;
     g.M = t.M; g.N = t.N; g.K = t.K; g.accumulate = t.accumulate;
-    g.alpha = 1.f; g.gate_scale = 1.f; g.splits = 1; g.k_per_split = t.K;
-    bgemm_tile_body<128, 128, 2, true, false, 4>(g, id - q.start[p], 0, 0);
+    g.alpha = 1.f; g.gate_scale = 1.f; g.splits = S; g.k_per_split = t.kps; g.slab = t.slab;
+    if (S == 1) {
+        bgemm_tile_body<128, 128, 2, true, false, 4>(g, tile, 0, 0);
+        return;
+    }
+    bgemm_tile_body<128, 128, 2, true, false, 4, true>(g, tile, by, 0);
+    __shared__ int last_s;
+    // the partial tile was written with device-scope stores: once they have completed (no cache to write back: a release fence here would
+    // flush the XCD's whole L2, 0.2 us per workgroup -- measured) ...
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                                 // ... for every thread of the workgroup, the workgroup is counted
+    int* ctr = q.counters + (q.start[p] / S + tile);
+    if (threadIdx.x == 0) {
+        const int seen = atomicAdd(ctr, 1);
+        last_s = seen == S - 1;
+        if (seen == S - 1) *ctr = 0;                 // nobody else touches the counter any more in this launch
+    }
+    __syncthreads();
+    if (!last_s) return;
+    // the tile's origin, as bgemm_tile_body finds it
+    const int tilesM = (t.M + 127) / 128, tilesN = (t.N + 127) / 128;
+    const int GN = 8, grp = tile / (GN * tilesM), gw = min(GN, tilesN - grp * GN), loc = tile - grp * GN * tilesM;
+    const int m0 = (loc / gw) * 128, n0 = (grp * GN + loc % gw) * 128;
+    const long MN = (long)t.M * t.N;
+#pragma unroll 4
+    for (int e = threadIdx.x; e < 128 * 32; e += 256) {          // 128 rows x 32 column quads
+        const int m = m0 + (e >> 5), n = n0 + ((e & 31) << 2);
+        if (m >= t.M || n >= t.N) continue;                       // (N is a multiple of 8: a quad is inside or outside as a whole)
+        const float* sp = t.slab + (long)m * t.N + n;
+        auto ld4 = [](const float* a) {               // device-scope loads: from memory, never a stale line of this XCD's L2
+            return make_float4(__hip_atomic_load(a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), __hip_atomic_load(a + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
+                               __hip_atomic_load(a + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), __hip_atomic_load(a + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        };
+        float4 v = ld4(sp);
+        for (int k = 1; k < S; ++k) {
+            const float4 w = ld4(sp + k * MN);
+            v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w;
+        }
+        float* cp = t.C + (long)m * t.ldc + n;
+        if (t.cvec) {
+            if (t.accumulate) { const float4 o = *reinterpret_cast<const float4*>(cp); v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
+            *reinterpret_cast<float4*>(cp) = v;
+        } else {
+            if (t.accumulate) { v.x += cp[0]; v.y += cp[1]; v.z += cp[2]; v.w += cp[3]; }
+            cp[0] = v.x; cp[1] = v.y; cp[2] = v.z; cp[3] = v.w;
+        }
+    }
 }
 
 // BATCH: four slab loads in flight at a time (same summation order).  A runtime-bounded loop of one load and one dependent
@@ -1545,14 +1602,24 @@ extern "C" int cst_gemm_bf16_argmax(const void* A, long lda, const void* B, long
 // ---- grouped weight gradients: cst_gemm_bf16_tt calls between _group_begin and _group_end are collected (per host thread) and
 // launched together by _group_end.  A group whose tiles would not fill the chip is launched product by product, as without a group.
 struct TtDeferred { BTtProblem p; int splitk; float* ws; long ws_floats; };
-static thread_local struct { bool open; int n; TtDeferred d[CST_TT_GROUP_MAX]; } tt_group = {false, 0, {}};
+static thread_local struct { bool open; int n; TtDeferred d[CST_TT_GROUP_MAX]; int* counters; int ncounters; int last_splits; } tt_group = {false, 0, {}, nullptr, 0, 0};
 
 static int tt_single(const void* A, long lda, const void* B, long ldb, float* C, long ldc, int M, int N, int K,
                      int accumulate, int splitk, float* workspace, long workspace_floats, void* stream);
 
-static int tt_group_min_tiles() {
-    static const int v = [] { const char* e = getenv("CST_TT_GROUP_MIN"); return e ? atoi(e) : 224; }();     // 0: never group
-    return v;
+static int tt_group_env(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
+static int tt_group_min_tiles() { static const int v = tt_group_env("CST_TT_GROUP_MIN", 224); return v; }     // 0: never group
+static int tt_group_forced_splits() { static const int v = tt_group_env("CST_TT_GROUP_SPLITS", 0); return v; }   // 0: the rule below
+
+// K splits of a grouped launch (tools/tt_group_probe.py, CST_TT_GROUP_SPLITS = 1 / 2 / 3).  Two workgroups fit a CU and a CU with two
+// runs 1.6x as fast as a CU with one, so a group of up to 256 tiles (the d = 512 layers: 192) runs S = 2 workgroups per tile, all
+// resident at once: 107 -> 83 us (9216 tokens), 405 -> 299 us (30720).  Above that the partial-tile round trip through memory costs
+// more than the better balance returns (336 tiles, 9216 tokens: 135 us whole-K, 163 us with S = 2, 169 us with S = 3).
+static int tt_group_splits(long tiles, int kmin, long sum_mn, long ws_floats, int ncounters) {
+    const int forced = tt_group_forced_splits();
+    const int S = forced > 0 ? forced : (2 * tiles <= 512 ? 2 : 1);
+    if (S <= 1 || S > 4 || S * sum_mn > ws_floats || tiles > ncounters || kmin / S < 1024) return 1;
+    return S;
 }
 
 static int tt_group_flush(hipStream_t st) {
@@ -1560,25 +1627,32 @@ static int tt_group_flush(hipStream_t st) {
     tt_group.n = 0;
     if (n == 0) return CST_OK;
     BTtGroup q{};
-    long tiles = 0;
+    long tiles = 0, sum_mn = 0;
     double flops = 0, bytes = 0;
+    int kmax = 0, kmin = 0x7fffffff;
+    bool one_ws = true;
     for (int i = 0; i < n; ++i) {
         const BTtProblem& t = tt_group.d[i].p;
         q.p[i] = t;
-        q.start[i] = (int)tiles;
         tiles += (long)cst_div_up(t.M, 128) * cst_div_up(t.N, 128);
+        sum_mn += (long)t.M * t.N;
         flops += 2.0 * t.M * t.N * t.K;
         bytes += 2.0 * ((double)t.M * t.K + (double)t.N * t.K) + 4.0 * t.M * t.N;
+        kmax = t.K > kmax ? t.K : kmax;
+        kmin = t.K < kmin ? t.K : kmin;
+        one_ws = one_ws && tt_group.d[i].ws == tt_group.d[0].ws && tt_group.d[i].ws_floats == tt_group.d[0].ws_floats;
     }
-    q.start[n] = (int)tiles; q.n = n;
-    // whole-K workgroups need enough tiles to occupy the CUs: 336 tiles (d = 768 layers) always win; 192 tiles (d = 512) win while the
-    // contraction is short (9216 tokens: 127 -> 102 us, 4608: 90 -> 54, 15360: 186 -> 176) and lose to per-product split-K when it is
-    // long (30720 tokens: 344 -> 399 us) -- tools/tt_group_probe.py
+    // whole-K workgroups need enough tiles to occupy the CUs: 336 tiles (d = 768 layers) always win; 192 tiles (d = 512) with whole-K
+    // workgroups win while the contraction is short (9216 tokens: 127 -> 102 us, 4608: 90 -> 54, 15360: 186 -> 176) and lose to
+    // per-product split-K when it is long (30720 tokens: 344 -> 399 us); with two workgroups per tile they win throughout (see
+    // tt_group_splits) -- tools/tt_group_probe.py
     const int min_tiles = tt_group_min_tiles();
-    int kmax = 0;
-    for (int i = 0; i < n; ++i) kmax = q.p[i].K > kmax ? q.p[i].K : kmax;
-    const bool fills = tiles >= min_tiles || (min_tiles == 224 && tiles >= 160 && kmax <= 16384);
+    float* ws = tt_group.d[0].ws;
+    const int S = (one_ws && ws && tt_group.counters && (((uintptr_t)ws) & 15) == 0)
+                      ? tt_group_splits(tiles, kmin, sum_mn, tt_group.d[0].ws_floats, tt_group.ncounters) : 1;
+    const bool fills = tiles >= min_tiles || (min_tiles == 224 && ((S == 2 && tiles >= 128) || (tiles >= 160 && kmax <= 16384)));
     if (n == 1 || min_tiles <= 0 || !fills) {
+        tt_group.last_splits = 0;
         for (int i = 0; i < n; ++i) {
             const TtDeferred& d = tt_group.d[i];
             const int rc = tt_single(d.p.A, d.p.lda, d.p.B, d.p.ldb, d.p.C, d.p.ldc, d.p.M, d.p.N, d.p.K, d.p.accumulate, d.splitk, d.ws, d.ws_floats, st);
@@ -1586,6 +1660,18 @@ static int tt_group_flush(hipStream_t st) {
         }
         return CST_OK;
     }
+    tt_group.last_splits = S;
+    long items = 0, off = 0;
+    for (int i = 0; i < n; ++i) {
+        BTtProblem& t = q.p[i];
+        q.start[i] = (int)items;
+        items += (long)cst_div_up(t.M, 128) * cst_div_up(t.N, 128) * S;
+        t.kps = S > 1 ? cst_div_up(cst_div_up(t.K, S), 64) * 64 : t.K;        // (S - 1) kps < K: K >= 1024 S
+        t.slab = S > 1 ? ws + off : nullptr;
+        t.cvec = (((uintptr_t)t.C) & 15) == 0 && t.ldc % 4 == 0;
+        off += S * (long)t.M * t.N;
+    }
+    q.start[n] = (int)items; q.n = n; q.splits = S; q.counters = tt_group.counters;
     constexpr size_t lds = 2 * (128 * BROW + 128 * BROW);
     static CstPerDevice attr_done;
     if (lds > 64 * 1024 && cst_first_on_device(attr_done))
@@ -1595,19 +1681,23 @@ static int tt_group_flush(hipStream_t st) {
         (void)hipEventCreate(&ea); (void)hipEventCreate(&eb);
         // recorded as ONE product [sum of M_p N_p / 128] x 128 over the first problem's K (bench.py labels the 128-column TT shape a group)
         cst_prof_push_shape(ea, eb, flops, bytes, 1, (int)(flops / (256.0 * q.p[0].K)), 128, -q.p[0].K);
-        hipExtLaunchKernelGGL(cst_gemm_bf16_tt_group_kernel, dim3((unsigned)tiles), dim3(256), lds, st, ea, eb, 0, q);
+        hipExtLaunchKernelGGL(cst_gemm_bf16_tt_group_kernel, dim3((unsigned)items), dim3(256), lds, st, ea, eb, 0, q);
     } else {
-        hipLaunchKernelGGL(cst_gemm_bf16_tt_group_kernel, dim3((unsigned)tiles), dim3(256), lds, st, q);
+        hipLaunchKernelGGL(cst_gemm_bf16_tt_group_kernel, dim3((unsigned)items), dim3(256), lds, st, q);
     }
     CST_LAUNCH_CHECK("cst_gemm_bf16_tt_group");
     return CST_OK;
 }
 
-extern "C" int cst_gemm_bf16_tt_group_begin(void* /*stream: the products are launched by _group_end, on ITS stream*/) {
+extern "C" int cst_gemm_bf16_tt_group_begin(int* counters, int ncounters, void* /*stream: the products are launched by _group_end, on ITS stream*/) {
     CST_REQUIRE(!tt_group.open, "cst_gemm_bf16_tt_group_begin: a group is already open on this thread");
-    tt_group.open = true; tt_group.n = 0;
+    CST_REQUIRE(ncounters >= 0 && (counters || ncounters == 0), "cst_gemm_bf16_tt_group_begin: %d counters at a null address", ncounters);
+    tt_group.open = true; tt_group.n = 0; tt_group.counters = counters; tt_group.ncounters = counters ? ncounters : 0;
     return CST_OK;
 }
+
+/* how the last group of this thread was launched: 0 = product by product, S >= 1 = one kernel with S workgroups per tile */
+extern "C" int cst_gemm_bf16_tt_group_last_splits(void) { return tt_group.last_splits; }
 
 extern "C" int cst_gemm_bf16_tt_group_end(void* stream) {
     CST_REQUIRE(tt_group.open, "cst_gemm_bf16_tt_group_end: no group is open on this thread");
@@ -1628,7 +1718,7 @@ extern "C" int cst_gemm_bf16_tt(const void* A, long lda, const void* B, long ldb
             if (rc != CST_OK) return rc;
         }
         TtDeferred& d = tt_group.d[tt_group.n++];
-        d.p = BTtProblem{(const bf16_t*)A, (const bf16_t*)B, C, lda, ldb, ldc, M, N, K, accumulate};
+        d.p = BTtProblem{(const bf16_t*)A, (const bf16_t*)B, C, lda, ldb, ldc, M, N, K, accumulate, nullptr, K, 0};
         d.splitk = splitk; d.ws = workspace; d.ws_floats = workspace_floats;
         return CST_OK;
     }

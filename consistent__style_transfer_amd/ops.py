@@ -168,7 +168,8 @@ def _f32(t):
 # =============================================================================================
 _WS = {}
 LSTM_SPLITK = 2                      # split-K of the fused gate GEMM + LSTM cell (measured best of 0..4 on the bench step)
-WS_FLOATS = 16 * 1024 * 1024         # 64 MiB split-K slab workspace per device
+WS_FLOATS = 32 * 1024 * 1024         # 128 MiB split-K slab workspace per device
+WS_COUNTERS = 4096
 
 
 _LANE = [0]          # which concurrent branch of a step is issuing work (stages.Fork sets it)
@@ -185,7 +186,8 @@ def _workspace(dev):
     key = (dev, _LANE[0])
     ws = _WS.get(key)
     if ws is None:
-        ws = _WS[key] = torch.empty(WS_FLOATS, device=dev, dtype=torch.float32)
+        # WS_FLOATS of slab space + WS_COUNTERS zero words behind it (the per-tile arrival counters of grouped launches: tt_group)
+        ws = _WS[key] = torch.zeros(WS_FLOATS + WS_COUNTERS, device=dev, dtype=torch.float32)
     return ws
 
 
@@ -348,7 +350,8 @@ class tt_group:
     are defined only after the block; operands must stay alive until then (they are locals of the calling backward)."""
 
     def __enter__(self):
-        call("cst_gemm_bf16_tt_group_begin")
+        dev = torch.device("cuda", torch.cuda.current_device())
+        call("cst_gemm_bf16_tt_group_begin", _workspace(dev)[WS_FLOATS:], WS_COUNTERS)
         return self
 
     def __exit__(self, *exc):

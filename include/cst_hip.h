@@ -264,14 +264,19 @@ int cst_gemm_bf16_tt(const void* A, long lda, const void* B, long ldb, float* C,
 long cst_gemm_bf16_tt_workspace_floats(int M, int N, int K, int splitk);
 /* Grouped weight gradients.  Between _group_begin and _group_end (same host thread) cst_gemm_bf16_tt calls with splitk <= 1 only
  * RECORD their product; _group_end launches all of them as ONE kernel whose workgroups are numbered through the problems' 128 x 128
- * output tiles (up to 8 problems per launch; more are launched in batches of 8), each workgroup running the whole contraction: the
- * four dW of an encoder layer (backward of mlm.py:20-24, match.py:18-22) have 36-108 tiles each -- one by one they need split-K slabs
- * and a reduce launch each to fill 256 CUs, together (336 tiles) they do not.  A group with fewer than CST_TT_GROUP_MIN (env, default
- * 224, or 160 when no contraction is longer than 16384; 0 = never group) tiles in total is launched product by product exactly as
- * without a group.  Operands and outputs must stay
- * alive and unchanged until _group_end returns; results are defined only after it.  _group_end always closes the group. */
-int cst_gemm_bf16_tt_group_begin(void* stream);
+ * output tiles (up to 8 problems per launch; more are launched in batches of 8): the four dW of an encoder layer (backward of
+ * mlm.py:20-24, match.py:18-22) have 36-108 tiles each -- one by one they need split-K slabs and a reduce launch each to fill 256
+ * CUs, together (336 tiles) they do not.  A group of at most 256 tiles (d = 512 layers: 192) splits every contraction in two: two
+ * workgroups per tile write partial tiles to the recorded calls' workspace and the one that finishes last (one counter per tile,
+ * nobody waits) adds them in split order -- no second launch, the same sum whichever workgroup that is.
+ *   counters: ncounters ints, ZERO when the group is launched; the kernel leaves them zero.  null: whole-K workgroups only.
+ * A group with fewer than 128 tiles in total (env CST_TT_GROUP_MIN overrides the rule; 0 = never group) is launched product by
+ * product exactly as without a group.  Operands and outputs must stay alive and unchanged
+ * until _group_end returns; results are defined only after it.  _group_end always closes the group. */
+int cst_gemm_bf16_tt_group_begin(int* counters, int ncounters, void* stream);
 int cst_gemm_bf16_tt_group_end(void* stream);
+/* diagnostics: how this thread's last group was launched -- 0 product by product, S >= 1 one kernel with S workgroups per tile */
+int cst_gemm_bf16_tt_group_last_splits(void);
 
 /* All L time steps of both directions of the BiLSTM encoder (rnn.py:25-27, called at rnn.py:57, :62) in ONE launch: a
  * workgroup takes 16 batch rows of one direction through the whole sequence (recurrences are independent across batch

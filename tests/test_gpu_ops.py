@@ -946,9 +946,42 @@ def test_gemm_bf16_tt_group_equals_whole_k_products_bit_for_bit(ops):
     # the group is closed again after the block, and a second begin inside an open group is refused
     with ops.tt_group():
         with pytest.raises(RuntimeError, match="already open"):
-            ops.call("cst_gemm_bf16_tt_group_begin")
+            ops.call("cst_gemm_bf16_tt_group_begin", None, 0)
     with pytest.raises(RuntimeError, match="no group is open"):
         ops.call("cst_gemm_bf16_tt_group_end")
+
+
+def test_gemm_bf16_tt_group_split_contraction_sums_partials_in_split_order(ops):
+    """The weight gradients of one d = 512 encoder layer are 192 tiles: the grouped launch splits every contraction S ways (S workgroups a
+    tile; the one that finishes last adds the partial tiles in split order and leaves the tile's counter at zero).  Whatever S the rule
+    picks, every output must equal, bit for bit, the fp32 sum in split order of the whole-K products over the S row ranges -- on every
+    one of several launches (the counters are reused), with an accumulating output among them."""
+    from consistent__style_transfer_amd._lib import call_plain
+    d, F, K = 512, 2048, 4608
+    shapes = [(d, F), (F, d), (d, d), (3 * d, d)]
+    prob = []
+    for i, (M, N) in enumerate(shapes):
+        prob.append((ops.cast_bf16(dev(rnd(K, M, seed=70 + i, scale=0.5)), want_t=False)[0], ops.cast_bf16(dev(rnd(K, N, seed=80 + i, scale=0.5)), want_t=False)[0], M, N))
+    outs = None
+    for rep in range(3):
+        outs = [torch.full((M, N), 0.25, device="cuda") if i == 1 else torch.full((M, N), float("nan"), device="cuda") for i, (_, _, M, N) in enumerate(prob)]
+        with ops.tt_group():
+            for i, (Ab, Bb, M, N) in enumerate(prob):
+                ops.gemm_bf16_tt(Ab, Bb, M, N, C=outs[i], accumulate=i == 1)
+        S = call_plain("cst_gemm_bf16_tt_group_last_splits")
+        assert S >= 2, f"expected a split contraction for 192 tiles (got {S}); CST_TT_GROUP_SPLITS / CST_TT_GROUP_MIN set?"
+        kps = -(-(-(-K // S)) // 64) * 64
+        for i, (Ab, Bb, M, N) in enumerate(prob):
+            want = None
+            for s_ in range(S):
+                k0, k1 = s_ * kps, min(K, (s_ + 1) * kps)
+                part = ops.gemm_bf16_tt(Ab[k0:k1], Bb[k0:k1], M, N, splitk=1)
+                want = part if want is None else want + part
+            if i == 1:
+                want = want + 0.25
+            assert torch.equal(outs[i], want), f"launch {rep}, problem {i}: the {S}-way split sum is not the in-order sum of its partial products"
+    ws = ops._workspace(outs[0].device)
+    assert int((ws[ops.WS_FLOATS:] != 0).sum()) == 0, "the tile counters were not left at zero"
 
 
 def test_encoder_layer_bf16_tt_weight_grads_match_exact_mode(ops):

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """The weight gradients of one encoder layer (dW of FFN2, FFN1, out-projection, QKV: C = A^T B over the token count), launched one by one
 (split-K slabs + a reduce each) against ONE grouped launch of whole-K workgroups (cst_gemm_bf16_tt_group_*, ops.tt_group).
-    python tools/tt_group_probe.py            (CST_TT_GROUP_MIN=1 to force grouping of the small-d layers too)"""
+    python tools/tt_group_probe.py            (CST_TT_GROUP_MIN=1 to force grouping of the small-d layers too, CST_TT_GROUP_SPLITS=S to force S workgroups per tile)"""
 import os
 import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -48,6 +48,8 @@ for T, d, F, note in ((9216, 768, 2048, "Matcher d768"), (4608, 768, 2048, "MLM 
             four()
 
     t4, tg = timeit(four), timeit(grouped)
+    from consistent__style_transfer_amd._lib import call_plain
+    S = call_plain("cst_gemm_bf16_tt_group_last_splits")
     fl = 2.0 * T * (2 * d * F + 4 * d * d)
     tiles = 2 * (-(-d // 128)) * (F // 128) + (-(-d // 128)) ** 2 + (-(-3 * d // 128)) * (-(-d // 128))
-    print(f"{note:16s} T={T:6d} d={d} ({tiles} tiles): one by one {t4:7.1f} us ({fl / t4 / 1e6:4.0f} TF/s)   grouped {tg:7.1f} us ({fl / tg / 1e6:4.0f} TF/s)", flush=True)
+    print(f"{note:16s} T={T:6d} d={d} ({tiles} tiles): one by one {t4:7.1f} us ({fl / t4 / 1e6:4.0f} TF/s)   grouped {tg:7.1f} us ({fl / tg / 1e6:4.0f} TF/s, {S} split{'s' if S != 1 else ''})", flush=True)
