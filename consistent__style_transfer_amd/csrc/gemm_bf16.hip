@@ -73,11 +73,11 @@ __global__ __launch_bounds__(256) void cast_bf16_kernel(const void* __restrict__
 
 // fp32 input without dropout, everything 4-element aligned (every weight and activation of the module constants): float4
 // loads all in flight, 8-byte stores for both images, the transposed one gathered from LDS four rows at a time.
-__global__ __launch_bounds__(256) void cast_bf16_vec_kernel(const float* __restrict__ x, long ldx, int R, int C,
-                                                            bf16_t* __restrict__ out, long ldo, int Cp,
-                                                            bf16_t* __restrict__ out_t, long ldot, int Rp) {
+__device__ __forceinline__ void cast_bf16_vec_tile(const float* __restrict__ x, long ldx, int R, int C,
+                                                   bf16_t* __restrict__ out, long ldo, int Cp,
+                                                   bf16_t* __restrict__ out_t, long ldot, int Rp, const int bx, const int by) {
     __shared__ __attribute__((aligned(8))) bf16_t tile[64][68];
-    const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+    const int r0 = by * 64, c0 = bx * 64;
     float4 v[4];
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
@@ -113,6 +113,55 @@ __global__ __launch_bounds__(256) void cast_bf16_vec_kernel(const float* __restr
             *reinterpret_cast<uint2*>(out_t + (long)c * ldot + r) = u;
         }
     }
+}
+
+__global__ __launch_bounds__(256) void cast_bf16_vec_kernel(const float* __restrict__ x, long ldx, int R, int C,
+                                                            bf16_t* __restrict__ out, long ldo, int Cp,
+                                                            bf16_t* __restrict__ out_t, long ldot, int Rp) {
+    cast_bf16_vec_tile(x, ldx, R, C, out, ldo, Cp, out_t, ldot, Rp, blockIdx.x, blockIdx.y);
+}
+
+// Many matrices in one launch (cst_cast_bf16_multi: the bf16 twins of every trained weight of an optimizer group, once per optimizer
+// step): the jobs ride in the kernel arguments, a block finds its job from the running block counts.
+#define CST_CAST_MULTI_MAX 40
+struct CastJob { const float* x; bf16_t* out; bf16_t* out_t; int ldx, ldo, ldot, R, C, gx, start; };
+struct CastJobs { CastJob j[CST_CAST_MULTI_MAX]; int n; };
+
+__global__ __launch_bounds__(256) void cast_bf16_multi_kernel(CastJobs q) {
+    int k = 0;
+    for (int i = 1; i < q.n; ++i)
+        if ((int)blockIdx.x >= q.j[i].start) k = i;
+    const CastJob& j = q.j[k];
+    const int local = blockIdx.x - j.start;
+    cast_bf16_vec_tile(j.x, j.ldx, j.R, j.C, j.out, j.ldo, j.out ? j.ldo : j.C, j.out_t, j.ldot, j.out_t ? j.ldot : j.R, local % j.gx, local / j.gx);
+}
+
+/* table: n rows of 8 host int64 words {x, ldx, R, C, out, ldo, out_t, ldot} -- the arguments of n cst_cast_bf16 calls on fp32 inputs
+ * without dropout, every one of which must qualify for the vector kernel (C, ldx, ldo, ldot multiples of 4; x 16-byte, outputs 8-byte aligned) */
+extern "C" int cst_cast_bf16_multi(const long* table, int n, void* stream) {
+    CST_REQUIRE(table && n > 0, "cst_cast_bf16_multi: empty table");
+    hipStream_t st = (hipStream_t)stream;
+    for (int base = 0; base < n; base += CST_CAST_MULTI_MAX) {
+        CastJobs q{};
+        q.n = n - base < CST_CAST_MULTI_MAX ? n - base : CST_CAST_MULTI_MAX;
+        long blocks = 0;
+        for (int i = 0; i < q.n; ++i) {
+            const long* t = table + (long)(base + i) * 8;
+            const void* x = (const void*)t[0]; const long ldx = t[1]; const long R = t[2], C = t[3];
+            void* out = (void*)t[4]; const long ldo = t[5]; void* out_t = (void*)t[6]; const long ldot = t[7];
+            CST_REQUIRE(x && (out || out_t) && R > 0 && C > 0 && ldx >= C && (!out || ldo >= C) && (!out_t || ldot >= R) && ldx < (1L << 31) && ldo < (1L << 31) && ldot < (1L << 31),
+                        "cst_cast_bf16_multi: job %d: bad arguments", base + i);
+            CST_REQUIRE(C % 4 == 0 && ldx % 4 == 0 && (((uintptr_t)x) & 15) == 0 && (!out || (ldo % 4 == 0 && (((uintptr_t)out) & 7) == 0)) &&
+                        (!out_t || (ldot % 4 == 0 && (((uintptr_t)out_t) & 7) == 0)), "cst_cast_bf16_multi: job %d does not qualify for the vector kernel", base + i);
+            const long Cp = out ? ldo : C, Rp = out_t ? ldot : R;
+            const int gx = cst_div_up((int)(Cp > C ? Cp : C), 64), gy = cst_div_up((int)(Rp > R ? Rp : R), 64);
+            q.j[i] = CastJob{(const float*)x, (bf16_t*)out, (bf16_t*)out_t, (int)ldx, (int)ldo, (int)ldot, (int)R, (int)C, gx, (int)blocks};
+            blocks += (long)gx * gy;
+        }
+        hipLaunchKernelGGL(cast_bf16_multi_kernel, dim3((unsigned)blocks), dim3(256), 0, st, q);
+        CST_LAUNCH_CHECK("cst_cast_bf16_multi");
+    }
+    return CST_OK;
 }
 
 extern "C" int cst_cast_bf16(const void* x, int x_is_bf16, long ldx, int R, int C,

@@ -175,7 +175,7 @@ def probe_split():
 def _lstm_frag_order(wb, H):
     """bf16 W_hh [4H, H] (K contiguous) -> the MFMA-fragment order cst_lstm_seq_fwd streams:
     [wave][gate][tile][k step][lane = 16 lq + lr][8], element = W_hh[q*H + 64w + 16j + lr][32kk + 8lq + e]."""
-    hit = getattr(wb, "_cst_frag", None)          # the bf16 copy lives as long as its optimizer version (ops.weight_bf16): so does its re-ordering
+    hit = getattr(wb, "_cst_frag", None)          # parked on the bf16 twin: ops.weight_bf16 drops every _cst_* attribute when it rewrites the twin
     if hit is None:
         v = wb[:, :H].reshape(4, 4, H // 64, 16, H // 32, 4, 8)       # (q, w, j, lr, kk, lq, e)
         hit = wb._cst_frag = v.permute(1, 0, 2, 4, 5, 3, 6).contiguous()   # (w, q, j, kk, lq, lr, e)

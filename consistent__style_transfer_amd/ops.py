@@ -243,6 +243,10 @@ def weight_bf16(W):
     capture they are shared between the uses that see the same optimizer version."""
     grp = getattr(W, "_cst_group", None)
     capturing = torch.cuda.is_current_stream_capturing()
+    if grp is not None and W.is_cuda:
+        hit = _group_twins(grp, W, capturing)
+        if hit is not None:
+            return hit
     ver = (W._version, grp.version if grp is not None else 0, W.data_ptr(), tuple(W.shape))
     key = id(W)
     if grp is not None and capturing:
@@ -261,6 +265,64 @@ def weight_bf16(W):
     if not capturing:                                # never cache tensors that live in a graph's private pool
         _WCACHE[key] = (weakref.ref(W, lambda _r, k=key: _WCACHE.pop(k, None)), ver, rm, tr)
     return rm, tr
+
+
+_CAPTURE_EPOCH = [0]          # bumped around every hipGraph capture (capture_scope_reset)
+
+
+class _GroupTwins:
+    """The bf16 twins (row-major + transposed) of the trained weights of ONE optimizer group (optim.FlatGroup), in persistent buffers
+    refreshed by ONE launch (cst_cast_bf16_multi) at the first use after every optimizer step of the group -- instead of one cast
+    launch per weight and step.  A weight joins at its first eager use.  Inside a hipGraph capture the refresh is issued at the first
+    use of the capture whatever the state outside says: the replays must redo it after every captured Adam step."""
+
+    def __init__(self):
+        self.ent = {}               # id(W) -> [weakref, rm, tr, data_ptr, W._version at the last refresh, key of the last refresh]
+        self.table = None
+
+    def key(self, grp, capturing):
+        return ("capture", _CAPTURE_EPOCH[0], grp.version) if capturing else ("eager", grp.version)
+
+    def refresh(self, key):
+        dead = [k for k, e in self.ent.items() if e[0]() is None]
+        for k in dead:
+            del self.ent[k]
+            self.table = None
+        live = list(self.ent.values())
+        if self.table is None or self.table.shape[0] != len(live):
+            rows = []
+            for e in live:
+                W, rm, tr = e[0](), e[1], e[2]
+                rows.append([W.data_ptr(), _ld(W), W.shape[0], W.shape[1], rm.data_ptr(), rm.stride(0), tr.data_ptr(), tr.stride(0)])
+            self.table = torch.tensor(rows, dtype=torch.int64)
+        call("cst_cast_bf16_multi", self.table, len(live))
+        for e in live:
+            e[4], e[5] = e[0]()._version, key
+            for t in (e[1], e[2]):                  # whatever callers derived from the old contents and parked on the twin (gen_fn._lstm_frag_order)
+                for a in [a for a in t.__dict__ if a.startswith("_cst_")]:
+                    del t.__dict__[a]
+
+
+def _group_twins(grp, W, capturing):
+    tw = getattr(grp, "_bf16_twins", None)
+    if tw is None:
+        tw = grp._bf16_twins = _GroupTwins()
+    key = tw.key(grp, capturing)
+    e = tw.ent.get(id(W))
+    if e is not None and (e[0]() is not W or e[3] != W.data_ptr() or tuple(e[1].shape) != (W.shape[0], _up64(W.shape[1]))):
+        del tw.ent[id(W)]           # a recycled id() or re-laid-out storage: register again
+        tw.table, e = None, None
+    if e is None:
+        if (capturing or W.dim() != 2 or W.stride(1) != 1 or W.shape[1] % 4 or W.stride(0) % 4 or W.data_ptr() % 16
+                or W.dtype != torch.float32):
+            return None             # (the per-weight path: nothing persistent may be allocated while capturing)
+        rm, tr = cast_bf16(W.detach())
+        tw.ent[id(W)] = [weakref.ref(W), rm, tr, W.data_ptr(), W._version, key]
+        tw.table = None
+        return rm, tr
+    if e[5] != key or e[4] != W._version:
+        tw.refresh(key)
+    return e[1], e[2]
 
 
 def cast_fp8_rows(W, transposed=False):
@@ -318,6 +380,7 @@ def capture_scope_reset():
     _WCACHE_CAPTURE.clear()
     _W8CACHE_CAPTURE.clear()
     _SIDE_BF16.clear()
+    _CAPTURE_EPOCH[0] += 1
 
 
 def gemm_bf16(Ab, Bb, M, N, C=None, Cb=None, bias=None, addend=None, aux=None, act=0, gate_scale=1.0, alpha=1.0,

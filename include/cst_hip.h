@@ -104,6 +104,12 @@ int cst_gemm_bf16_pp_config(int M, int N, int K);
 int cst_cast_bf16(const void* x, int x_is_bf16, long ldx, int R, int C,
                   void* out, long ldo, void* out_t, long ldot,
                   float drop_p, uint32_t drop_seed, uint32_t drop_stream, const void* drop_seed_dev, void* stream);
+/* n cst_cast_bf16 calls (fp32 inputs, no dropout) in ONE launch: the bf16 twins (row-major + transposed) of every trained weight
+ * of an optimizer group, refreshed once per optimizer step instead of one launch per weight (mlm.py:20-24, match.py:18-22 Linear
+ * weights; the casts were 84 launches of the step).  table: n rows of 8 HOST int64 words {x, ldx, R, C, out, ldo, out_t, ldot},
+ * the arguments cst_cast_bf16 takes; every row must qualify for its vector kernel (C, ldx, ldo, ldot multiples of 4, x 16-byte and
+ * the outputs 8-byte aligned).  The rows ride in the kernel arguments (batches of 40): nothing is read from `table` after return. */
+int cst_cast_bf16_multi(const long* table, int n, void* stream);
 /* out[c] (+)= sum_r X[r,c] for a bf16 matrix (fp32 sums); accumulate != 0: `out` already holds the value the sums are added to
  * (e.g. zeros from the caller's own arena -- the library then skips its fill kernel). */
 int cst_colsum_bf16(const void* X, long ld, int M, int N, float* out, int accumulate, void* stream);
