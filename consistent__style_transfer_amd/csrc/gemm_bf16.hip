@@ -1648,10 +1648,12 @@ extern "C" int cst_gemm_bf16_argmax(const void* A, long lda, const void* B, long
                        0.f, 0, 0, nullptr, 64, 1, nullptr, 0, stream, (unsigned long long*)amax_packed);
 }
 
-// ---- grouped weight gradients: cst_gemm_bf16_tt calls between _group_begin and _group_end are collected (per host thread) and
+// ---- grouped weight gradients: cst_gemm_bf16_tt calls between _group_begin and _group_end are collected and
 // launched together by _group_end.  A group whose tiles would not fill the chip is launched product by product, as without a group.
 struct TtDeferred { BTtProblem p; int splitk; float* ws; long ws_floats; };
-static thread_local struct { bool open; int n; TtDeferred d[CST_TT_GROUP_MAX]; int* counters; int ncounters; int last_splits; } tt_group = {false, 0, {}, nullptr, 0, 0};
+// ONE group per process: it is opened inside a backward pass (autograd's device thread) and may be closed by the thread that started
+// that pass; this host code issues GPU work from one thread at a time.
+static struct { bool open; int n; TtDeferred d[CST_TT_GROUP_MAX]; int* counters; int ncounters; int last_splits; } tt_group = {false, 0, {}, nullptr, 0, 0};
 
 static int tt_single(const void* A, long lda, const void* B, long ldb, float* C, long ldc, int M, int N, int K,
                      int accumulate, int splitk, float* workspace, long workspace_floats, void* stream);
@@ -1739,17 +1741,17 @@ static int tt_group_flush(hipStream_t st) {
 }
 
 extern "C" int cst_gemm_bf16_tt_group_begin(int* counters, int ncounters, void* /*stream: the products are launched by _group_end, on ITS stream*/) {
-    CST_REQUIRE(!tt_group.open, "cst_gemm_bf16_tt_group_begin: a group is already open on this thread");
+    CST_REQUIRE(!tt_group.open, "cst_gemm_bf16_tt_group_begin: a group is already open");
     CST_REQUIRE(ncounters >= 0 && (counters || ncounters == 0), "cst_gemm_bf16_tt_group_begin: %d counters at a null address", ncounters);
     tt_group.open = true; tt_group.n = 0; tt_group.counters = counters; tt_group.ncounters = counters ? ncounters : 0;
     return CST_OK;
 }
 
-/* how the last group of this thread was launched: 0 = product by product, S >= 1 = one kernel with S workgroups per tile */
+/* how the last group was launched: 0 = product by product, S >= 1 = one kernel with S workgroups per tile */
 extern "C" int cst_gemm_bf16_tt_group_last_splits(void) { return tt_group.last_splits; }
 
 extern "C" int cst_gemm_bf16_tt_group_end(void* stream) {
-    CST_REQUIRE(tt_group.open, "cst_gemm_bf16_tt_group_end: no group is open on this thread");
+    CST_REQUIRE(tt_group.open, "cst_gemm_bf16_tt_group_end: no group is open");
     tt_group.open = false;
     return tt_group_flush((hipStream_t)stream);
 }
@@ -1761,7 +1763,7 @@ extern "C" int cst_gemm_bf16_tt(const void* A, long lda, const void* B, long ldb
                 "cst_gemm_bf16_tt: M=%d, N=%d must be multiples of 8 and K=%d a multiple of 64", M, N, K);
     CST_REQUIRE(lda >= M && ldb >= N && lda % 8 == 0 && ldb % 8 == 0 && ldc >= N && (((uintptr_t)A | (uintptr_t)B) & 15) == 0,
                 "cst_gemm_bf16_tt: operands must be 16-byte aligned, leading dimensions multiples of 8");
-    if (tt_group.open && splitk <= 1) {              // (an explicit split-K request is honoured at once, outside the group)
+    if (tt_group.open && splitk >= 0 && splitk <= 1) {     // (an explicit split-K request, or splitk < 0 = "now, split as you see fit", runs at once)
         if (tt_group.n == CST_TT_GROUP_MAX) {
             const int rc = tt_group_flush((hipStream_t)stream);
             if (rc != CST_OK) return rc;
@@ -1771,7 +1773,7 @@ extern "C" int cst_gemm_bf16_tt(const void* A, long lda, const void* B, long ldb
         d.splitk = splitk; d.ws = workspace; d.ws_floats = workspace_floats;
         return CST_OK;
     }
-    return tt_single(A, lda, B, ldb, C, ldc, M, N, K, accumulate, splitk, workspace, workspace_floats, stream);
+    return tt_single(A, lda, B, ldb, C, ldc, M, N, K, accumulate, splitk < 0 ? 0 : splitk, workspace, workspace_floats, stream);
 }
 
 static int tt_single(const void* A, long lda, const void* B, long ldb, float* C, long ldc, int M, int N, int K,

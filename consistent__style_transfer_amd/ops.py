@@ -396,29 +396,99 @@ def gemm_bf16(Ab, Bb, M, N, C=None, Cb=None, bias=None, addend=None, aux=None, a
     return C if C is not None else Cb
 
 
-def gemm_bf16_tt(Ab, Bb, M, N, C=None, accumulate=False, splitk=0):
-    """C[M,N] (+)= Ab[K,M]^T Bb[K,N]: bf16 operands whose ROW index is the contraction (token) index."""
+_TT = {"open": False, "depth": 0, "defer": 0, "n": 0, "keep": [], "owners": []}
+TT_GROUP_MAX = 8                     # = CST_TT_GROUP_MAX: problems per grouped launch
+
+
+def _tt_begin():
+    dev = torch.device("cuda", torch.cuda.current_device())
+    call("cst_gemm_bf16_tt_group_begin", _workspace(dev)[WS_FLOATS:], WS_COUNTERS)
+    _TT["open"], _TT["n"] = True, 0
+
+
+def _tt_end():
+    _TT["open"], _TT["n"] = False, 0
+    try:
+        call("cst_gemm_bf16_tt_group_end")             # always closes the group (what was recorded is launched even on an error path)
+    finally:
+        _TT["keep"].clear()                            # launched: the operands may be freed (stream order protects them)
+
+
+def gemm_bf16_tt(Ab, Bb, M, N, C=None, accumulate=False, splitk=0, owner=None):
+    """C[M,N] (+)= Ab[K,M]^T Bb[K,N]: bf16 operands whose ROW index is the contraction (token) index.  Inside `with tt_group():` the
+    product is only recorded (C is defined when the group is launched).  owner: the parameter whose gradient C is -- under
+    tt_deferred the launch comes after autograd has taken C as owner.grad, which tt_deferred verifies when it ends."""
     K = Ab.shape[0]
     assert Bb.shape[0] == K and Ab.dtype == torch.int16 and Bb.dtype == torch.int16
     if C is None:
         C = torch.empty(M, N, device=Ab.device, dtype=torch.float32)
+    rec = _TT["open"] and 0 <= splitk <= 1
+    if rec and _TT["depth"] == 0:
+        rec, splitk = False, -1                        # a group left open by tt_deferred, but this call is not part of one: run it now
+    if rec and _TT["n"] == TT_GROUP_MAX:
+        _tt_end()                                      # a full launch: send it off and start the next
+        _tt_begin()
     call("cst_gemm_bf16_tt", Ab, Ab.stride(0), Bb, Bb.stride(0), C, _ld(C), M, N, K, int(accumulate), splitk,
          _workspace(Ab.device), WS_FLOATS)
+    if rec:
+        # the operands stay alive until the launch.  NOT the output: a second reference would make autograd's AccumulateGrad copy the
+        # (not yet computed) gradient instead of taking the tensor itself
+        _TT["keep"].append((Ab, Bb))
+        _TT["n"] += 1
+        if owner is not None and _TT["defer"]:
+            _TT["owners"].append((weakref.ref(owner), C.data_ptr(), tuple(C.shape)))
     return C
 
 
 class tt_group:
     """`with tt_group():` -- the gemm_bf16_tt products issued inside are launched together when the block ends (cst_gemm_bf16_tt_group_*:
-    the weight gradients of one encoder layer in one whole-K launch instead of four split-K launches + four reduces).  Their results
-    are defined only after the block; operands must stay alive until then (they are locals of the calling backward)."""
+    the weight gradients of one encoder layer in one launch of whole-K workgroups instead of four split-K launches + four reduces).
+    Their results are defined only after the launch.  deferrable=True: inside `with tt_deferred():` the block's end does NOT launch --
+    the products stay recorded (operands kept alive here) and go out with the next blocks', TT_GROUP_MAX problems per launch, the rest
+    when tt_deferred ends: two small layers' weight gradients per launch fill the CUs' workgroup slots better than one (384 tiles on
+    512 slots against 192 twice).  Only for results nobody reads before tt_deferred ends."""
+
+    def __init__(self, deferrable=False):
+        self.deferrable = deferrable
 
     def __enter__(self):
-        dev = torch.device("cuda", torch.cuda.current_device())
-        call("cst_gemm_bf16_tt_group_begin", _workspace(dev)[WS_FLOATS:], WS_COUNTERS)
+        if _TT["open"] and not (self.deferrable and _TT["defer"]):
+            _tt_end()                                  # somebody's deferred products: launch them before this group starts
+        if not _TT["open"]:
+            _tt_begin()
+        _TT["depth"] += 1
         return self
 
     def __exit__(self, *exc):
-        call("cst_gemm_bf16_tt_group_end")             # always closes the group (what was recorded is launched even on an error path)
+        _TT["depth"] -= 1
+        if not (self.deferrable and _TT["defer"]) and _TT["open"]:
+            _tt_end()
+        return False
+
+
+_TT_DEFER_ON = os.environ.get("CST_TT_DEFER", "1") != "0"        # A/B switch (bench): 0 = every layer's weight gradients in their own launch
+TT_DEFER_MAX_K = 32768               # tools/tt_group_probe.py: two layers per launch win up to 30720 tokens (-18 %), lose at 73728 (+4 %)
+
+
+class tt_deferred:
+    """`with tt_deferred(): loss.backward()` -- see tt_group(deferrable=True).  Everything recorded is launched when the block ends."""
+
+    def __enter__(self):
+        _TT["defer"] += 1 if _TT_DEFER_ON else 0
+        return self
+
+    def __exit__(self, *exc):
+        _TT["defer"] -= 1 if _TT_DEFER_ON else 0
+        if _TT["defer"] == 0:
+            if _TT["open"]:
+                _tt_end()
+            owners, _TT["owners"] = _TT["owners"], []
+            if exc[0] is None:
+                for ref, ptr, shape in owners:
+                    W = ref()
+                    if W is not None and (W.grad is None or W.grad.data_ptr() != ptr):
+                        raise RuntimeError(f"tt_deferred: the gradient of a {shape} weight was copied or replaced before its deferred product ran "
+                                           "(autograd did not take the output tensor itself): its values are undefined")
         return False
 
 
@@ -918,11 +988,16 @@ class EncoderLayerBf16Fn(torch.autograd.Function):
         if wg:
             if tt:                                        # dW = dY^T X from the row-major copies
                 in_w, out_w, l1_w, l2_w = ctx.wrefs
-                with tt_group():                          # the four weight gradients of the layer: one launch
-                    dl2w = gemm_bf16_tt(dfb, wh, d, F, C=_gout(l2_w))
-                    dl1w = gemm_bf16_tt(dhb, wy1, F, d, C=_gout(l1_w))
-                    doutw = gemm_bf16_tt(dob, watt, d, d, C=_gout(out_w))
-                    dinw = gemm_bf16_tt(dqb, wx, 3 * d, d, C=_gout(in_w))
+                # the four weight gradients of the layer in one launch; layers of at most 256 output tiles (d = 512: 192) two layers per
+                # launch under tt_deferred (pretrain 6.23 -> 6.11 ms at d = 512, 14.74 -> 14.45 ms on the book workload; the d = 768
+                # layers' 336 tiles gain nothing in the step: 8.16 -> 8.18 ms)
+                c128 = lambda n: (n + 127) // 128
+                tiles = 2 * c128(d) * c128(F) + c128(d) * c128(d) + c128(3 * d) * c128(d)
+                with tt_group(deferrable=T <= TT_DEFER_MAX_K and tiles <= 256):
+                    dl2w = gemm_bf16_tt(dfb, wh, d, F, C=_gout(l2_w), owner=l2_w)
+                    dl1w = gemm_bf16_tt(dhb, wy1, F, d, C=_gout(l1_w), owner=l1_w)
+                    doutw = gemm_bf16_tt(dob, watt, d, d, C=_gout(out_w), owner=out_w)
+                    dinw = gemm_bf16_tt(dqb, wx, 3 * d, d, C=_gout(in_w), owner=in_w)
             else:
                 dht = cast_bf16(dhb[:, :F], want_rm=False)[1]
                 dl2w = gemm_bf16(dft, wh, d, F, C=new(d, F))

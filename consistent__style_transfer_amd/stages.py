@@ -198,7 +198,8 @@ class PretrainStage(nn.Module):
                 bucketed_backward(loss, stack, self.groups[k], head, embed, reducer, last=last, tag=k)
                 stack.taps = None
                 continue
-            loss.backward()
+            with ops.tt_deferred():                       # the encoder layers' weight gradients go out two layers per launch
+                loss.backward()
             self.groups[k].gather_grads(False)
             if reducer is not None:
                 if not last:

@@ -268,8 +268,9 @@ int cst_gemm_bf16_w8(const void* A, long lda, const void* Bq, long ldb, const fl
 int cst_gemm_bf16_tt(const void* A, long lda, const void* B, long ldb, float* C, long ldc, int M, int N, int K,
                      int accumulate, int splitk, float* workspace, long workspace_floats, void* stream);
 long cst_gemm_bf16_tt_workspace_floats(int M, int N, int K, int splitk);
-/* Grouped weight gradients.  Between _group_begin and _group_end (same host thread) cst_gemm_bf16_tt calls with splitk <= 1 only
- * RECORD their product; _group_end launches all of them as ONE kernel whose workgroups are numbered through the problems' 128 x 128
+/* Grouped weight gradients.  Between _group_begin and _group_end (one group per process at a time; begin and end may come from
+ * different host threads, e.g. autograd's device thread and the thread that called backward) cst_gemm_bf16_tt calls with splitk 0 or 1
+ * only RECORD their product (splitk < 0: run now with the automatic split; splitk >= 2: run now with that split); _group_end launches all of them as ONE kernel whose workgroups are numbered through the problems' 128 x 128
  * output tiles (up to 8 problems per launch; more are launched in batches of 8): the four dW of an encoder layer (backward of
  * mlm.py:20-24, match.py:18-22) have 36-108 tiles each -- one by one they need split-K slabs and a reduce launch each to fill 256
  * CUs, together (336 tiles) they do not.  A group of at most 256 tiles (d = 512 layers: 192) splits every contraction in two: two
@@ -281,7 +282,7 @@ long cst_gemm_bf16_tt_workspace_floats(int M, int N, int K, int splitk);
  * until _group_end returns; results are defined only after it.  _group_end always closes the group. */
 int cst_gemm_bf16_tt_group_begin(int* counters, int ncounters, void* stream);
 int cst_gemm_bf16_tt_group_end(void* stream);
-/* diagnostics: how this thread's last group was launched -- 0 product by product, S >= 1 one kernel with S workgroups per tile */
+/* diagnostics: how the last group was launched -- 0 product by product, S >= 1 one kernel with S workgroups per tile */
 int cst_gemm_bf16_tt_group_last_splits(void);
 
 /* All L time steps of both directions of the BiLSTM encoder (rnn.py:25-27, called at rnn.py:57, :62) in ONE launch: a
