@@ -467,6 +467,7 @@ class tt_group:
 
 
 _TT_DEFER_ON = os.environ.get("CST_TT_DEFER", "1") != "0"        # A/B switch (bench): 0 = every layer's weight gradients in their own launch
+TT_DEFER_MAX_TILES = 256             # layers with more weight-gradient tiles than this are launched layer by layer (see EncoderLayerBf16Fn.backward)
 TT_DEFER_MAX_K = 32768               # tools/tt_group_probe.py: two layers per launch win up to 30720 tokens (-18 %), lose at 73728 (+4 %)
 
 
@@ -993,7 +994,7 @@ class EncoderLayerBf16Fn(torch.autograd.Function):
                 # layers' 336 tiles gain nothing in the step: 8.16 -> 8.18 ms)
                 c128 = lambda n: (n + 127) // 128
                 tiles = 2 * c128(d) * c128(F) + c128(d) * c128(d) + c128(3 * d) * c128(d)
-                with tt_group(deferrable=T <= TT_DEFER_MAX_K and tiles <= 256):
+                with tt_group(deferrable=T <= TT_DEFER_MAX_K and tiles <= TT_DEFER_MAX_TILES):
                     dl2w = gemm_bf16_tt(dfb, wh, d, F, C=_gout(l2_w), owner=l2_w)
                     dl1w = gemm_bf16_tt(dhb, wy1, F, d, C=_gout(l1_w), owner=l1_w)
                     doutw = gemm_bf16_tt(dob, watt, d, d, C=_gout(out_w), owner=out_w)

@@ -559,13 +559,28 @@ def test_pretrain_deferred_weight_gradients_equal_per_layer_launches():
     pre.setup_optim()
     x, nx_1, nx_2, nx, label, c_label = cu(pre_batch(c, 0))
     res = {}
-    for mode in ("deferred", "plain", "deferred"):
-        for p in pre.matcher.parameters():
-            p.grad = None
-        loss = ops.mse_loss(pre.matcher(nx_1, nx_2), c_label)
-        with (ops.tt_deferred() if mode == "deferred" else contextlib.nullcontext()):
-            loss.backward()
-        res[mode] = {n: p.grad.clone() for n, p in pre.matcher.named_parameters() if p.grad is not None}
+    launches = {"deferred": 0, "plain": 0}
+    orig, limit = ops.call, ops.TT_DEFER_MAX_TILES
+    ops.TT_DEFER_MAX_TILES = 10 ** 9              # (the fixture's d = 768 layers are above the product's limit: defer them here all the same)
+    try:
+        for mode in ("deferred", "plain", "deferred"):
+            for p in pre.matcher.parameters():
+                p.grad = None
+            loss = ops.mse_loss(pre.matcher(nx_1, nx_2), c_label)
+
+            def spy(nm, *a, _m=mode):
+                launches[_m] += nm == "cst_gemm_bf16_tt_group_end"
+                return orig(nm, *a)
+
+            ops.call = spy
+            with (ops.tt_deferred() if mode == "deferred" else contextlib.nullcontext()):
+                loss.backward()
+            ops.call = orig
+            res[mode] = {n: p.grad.clone() for n, p in pre.matcher.named_parameters() if p.grad is not None}
+    finally:
+        ops.call, ops.TT_DEFER_MAX_TILES = orig, limit
+    nl = len(pre.matcher.matcher.layers)
+    assert launches["plain"] == nl and launches["deferred"] == 2 * ((nl + 1) // 2), launches      # two deferred passes, two layers a launch
     nw = 0
     for n, a in res["plain"].items():
         if a.dim() == 2 and "embedding" not in n and "layers" in n:
