@@ -1327,24 +1327,43 @@ class SoftEmbedFn(torch.autograd.Function):
         R, V = p.shape
         E = table.shape[0] if table_is_ev else table.shape[1]
         out = torch.empty(R, E, device=p.device, dtype=torch.float32)
-        gemm(p, True, table, bool(table_is_ev), out, R, E, V)
-        ctx.save_for_backward(p, table)
+        # the decoder's softmax leaves a bf16 twin of its output (zero-padded to a multiple of 64 columns): with it both products of
+        # this node run on the bf16 GEMMs (the discriminator step's embedding of the generated distribution, main_optimize.py:119-120)
+        pb = _side_take(p) if not _STATE["f32"] else None
+        if pb is not None and (pb.shape != (R, _up64(V)) or E % 8 or V % 8):
+            pb = None
+        if pb is not None:
+            rm, tr = weight_bf16(table)                                    # [E, V]: rm = [E, Vp], tr = [V, Ep];  [V, E]: rm = [V, Ep], tr = [E, Vp]
+            gemm_bf16(pb, rm if table_is_ev else tr, R, E, C=out)
+        else:
+            gemm(p, True, table, bool(table_is_ev), out, R, E, V)
+        ctx.save_for_backward(p, table, pb)
         ctx.ev = table_is_ev
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        p, table = ctx.saved_tensors
+        p, table, pb = ctx.saved_tensors
         dout = dout.contiguous()
         R, V = p.shape
         E = dout.shape[1]
         dp = dt = None
+        doutb = cast_bf16(dout, want_t=False)[0] if pb is not None and E % 64 == 0 else None
         if ctx.needs_input_grad[0]:
             dp = torch.empty(R, V, device=p.device, dtype=torch.float32)
-            gemm(dout, True, table, not ctx.ev, dp, R, V, E)
+            if doutb is not None:
+                rm, tr = weight_bf16(table)
+                gemm_bf16(doutb, tr if ctx.ev else rm, R, V, C=dp)
+            else:
+                gemm(dout, True, table, not ctx.ev, dp, R, V, E)
         if ctx.needs_input_grad[1]:
             dt = torch.empty_like(table)
-            if ctx.ev:
+            if doutb is not None and R % 64 == 0:                          # dout^T p / p^T dout straight from the row-major bf16 twins
+                if ctx.ev:
+                    gemm_bf16_tt(doutb, pb, E, V, C=dt)
+                else:
+                    gemm_bf16_tt(pb, doutb, V, E, C=dt)
+            elif ctx.ev:
                 gemm(dout, False, p, False, dt, E, V, R)
             else:
                 gemm(p, False, dout, False, dt, V, E, R)

@@ -426,6 +426,47 @@ def test_shared_soft_embed_bf16_twin_matches_staged_product(ops):
     close(res[1][0][1], ref, 3e-2, 3e-2 * float(ref.abs().max()))
 
 
+@pytest.mark.parametrize("ev", [False, True])
+def test_soft_embed_bf16_twin_matches_staged_product(ops, ev):
+    """ops.SoftEmbedFn (discriminator.py:39 on the generated distribution, main_optimize.py:119-120) with the softmax kernel's bf16 twin:
+    out = p @ table on the bf16 GEMM, d table = dout^T p through the transposed-read product, d p on the bf16 GEMM -- against the
+    fp32-staged products of the same node (both round their operands to bf16) and an fp64 product."""
+    ops.set_precision("bf16")
+    R, V, E = 192, 10000, 128
+    Vp = (V + 63) // 64 * 64
+    x = dev(rnd(R, V, seed=7, scale=2.0))
+    tab0 = dev(rnd(E, V, seed=10) if ev else rnd(V, E, seed=10))
+    dout = dev(rnd(R, E, seed=11))
+    res = []
+    for twin in (False, True):
+        p = torch.empty(R, V, device="cuda")
+        pb = torch.empty(R, Vp, dtype=torch.int16, device="cuda") if twin else None
+        ops.softmax_tau(x, 1.0, p, None, p_b=pb)
+        p.requires_grad_(True)
+        tab = tab0.clone().requires_grad_(True)
+        if twin:
+            ops._side_put(p, pb)
+        names = []
+        orig = ops.call
+        ops.call = lambda nm, *a: (names.append(nm), orig(nm, *a))[1]
+        try:
+            out = ops.SoftEmbedFn.apply(p, tab, ev)
+            out.backward(dout)
+        finally:
+            ops.call = orig
+        assert ("cst_gemm" in names) == (not twin), names          # with the twin no fp32-staged product is left
+        res.append((out.detach().clone(), p.grad.clone(), tab.grad.clone()))
+    close(res[0][0], res[1][0], 1e-3, 1e-4)
+    close(res[0][1], res[1][1], 2e-2, 2e-2 * float(res[0][1].abs().max()))
+    close(res[0][2], res[1][2], 2e-2, 2e-2 * float(res[0][2].abs().max()))
+    pr = torch.softmax(x.double(), -1).cpu()
+    t64 = tab0.double().cpu()
+    ref = pr @ (t64.T if ev else t64)
+    close(res[1][0], ref.float(), 3e-2, 3e-2 * float(ref.abs().max()))
+    dt = dout.double().cpu().T @ pr if ev else pr.T @ dout.double().cpu()
+    close(res[1][2], dt.float(), 3e-2, 3e-2 * float(dt.abs().max()))
+
+
 def test_argmax_ties_first_index(ops):
     x = torch.zeros(3, 1000)
     x[0, 17] = x[0, 500] = 2.0
