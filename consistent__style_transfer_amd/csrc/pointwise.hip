@@ -258,7 +258,12 @@ extern "C" int cst_tps_embed_bwd(const float* dx, const int64_t* ids, float* dpr
 //   col[(b*T + t), r*E + c] = e[b, t + r - (k-1), c], T = L + k - 1.
 // mode 1 (RelGAN_D): e [B,L,R*es], col[((b*R + rep)*T + t), i*es + q] = e[b, t+i, rep*es + q], T = L-k+1.
 // ---------------------------------------------------------------------------------------------
-__global__ void im2col_kernel(const float* __restrict__ e, float* __restrict__ col, int B, int L, int E, int k, int mode, int R) {
+template <typename OUT> __device__ __forceinline__ OUT pw_out(float v);
+template <> __device__ __forceinline__ float pw_out<float>(float v) { return v; }
+template <> __device__ __forceinline__ bf16_t pw_out<bf16_t>(float v) { return pw_f2bf(v); }
+
+template <typename OUT>
+__global__ void im2col_kernel(const float* __restrict__ e, OUT* __restrict__ col, int B, int L, int E, int k, int mode, int R) {
     if (mode == 0) {
         const int T = L + k - 1;
         const long KE = (long)k * E;
@@ -266,7 +271,7 @@ __global__ void im2col_kernel(const float* __restrict__ e, float* __restrict__ c
             const long cc = i % KE, t = (i / KE) % T, b = i / (KE * T);
             const long r = cc / E, c = cc % E;
             const long l = t + r - (k - 1);
-            col[i] = (l >= 0 && l < L) ? e[(b * L + l) * E + c] : 0.f;
+            col[i] = pw_out<OUT>((l >= 0 && l < L) ? e[(b * L + l) * E + c] : 0.f);
         }
     } else {
         const int T = L - k + 1, es = E / R;
@@ -274,7 +279,7 @@ __global__ void im2col_kernel(const float* __restrict__ e, float* __restrict__ c
         EW_LOOP(i, (long)B * R * T * KE) {
             const long cc = i % KE, t = (i / KE) % T, rep = (i / (KE * T)) % R, b = i / (KE * T * R);
             const long w = cc / es, q = cc % es;
-            col[i] = e[(b * L + t + w) * E + rep * es + q];
+            col[i] = pw_out<OUT>(e[(b * L + t + w) * E + rep * es + q]);
         }
     }
 }
@@ -283,8 +288,19 @@ extern "C" int cst_im2col(const float* e, float* col, int B, int L, int E, int k
     CST_REQUIRE(e && col && B > 0 && L > 0 && E > 0 && k > 0, "cst_im2col: bad arguments");
     CST_REQUIRE(mode == 0 || (mode == 1 && R > 0 && E % R == 0 && L >= k), "cst_im2col: mode 1 needs L >= k and E %% R == 0");
     const long n = mode == 0 ? (long)B * (L + k - 1) * k * E : (long)B * R * (L - k + 1) * k * (E / R);
-    hipLaunchKernelGGL(im2col_kernel, ew_grid(n), dim3(EW_THREADS), 0, (hipStream_t)stream, e, col, B, L, E, k, mode, R);
+    hipLaunchKernelGGL(im2col_kernel<float>, ew_grid(n), dim3(EW_THREADS), 0, (hipStream_t)stream, e, col, B, L, E, k, mode, R);
     CST_LAUNCH_CHECK("cst_im2col");
+    return CST_OK;
+}
+
+/* the same rows in bf16 (dense, row length k E or k E / R): the A operand of the bf16 GEMM and the B operand of the transposed-read
+ * weight-gradient product, written once instead of staged from fp32 by every product that reads them */
+extern "C" int cst_im2col_b(const float* e, void* col_bf16, int B, int L, int E, int k, int mode, int R, void* stream) {
+    CST_REQUIRE(e && col_bf16 && B > 0 && L > 0 && E > 0 && k > 0, "cst_im2col_b: bad arguments");
+    CST_REQUIRE(mode == 0 || (mode == 1 && R > 0 && E % R == 0 && L >= k), "cst_im2col_b: mode 1 needs L >= k and E %% R == 0");
+    const long n = mode == 0 ? (long)B * (L + k - 1) * k * E : (long)B * R * (L - k + 1) * k * (E / R);
+    hipLaunchKernelGGL(im2col_kernel<bf16_t>, ew_grid(n), dim3(EW_THREADS), 0, (hipStream_t)stream, e, (bf16_t*)col_bf16, B, L, E, k, mode, R);
+    CST_LAUNCH_CHECK("cst_im2col_b");
     return CST_OK;
 }
 
@@ -342,14 +358,15 @@ extern "C" int cst_seqmax_fwd(const float* x, float* out, long ldo, int* arg, in
 }
 
 // dx[g,t,f] = (t == arg[g,f] && (!relu_gate || y[g,f] > 0)) ? dout[g*ldd + f] : 0   (writes every element)
+template <typename OUT>
 __global__ void seqmax_bwd_kernel(const float* __restrict__ dout, long ldd, const int* __restrict__ arg,
                                   const float* __restrict__ y, long ldy, int relu_gate,
-                                  float* __restrict__ dx, int G, int T, int F) {
+                                  OUT* __restrict__ dx, int G, int T, int F) {
     EW_LOOP(i, (long)G * T * F) {
         const long f = i % F, t = (i / F) % T, g = i / ((long)F * T);
         float v = 0.f;
         if (arg[g * F + f] == t && (!relu_gate || y[g * ldy + f] > 0.f)) v = dout[g * ldd + f];
-        dx[i] = v;
+        dx[i] = pw_out<OUT>(v);
     }
 }
 
@@ -357,8 +374,19 @@ extern "C" int cst_seqmax_bwd(const float* dout, long ldd, const int* arg, const
                               float* dx, int G, int T, int F, void* stream) {
     CST_REQUIRE(dout && arg && dx && G > 0 && T > 0 && F > 0, "cst_seqmax_bwd: bad arguments");
     CST_REQUIRE(!relu_gate || y, "cst_seqmax_bwd: relu gate needs the pooled values");
-    hipLaunchKernelGGL(seqmax_bwd_kernel, ew_grid((long)G * T * F), dim3(EW_THREADS), 0, (hipStream_t)stream, dout, ldd, arg, y, ldy, relu_gate, dx, G, T, F);
+    hipLaunchKernelGGL(seqmax_bwd_kernel<float>, ew_grid((long)G * T * F), dim3(EW_THREADS), 0, (hipStream_t)stream, dout, ldd, arg, y, ldy, relu_gate, dx, G, T, F);
     CST_LAUNCH_CHECK("cst_seqmax_bwd");
+    return CST_OK;
+}
+
+/* the same gradient written in bf16 only ([G T, F] dense): operand of the bf16 dgrad / weight-gradient products behind it */
+extern "C" int cst_seqmax_bwd_b(const float* dout, long ldd, const int* arg, const float* y, long ldy, int relu_gate,
+                                void* dx_bf16, int G, int T, int F, void* stream) {
+    CST_REQUIRE(dout && arg && dx_bf16 && G > 0 && T > 0 && F > 0, "cst_seqmax_bwd_b: bad arguments");
+    CST_REQUIRE(!relu_gate || y, "cst_seqmax_bwd_b: relu gate needs the pooled values");
+    hipLaunchKernelGGL(seqmax_bwd_kernel<bf16_t>, ew_grid((long)G * T * F), dim3(EW_THREADS), 0, (hipStream_t)stream, dout, ldd, arg, y, ldy, relu_gate,
+                       (bf16_t*)dx_bf16, G, T, F);
+    CST_LAUNCH_CHECK("cst_seqmax_bwd_b");
     return CST_OK;
 }
 

@@ -231,8 +231,8 @@ _WCACHE = {}
 _WCACHE_CAPTURE = {}
 
 
-def weight_bf16(W):
-    """bf16 row-major + transposed copies of a weight.
+def weight_bf16(W, shape2d=None):
+    """bf16 row-major + transposed copies of a weight (shape2d: the [N, K] matrix a convolution weight is used as).
 
     Frozen weights (no optim.FlatGroup owns them: the critics of the optimize stage, modules in
     eval/transfer use) are cast once and cached; the key is the torch in-place version
@@ -243,11 +243,12 @@ def weight_bf16(W):
     capture they are shared between the uses that see the same optimizer version."""
     grp = getattr(W, "_cst_group", None)
     capturing = torch.cuda.is_current_stream_capturing()
+    Wd = W.detach() if shape2d is None else W.detach().view(shape2d)
     if grp is not None and W.is_cuda:
-        hit = _group_twins(grp, W, capturing)
+        hit = _group_twins(grp, W, capturing, Wd)
         if hit is not None:
             return hit
-    ver = (W._version, grp.version if grp is not None else 0, W.data_ptr(), tuple(W.shape))
+    ver = (W._version, grp.version if grp is not None else 0, W.data_ptr(), tuple(Wd.shape))
     key = id(W)
     if grp is not None and capturing:
         # inside one capture the copies made earlier in the same capture stay valid until the next
@@ -255,13 +256,13 @@ def weight_bf16(W):
         hit = _WCACHE_CAPTURE.get(key)
         if hit is not None and hit[0]() is W and hit[1] == ver:
             return hit[2], hit[3]
-        rm, tr = cast_bf16(W.detach())
+        rm, tr = cast_bf16(Wd)
         _WCACHE_CAPTURE[key] = (weakref.ref(W), ver, rm, tr)
         return rm, tr
     hit = _WCACHE.get(key)
     if hit is not None and hit[0]() is W and hit[1] == ver:      # the weak reference guards against a recycled id()
         return hit[2], hit[3]
-    rm, tr = cast_bf16(W.detach())
+    rm, tr = cast_bf16(Wd)
     if not capturing:                                # never cache tensors that live in a graph's private pool
         _WCACHE[key] = (weakref.ref(W, lambda _r, k=key: _WCACHE.pop(k, None)), ver, rm, tr)
     return rm, tr
@@ -292,8 +293,8 @@ class _GroupTwins:
         if self.table is None or self.table.shape[0] != len(live):
             rows = []
             for e in live:
-                W, rm, tr = e[0](), e[1], e[2]
-                rows.append([W.data_ptr(), _ld(W), W.shape[0], W.shape[1], rm.data_ptr(), rm.stride(0), tr.data_ptr(), tr.stride(0)])
+                rm, tr = e[1], e[2]
+                rows.append([e[3], e[6][2], e[6][0], e[6][1], rm.data_ptr(), rm.stride(0), tr.data_ptr(), tr.stride(0)])
             self.table = torch.tensor(rows, dtype=torch.int64)
         call("cst_cast_bf16_multi", self.table, len(live))
         for e in live:
@@ -303,21 +304,22 @@ class _GroupTwins:
                     del t.__dict__[a]
 
 
-def _group_twins(grp, W, capturing):
+def _group_twins(grp, W, capturing, Wd):
+    """Wd: the detached 2-D matrix W is used as (W itself, or a view of a convolution weight)."""
     tw = getattr(grp, "_bf16_twins", None)
     if tw is None:
         tw = grp._bf16_twins = _GroupTwins()
     key = tw.key(grp, capturing)
     e = tw.ent.get(id(W))
-    if e is not None and (e[0]() is not W or e[3] != W.data_ptr() or tuple(e[1].shape) != (W.shape[0], _up64(W.shape[1]))):
-        del tw.ent[id(W)]           # a recycled id() or re-laid-out storage: register again
+    if e is not None and (e[0]() is not W or e[3] != Wd.data_ptr() or Wd.dim() != 2 or e[6] != (Wd.shape[0], Wd.shape[1], Wd.stride(0))):
+        del tw.ent[id(W)]           # a recycled id(), re-laid-out storage or another 2-D reading: register again
         tw.table, e = None, None
     if e is None:
-        if (capturing or W.dim() != 2 or W.stride(1) != 1 or W.shape[1] % 4 or W.stride(0) % 4 or W.data_ptr() % 16
-                or W.dtype != torch.float32):
+        if (capturing or Wd.dim() != 2 or Wd.stride(1) != 1 or Wd.shape[1] % 4 or Wd.stride(0) % 4 or Wd.data_ptr() % 16
+                or Wd.dtype != torch.float32):
             return None             # (the per-weight path: nothing persistent may be allocated while capturing)
-        rm, tr = cast_bf16(W.detach())
-        tw.ent[id(W)] = [weakref.ref(W), rm, tr, W.data_ptr(), W._version, key]
+        rm, tr = cast_bf16(Wd)
+        tw.ent[id(W)] = [weakref.ref(W), rm, tr, Wd.data_ptr(), W._version, key, (Wd.shape[0], Wd.shape[1], Wd.stride(0))]
         tw.table = None
         return rm, tr
     if e[5] != key or e[4] != W._version:
@@ -1222,9 +1224,16 @@ class ConvBankFn(torch.autograd.Function):
                 continue
             T = L + k - 1 if mode == 0 else L - k + 1
             KE = k * (E if mode == 0 else E // R)
-            col = torch.empty(G * T, KE, device=dev, dtype=torch.float32)
-            call("cst_im2col", e, col, B, L, E, k, mode, R)
-            y = linear_fwd(col, w.reshape(F_, KE), b, act=1)
+            # bf16 mode: the window rows are written in bf16 once (A operand here, B operand of the weight gradient) and the
+            # products run on the bf16 GEMMs -- the fp32-staged kernel rounded the same operands to bf16 in its staging
+            if not _STATE["f32"] and KE % 64 == 0 and F_ % 64 == 0 and (not w.requires_grad or (G * T) % 64 == 0):
+                col = torch.empty(G * T, KE, device=dev, dtype=torch.int16)
+                call("cst_im2col_b", e, col, B, L, E, k, mode, R)
+                y = gemm_bf16(col, weight_bf16(w, (F_, KE))[0], G * T, F_, C=torch.empty(G * T, F_, device=dev, dtype=torch.float32), bias=b, act=1)
+            else:
+                col = torch.empty(G * T, KE, device=dev, dtype=torch.float32)
+                call("cst_im2col", e, col, B, L, E, k, mode, R)
+                y = linear_fwd(col, w.reshape(F_, KE), b, act=1)
             arg = torch.empty(G, F_, device=dev, dtype=torch.int32)
             call("cst_seqmax_fwd", y, feats[:, off:], Ftot, arg, G, T, F_)
             saved += [col, arg]
@@ -1232,6 +1241,7 @@ class ConvBankFn(torch.autograd.Function):
         ctx.save_for_backward(feats, *ws, *saved)
         ctx.cfg = (B, L, E, mode, R, len(ws))
         ctx.fused = fused
+        ctx.wrefs = ws                                     # the parameters themselves (their bf16 twins are keyed by them)
         return feats
 
     @staticmethod
@@ -1264,6 +1274,15 @@ class ConvBankFn(torch.autograd.Function):
                 continue
             T = col.shape[0] // G
             KE = col.shape[1]
+            if col.dtype == torch.int16:                   # the bf16 path of the forward pass
+                dyb = torch.empty(G * T, F_, device=dev, dtype=torch.int16)
+                call("cst_seqmax_bwd_b", dfeats[:, off:], Ftot, arg, feats[:, off:], Ftot, 1, dyb, G, T, F_)
+                grads += [gemm_bf16_tt(dyb, col, F_, KE).view_as(w) if wg else None, colsum_bf16(dyb, F_) if wg else None]
+                if de is not None:
+                    dcol = gemm_bf16(dyb, weight_bf16(ctx.wrefs[i], (F_, KE))[1], G * T, KE, C=torch.empty(G * T, KE, device=dev, dtype=torch.float32))
+                    call("cst_col2im", dcol, de, B, L, E, k, mode, R, int(i > 0))
+                off += F_
+                continue
             dy = torch.empty(G * T, F_, device=dev, dtype=torch.float32)
             call("cst_seqmax_bwd", dfeats[:, off:], Ftot, arg, feats[:, off:], Ftot, 1, dy, G, T, F_)
             w2 = w.reshape(F_, KE)

@@ -480,6 +480,8 @@ int cst_tps_embed_bwd(const float* dx, const int64_t* ids, float* dpre, float* d
 /* im2col for the two convolution stacks: mode 0 = TextCNN (classifier.py:18,30: k x E window,
  * zero padding k-1), mode 1 = RelGAN_D (discriminator.py:21-24,41: k x (E/R) window, stride E/R). */
 int cst_im2col(const float* e, float* col, int B, int L, int E, int k, int mode, int R, void* stream);
+/* the same rows written in bf16 (dense): operands of the bf16 GEMMs of the convolution, no fp32 plane (bf16 mode, k E a multiple of 64) */
+int cst_im2col_b(const float* e, void* col_bf16, int B, int L, int E, int k, int mode, int R, void* stream);
 int cst_col2im(const float* dcol, float* de, int B, int L, int E, int k, int mode, int R, int accumulate, void* stream);
 
 /* One filter size of the RelGAN_D convolution bank, fused: Conv2d(1, F, (k, E/R), stride (1, E/R)) over
@@ -504,6 +506,9 @@ int cst_relconv_bwd_weight(const float* dfeats, long ldd, const float* feats, lo
 int cst_seqmax_fwd(const float* x, float* out, long ldo, int* arg, int G, int T, int F, void* stream);
 int cst_seqmax_bwd(const float* dout, long ldd, const int* arg, const float* y, long ldy, int relu_gate,
                    float* dx, int G, int T, int F, void* stream);
+/* the same gradient in bf16 only ([G T, F] dense): the operand of the bf16 dgrad / weight-gradient products of the convolution */
+int cst_seqmax_bwd_b(const float* dout, long ldd, const int* arg, const float* y, long ldy, int relu_gate,
+                     void* dx_bf16, int G, int T, int F, void* stream);
 
 int cst_dropout(const float* x, long ldx, float* out, long ldo, int R, int C,
                 float drop_p, uint32_t drop_seed, uint32_t drop_stream, const void* drop_seed_dev, void* stream);

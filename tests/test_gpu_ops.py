@@ -768,6 +768,44 @@ def test_conv_bank(ops, mode, B, L, E, R, nf):
         close(wb[2 * i + 1].grad, c.bias.grad, 3e-4, 3e-5)
 
 
+@pytest.mark.parametrize("train_w", [True, False])
+def test_conv_bank_bf16_path(ops, train_w):
+    """TextCNN at the reference constants (classifier.py:18,30: E = 128, 128 filters, k = 3, 4, 5) in bf16 mode: the window rows exist in
+    bf16 only (cst_im2col_b), conv / dgrad / weight gradient run on the bf16 GEMMs (cst_seqmax_bwd_b feeds them), no fp32-staged
+    product.  Against torch on operands rounded to bf16 (what both this path and the staged kernel multiply)."""
+    ops.set_precision("bf16")
+    B, L, E, nf = 64, 14, 128, 128                       # B (L + k - 1) = 1024 / 1088 / 1152: multiples of 64
+    bf = lambda t: t.to(torch.bfloat16).float()
+    e = bf(rnd(B, L, E, seed=1)).requires_grad_(True)
+    convs = [torch.nn.Conv2d(1, nf, (k, E), padding=(k - 1, 0)) for k in (3, 4, 5)]
+    for c in convs:
+        c.weight.data = bf(c.weight.data)
+    ys = [F.relu(c(e.unsqueeze(1))).squeeze(3) for c in convs]
+    ref = torch.cat([F.max_pool1d(y, y.size(2)).squeeze(2) for y in ys], 1)
+    w = rnd(*ref.shape, seed=2)
+    (ref * w).sum().backward()
+    eg = dev(e.detach()).requires_grad_(True)
+    wb = []
+    for c in convs:
+        wb += [dev(c.weight.detach()).requires_grad_(train_w), dev(c.bias.detach()).requires_grad_(train_w)]
+    names = []
+    orig = ops.call
+    ops.call = lambda nm, *a: (names.append(nm), orig(nm, *a))[1]
+    try:
+        out = ops.ConvBankFn.apply(eg, 0, 1, *wb)
+        (out * dev(w)).sum().backward()
+    finally:
+        ops.call = orig
+    assert "cst_gemm" not in names and "cst_im2col" not in names and names.count("cst_im2col_b") == 3, names
+    close(out, ref, 2e-3, 2e-3)
+    # gradients: dy is rounded to bf16 on this path (fp32 in torch)
+    close(eg.grad, e.grad, 2e-2, 2e-2 * float(e.grad.abs().max()))
+    if train_w:
+        for i, c in enumerate(convs):
+            close(wb[2 * i].grad, c.weight.grad, 2e-2, 2e-2 * float(c.weight.grad.abs().max()))
+            close(wb[2 * i + 1].grad, c.bias.grad, 2e-2, 2e-2 * float(c.bias.grad.abs().max()))
+
+
 def test_small_ops(ops):
     from consistent__style_transfer_amd._lib import call
     # highway
