@@ -20,7 +20,7 @@ def stats(path, steps, out):
     rows = list(csv.DictReader(open(path)))
     tot = sum(float(r["TotalDurationNs"]) for r in rows)
     fam = collections.defaultdict(lambda: [0, 0.0])
-    BOTH = "`cst_gemm_bf16_kernel<*>` + `cst_gemm_bf16_pp_kernel<*>` (the bf16 GEMM of cst_gemm_bf16 / _tt: its two kernels together)"
+    BOTH = "`cst_gemm_bf16_kernel<*>` + `cst_gemm_bf16_tt_group_kernel` + `cst_gemm_bf16_pp_kernel<*>` (the bf16 GEMM of cst_gemm_bf16 / _tt: its kernels together)"
     for r in rows:
         n = short(r["Name"])
         f = "cst_gemm_kernel<*>" if n.startswith("cst_gemm_kernel") else ("cst_gemm_bf16_kernel<*>" if n.startswith("cst_gemm_bf16_kernel") else n)
@@ -28,13 +28,14 @@ def stats(path, steps, out):
             f = "cst_gemm_bf16_pp_kernel<*>"
         fam[f][0] += int(r["Calls"])
         fam[f][1] += float(r["TotalDurationNs"])
-        if f in ("cst_gemm_bf16_kernel<*>", "cst_gemm_bf16_pp_kernel<*>"):
+        if f in ("cst_gemm_bf16_kernel<*>", "cst_gemm_bf16_pp_kernel<*>", "cst_gemm_bf16_tt_group_kernel"):
             fam[BOTH][0] += int(r["Calls"])
             fam[BOTH][1] += float(r["TotalDurationNs"])
     with open(out, "w") as f:
         f.write(f"rocprofv3 --kernel-trace --stats, {steps} steps: total kernel time {tot / 1e6:.2f} ms = {tot / 1e6 / steps:.2f} ms/step\n")
-        f.write("(the first row is the SUM of the two rows of the bf16 GEMM's kernels below it -- the big-tile ping-pong kernel of csrc/gemm_pp.hip takes the shapes it wins,\n"
-                " the LDS-DMA tile kernels of csrc/gemm_bf16.hip the rest and all weight-gradient (TT) products; bench.py's roofline.kernel is this family)\n\n")
+        f.write("(the first row is the SUM of the rows of the bf16 GEMM's kernels below it -- the big-tile ping-pong kernel of csrc/gemm_pp.hip takes the shapes it wins,\n"
+                " the LDS-DMA tile kernels of csrc/gemm_bf16.hip the rest, the grouped launch of the same tile body the weight gradients of a layer / of the generator;\n"
+                " bench.py's roofline.kernel is this family, its member cst_gemm_bf16_kernel = the tile kernels + the grouped launches)\n\n")
         f.write("| kernel (family) | calls/step | total ms/step | avg us | % |\n|---|---|---|---|---|\n")
         for k, (c, t) in sorted(fam.items(), key=lambda kv: -kv[1][1])[:29]:
             name = k if k == BOTH else f"`{k}`"
@@ -53,7 +54,7 @@ def pmc(fetch, write, out, workload="yelp_6l_d768_b256"):
                 continue
             k = short(r["Kernel_Name"])
             k = "cst_gemm_kernel" if k.startswith("cst_gemm_kernel") else k
-            k = "cst_gemm_bf16_kernel" if k.startswith("cst_gemm_bf16_kernel") else k
+            k = "cst_gemm_bf16_kernel" if (k.startswith("cst_gemm_bf16_kernel") or k.startswith("cst_gemm_bf16_tt_group_kernel")) else k
             k = "cst_gemm_bf16_pp_kernel" if "cst_gemm_bf16_pp_kernel" in k else k
             d[k][0] += 1
             d[k][1] += float(r["Counter_Value"])
