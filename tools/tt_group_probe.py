@@ -53,10 +53,10 @@ for T, d, F, note in ((9216, 768, 2048, "Matcher d768"), (4608, 768, 2048, "MLM 
                 with ops.tt_group(deferrable=True):
                     four()
 
-    t4, tg = timeit(four), timeit(grouped)
-    t2 = timeit(two_layers) / 2
     from consistent__style_transfer_amd._lib import call_plain
-    S = call_plain("cst_gemm_bf16_tt_group_last_splits")
+    t4, tg = timeit(four), timeit(grouped)
+    S = call_plain("cst_gemm_bf16_tt_group_last_splits")          # of the one-layer group (0: launched product by product)
+    t2 = timeit(two_layers) / 2
     fl = 2.0 * T * (2 * d * F + 4 * d * d)
     tiles = 2 * (-(-d // 128)) * (F // 128) + (-(-d // 128)) ** 2 + (-(-3 * d // 128)) * (-(-d // 128))
     print(f"{note:16s} T={T:6d} d={d} ({tiles} tiles): one by one {t4:7.1f} us ({fl / t4 / 1e6:4.0f} TF/s)   grouped {tg:7.1f} us ({fl / tg / 1e6:4.0f} TF/s, {S} split{'s' if S != 1 else ''})   two layers per launch {t2:7.1f} us a layer ({fl / t2 / 1e6:4.0f} TF/s)", flush=True)
