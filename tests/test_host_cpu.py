@@ -375,3 +375,98 @@ def test_evaluate_prepare_and_eval_pipeline(tmp_path):
     assert res["same"]["NT"] == 1.0                                    # identical texts tie: every pair is a success
     assert res["flip"]["STI"] > 0.0                                     # flipping sentiment words moves probability to the target class
     assert ev.main(["eval"]) == 2
+
+
+# ---- host logic of the grouped weight-gradient launches (ops.tt_group / tt_deferred / gen_fn.shared_param_grads): no GPU, the C ABI is
+# ---- replaced by a recorder; what is checked is WHEN the group is opened, launched and closed, what is kept alive, and what is verified
+def _tt_recorder(monkeypatch):
+    from consistent__style_transfer_amd import ops
+    calls = []
+
+    def fake_call(name, *a):
+        calls.append(name)
+
+    monkeypatch.setattr(ops, "call", fake_call)
+    monkeypatch.setattr(ops, "WS_FLOATS", 64)
+    monkeypatch.setattr(ops, "_workspace", lambda dev: torch.zeros(64 + ops.WS_COUNTERS))
+    monkeypatch.setattr(torch.cuda, "current_device", lambda: 0)
+    for k, v in (("open", False), ("depth", 0), ("defer", 0), ("n", 0)):
+        ops._TT[k] = v
+    ops._TT["keep"].clear()
+    ops._TT["owners"].clear()
+    return ops, calls
+
+
+def _tt_operands(K=64, M=8, N=8):
+    return torch.zeros(K, M, dtype=torch.int16), torch.zeros(K, N, dtype=torch.int16)
+
+
+def test_tt_group_launches_at_block_end_and_in_batches_of_eight(monkeypatch):
+    ops, calls = _tt_recorder(monkeypatch)
+    A, B = _tt_operands()
+    ops.gemm_bf16_tt(A, B, 8, 8)                                   # no group: an ordinary product
+    assert calls == ["cst_gemm_bf16_tt"]
+    calls.clear()
+    with ops.tt_group():
+        for _ in range(11):
+            ops.gemm_bf16_tt(A, B, 8, 8)
+        assert ops._TT["open"] and ops._TT["n"] == 3 and len(ops._TT["keep"]) == 3      # 8 went out when the ninth arrived
+    assert calls == (["cst_gemm_bf16_tt_group_begin"] + ["cst_gemm_bf16_tt"] * 8 + ["cst_gemm_bf16_tt_group_end", "cst_gemm_bf16_tt_group_begin"]
+                     + ["cst_gemm_bf16_tt"] * 3 + ["cst_gemm_bf16_tt_group_end"])
+    assert not ops._TT["open"] and ops._TT["depth"] == 0 and not ops._TT["keep"]
+    # the group is closed on an error path too, and what was recorded is launched
+    calls.clear()
+    with pytest.raises(ValueError):
+        with ops.tt_group():
+            ops.gemm_bf16_tt(A, B, 8, 8)
+            raise ValueError("boom")
+    assert calls[-1] == "cst_gemm_bf16_tt_group_end" and not ops._TT["open"] and ops._TT["depth"] == 0
+
+
+def test_tt_deferred_keeps_groups_open_checks_owners_and_runs_foreign_products_at_once(monkeypatch):
+    ops, calls = _tt_recorder(monkeypatch)
+    A, B = _tt_operands()
+    W = [torch.nn.Parameter(torch.zeros(8, 8)) for _ in range(3)]
+    outs = []
+    with ops.tt_deferred():
+        for w in W[:2]:
+            with ops.tt_group(deferrable=True):
+                outs.append(ops.gemm_bf16_tt(A, B, 8, 8, owner=w))
+            assert ops._TT["open"] and ops._TT["depth"] == 0           # the block ended, the launch did not happen
+        # a product outside any group while the deferred group is open: recorded nowhere, run at once (splitk -1 in the C ABI)
+        n_before = ops._TT["n"]
+        ops.gemm_bf16_tt(A, B, 8, 8)
+        assert ops._TT["n"] == n_before
+        # a group that may not be deferred launches what is pending first, then itself at its end
+        with ops.tt_group():
+            ops.gemm_bf16_tt(A, B, 8, 8)
+        assert not ops._TT["open"]
+        with ops.tt_group(deferrable=True):
+            outs.append(ops.gemm_bf16_tt(A, B, 8, 8, owner=W[2]))
+        for w, o in zip(W, outs):                                      # what autograd does with a gradient it takes: the tensor itself
+            w.grad = o
+    assert calls.count("cst_gemm_bf16_tt_group_begin") == calls.count("cst_gemm_bf16_tt_group_end") == 3
+    assert not ops._TT["open"] and not ops._TT["owners"] and not ops._TT["keep"] and ops._TT["defer"] == 0
+    # an output that was copied instead of taken is reported when the deferred block ends
+    with pytest.raises(RuntimeError, match="copied or replaced"):
+        with ops.tt_deferred():
+            with ops.tt_group(deferrable=True):
+                o = ops.gemm_bf16_tt(A, B, 8, 8, owner=W[0])
+            W[0].grad = o.clone()
+    assert not ops._TT["open"] and not ops._TT["owners"] and ops._TT["defer"] == 0
+    # only layers small enough are deferred by the encoder layer: the switch it uses
+    assert ops.TT_DEFER_MAX_TILES == 256 and ops.TT_GROUP_MAX == 8
+
+
+def test_shared_param_grads_adds_the_second_backward_into_the_first(monkeypatch):
+    """gen_fn.shared_param_grads: two uses of one parameter set inside the block -> the backward that runs second adds into the tensors
+    of the first and hands autograd nothing for them; outside the block (or on another stream) autograd sums as ever."""
+    from consistent__style_transfer_amd import gen_fn
+    assert gen_fn._GRAD_SHARE[0] is None
+    with gen_fn.shared_param_grads():
+        tok = gen_fn._GRAD_SHARE[0]
+        assert tok == {}
+        with gen_fn.shared_param_grads():                               # nests: the inner block has its own token
+            assert gen_fn._GRAD_SHARE[0] is not tok
+        assert gen_fn._GRAD_SHARE[0] is tok
+    assert gen_fn._GRAD_SHARE[0] is None
