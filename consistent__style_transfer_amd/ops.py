@@ -868,8 +868,8 @@ def _mm(Ab, opnd, M, N, **kw):
 
 class EncoderLayerBf16Fn(torch.autograd.Function):
     """The same layer as EncoderLayerFn on the bf16-operand GEMMs (cst_gemm_bf16 / cst_gemm_bf16_tt, direct-to-LDS
-    ring).  Forward and dgrad products read K-contiguous bf16 copies (activations cast once, weights cached per
-    optimizer version, transposed weight copies for dgrad); the weight gradients dW = dY^T X read the SAME
+    ring).  Forward and dgrad products read K-contiguous bf16 copies (activations cast once, weight twins refreshed once per
+    optimizer version by one launch per group, transposed weight copies for dgrad); the weight gradients dW = dY^T X read the SAME
     row-major activation copies through the transposed-LDS-read variant, so no activation is ever transposed
     in HBM (token counts that are not multiples of 64 -- toy shapes -- keep the transposed-copy path).  The FFN
     hidden state and its gradient exist ONLY in bf16.  Residual stream, LayerNorm, attention core and all
