@@ -234,13 +234,12 @@ _WCACHE_CAPTURE = {}
 def weight_bf16(W, shape2d=None):
     """bf16 row-major + transposed copies of a weight (shape2d: the [N, K] matrix a convolution weight is used as).
 
-    Frozen weights (no optim.FlatGroup owns them: the critics of the optimize stage, modules in
-    eval/transfer use) are cast once and cached; the key is the torch in-place version
-    (load_state_dict, .copy_) and the storage address.  TRAINED weights are cached only between
-    eager calls of one optimizer version and are ALWAYS recast while a hipGraph is being captured:
-    a capture must not bake in a cached tensor, because replays have to see the weights Adam has
-    updated since (and the cached tensor would be freed when the cache entry is replaced); within one
-    capture they are shared between the uses that see the same optimizer version."""
+    TRAINED weights (an optim.FlatGroup owns them) live in persistent per-group twin buffers (_GroupTwins): all twins of a group
+    are rewritten by ONE launch at the group's first use after each optimizer step -- and at the first use inside every hipGraph
+    capture, whatever the eager state says, so that replays redo it after every captured Adam step.  Weights that do not qualify
+    (first met while capturing, odd layouts) take the per-weight path below: cached between eager calls of one optimizer version,
+    recast inside a capture and shared only within it.  FROZEN weights (the critics of the optimize stage, modules in eval /
+    transfer use) are cast once and cached; the key is the torch in-place version (load_state_dict, .copy_) and the storage address."""
     grp = getattr(W, "_cst_group", None)
     capturing = torch.cuda.is_current_stream_capturing()
     Wd = W.detach() if shape2d is None else W.detach().view(shape2d)
